@@ -7,7 +7,7 @@
 // exposes through its getters, so the C restatement in oracle/fm_oracle.c (and
 // through it the HIP path) can be pinned against the real thing.
 //
-//   fm_ref_dump chain     <capture.u8>   <outdir> <block_size>   App::Process path (u8 ingest)
+//   fm_ref_dump chain     <capture.u8>   <outdir> <block_size> [deemph=us audio=lpr|lmr|stereo mix=f lpr=hz lmr=hz]   App::Process path (u8 ingest)
 //   fm_ref_dump cf32chain <capture.cf32> <outdir> <block_size>   Broadcast_FM_Demod::Process path
 //   fm_ref_dump prims     <indir>        <outdir>                per-primitive vectors
 //
@@ -111,12 +111,31 @@ struct ChainDump {
     }
 };
 
-static int run_chain(const char* in, const char* outdir, int block_size) {
+// optional key=value arguments -> Broadcast_FM_Demod_Controls (reference broadcast_fm_demod.h:64-89)
+static void apply_controls(Broadcast_FM_Demod& d, int argc, char** argv) {
+    auto& c = d.GetControls();
+    for (int i = 0; i < argc; i++) {
+        const char* a = argv[i];
+        if (!strncmp(a, "deemph=", 7)) { c.is_use_deemphasis_filter = true; c.filt_deemphasis_cutoff.SetValue(atoi(a + 7)); }
+        else if (!strncmp(a, "audio=", 6)) {
+            if (!strcmp(a + 6, "lpr")) c.audio_out = Broadcast_FM_Demod_Controls::LPR;
+            else if (!strcmp(a + 6, "lmr")) c.audio_out = Broadcast_FM_Demod_Controls::LMR;
+            else c.audio_out = Broadcast_FM_Demod_Controls::STEREO;
+        }
+        else if (!strncmp(a, "mix=", 4)) c.audio_stereo_mix_factor = (float)atof(a + 4);
+        else if (!strncmp(a, "lpr=", 4)) c.filt_audio_lpr_cutoff.SetValue(atoi(a + 4));
+        else if (!strncmp(a, "lmr=", 4)) c.filt_audio_lmr_cutoff.SetValue(atoi(a + 4));
+        else { fprintf(stderr, "unknown control %s\n", a); exit(2); }
+    }
+}
+
+static int run_chain(const char* in, const char* outdir, int block_size, int argc, char** argv) {
     Sink sink{outdir};
     ChainDump dump(sink);
     auto data = slurp<std::complex<uint8_t>>(in);
     App app(block_size);
     auto& demod = app.GetFMDemod();
+    apply_controls(demod, argc, argv);
     app.OnAudioBlock().Attach([&](tcb::span<const Frame<float>> x, const int Fs) { (void)Fs; dump.on_block(demod, x); });
     app.On_RDS_Bytes().Attach([&](tcb::span<const uint8_t> x) { put(dump.rds_bytes, x.data(), x.size()); });
     const size_t n_blocks = data.size() / (size_t)block_size;
@@ -133,11 +152,12 @@ static int run_chain(const char* in, const char* outdir, int block_size) {
     return 0;
 }
 
-static int run_cf32chain(const char* in, const char* outdir, int block_size) {
+static int run_cf32chain(const char* in, const char* outdir, int block_size, int argc, char** argv) {
     Sink sink{outdir};
     ChainDump dump(sink);
     auto data = slurp<cf32>(in);
     Broadcast_FM_Demod demod(block_size);
+    apply_controls(demod, argc, argv);
     uint8_t bytes_buf[16];
     DifferentialManchesterDecoder manchester{tcb::span<uint8_t>(bytes_buf, 16)};
     demod.OnAudioOut().Attach([&](tcb::span<const Frame<float>> x, const int Fs) { (void)Fs; dump.on_block(demod, x); });
@@ -276,8 +296,8 @@ static int run_prims(const char* indir, const char* outdir) {
 }
 
 int main(int argc, char** argv) {
-    if (argc >= 5 && !strcmp(argv[1], "chain")) return run_chain(argv[2], argv[3], atoi(argv[4]));
-    if (argc >= 5 && !strcmp(argv[1], "cf32chain")) return run_cf32chain(argv[2], argv[3], atoi(argv[4]));
+    if (argc >= 5 && !strcmp(argv[1], "chain")) return run_chain(argv[2], argv[3], atoi(argv[4]), argc - 5, argv + 5);
+    if (argc >= 5 && !strcmp(argv[1], "cf32chain")) return run_cf32chain(argv[2], argv[3], atoi(argv[4]), argc - 5, argv + 5);
     if (argc >= 4 && !strcmp(argv[1], "prims")) return run_prims(argv[2], argv[3]);
     fprintf(stderr, "usage: fm_ref_dump chain|cf32chain <in> <outdir> <block> | prims <indir> <outdir>\n");
     return 1;
