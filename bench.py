@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the MI355X FM demodulation hot path (driver contract: see the round prompt).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N>1: launched under torch.distributed.run)
+
+One "step" = one `fmd_process_cf32_dev` call = one block of every channel through the whole chain
+(decimating FIRs -> discriminator -> Hilbert -> pilot PLL -> x2/x3 mixers -> audio/RDS decimators -> stereo mix,
+RDS AGC + BPSK symbol sync + Manchester).  Workload at N=1: BASELINE.json configs[2] — 4096 synthetic FM channels
+@ 256 kSa/s batched on one MI355X, 16384-sample blocks (64 ms), inputs resident in HBM before the timed region.
+Channels shard across ranks (weak scaling: 4096 per GPU); the only collective is the per-step audio all-gather
+(RCCL), overlapped with the next step's compute.
+
+The JSON line carries `roofline` (dominant kernel, HIP-event timed inside the library on the processing stream)
+and, on rank 0 at N=1, `cpu_baseline` (the CPU oracle = port of the reference, all host cores, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+for p in (ROOT, ROOT / "tests", ROOT / "oracle"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_PEAK_TFLOPS = 157.3
+
+
+def algorithmic_bytes_per_sample(fs: int, u8: bool) -> float:
+    """cf32 (or u8) IQ in + stereo f32 audio out + RDS symbol floats out, per baseband sample."""
+    in_b = 2.0 if u8 else 8.0
+    audio = 8.0 * 32000.0 / fs
+    syms = 4.0 * 2375.0 / fs
+    return in_b + audio + syms
+
+
+def synth_block_device(torch, n_ch: int, n_total: int, fs: float, seed: int, device, u8: bool, chunk: int = 256):
+    """Synthetic multi-channel FM baseband on the GPU: stereo tones + pilot + L-R DSB-SC + BPSK RDS at 57 kHz, FM 75 kHz
+    deviation, noise 0.02/rail, scaled x100 (the RTL-SDR u8 amplitude) — the SURVEY §8(d) recipe.  Returns [C, n_total, 2]."""
+    out = torch.empty((n_ch, n_total, 2), dtype=torch.uint8 if u8 else torch.float32, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    t = torch.arange(n_total, device=device, dtype=torch.float64) / fs
+    two_pi = 2.0 * np.pi
+    for c0 in range(0, n_ch, chunk):
+        c1 = min(n_ch, c0 + chunk)
+        m = c1 - c0
+        jit = 1.0 + 0.05 * (2.0 * torch.rand((m, 4), generator=g, device=device, dtype=torch.float64) - 1.0)
+        ph = two_pi * torch.rand((m, 4), generator=g, device=device, dtype=torch.float64)
+        tt = t[None, :]
+        left = 0.5 * torch.sin(two_pi * 1000.0 * jit[:, 0:1] * tt + ph[:, 0:1]) + 0.3 * torch.sin(two_pi * 3300.0 * jit[:, 1:2] * tt + ph[:, 1:2])
+        right = 0.5 * torch.sin(two_pi * 440.0 * jit[:, 2:3] * tt + ph[:, 2:3]) + 0.3 * torch.sin(two_pi * 5000.0 * jit[:, 3:4] * tt + ph[:, 3:4])
+        n_sym = int(np.ceil(n_total / fs * 2375.0)) + 4
+        bits = torch.randint(0, 2, (m, n_sym // 2 + 2), generator=g, device=device)
+        diff = torch.cumsum(bits, dim=1) % 2
+        lvl = 2.0 * diff.to(torch.float64) - 1.0
+        sym = torch.stack([lvl, -lvl], dim=2).reshape(m, -1)
+        idx = torch.floor(t * 2375.0).to(torch.int64)
+        rds = sym[:, idx]
+        p = two_pi * 19000.0 * tt
+        mpx = 0.40 * (left + right) / 1.6 + 0.10 * torch.sin(p) + 0.40 * (left - right) / 1.6 * torch.sin(2.0 * p) + 0.06 * rds * torch.sin(3.0 * p)
+        phase = two_pi * 75000.0 * torch.cumsum(mpx, dim=1) / fs
+        i = torch.cos(phase) + 0.02 * torch.randn((m, n_total), generator=g, device=device, dtype=torch.float64)
+        q = torch.sin(phase) + 0.02 * torch.randn((m, n_total), generator=g, device=device, dtype=torch.float64)
+        iq = torch.stack([i, q], dim=2)
+        if u8:
+            out[c0:c1] = torch.clamp(torch.round(127.0 + 100.0 * iq), 0, 255).to(torch.uint8)
+        else:
+            out[c0:c1] = (100.0 * iq).to(torch.float32)
+        del left, right, rds, mpx, phase, i, q, iq, sym, lvl, diff, bits
+    return out
+
+
+def cpu_baseline(fs: int, block: int, budget_s: float = 12.0) -> dict:
+    """The CPU oracle (a port of the reference's scalar/AVX path, oracle/fm_oracle.c) on every host core: one
+    independent single-channel demodulator per thread (the reference is single-threaded per station), each fed
+    its own synthetic capture for `budget_s` seconds of wall time.  Checker code, used here only as the baseline."""
+    import oraclelib as O
+    import synth
+    n_thr = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_blk = 8
+    caps = [synth.to_cf32(synth.fm_capture(n_blk * block, fs=float(fs), seed=4000, channel=i)["iq"]) for i in range(min(n_thr, 4))]
+    O.lib()
+    counts = [0] * n_thr
+    stop_at = [0.0]
+
+    def work(i):
+        d = O.Demod(block, fs)
+        cap = caps[i % len(caps)]
+        k = 0
+        while time.perf_counter() < stop_at[0]:
+            d.process_cf32(cap[(k % n_blk) * block:(k % n_blk + 1) * block])
+            k += 1
+        counts[i] = k
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(n_thr)]
+    t0 = time.perf_counter()
+    stop_at[0] = t0 + budget_s
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    el = time.perf_counter() - t0
+    total = sum(counts) * block
+    return {"value": total / el / 1e6, "unit": "MSa/s", "cores": n_thr, "kind": "port",
+            "sample": f"{sum(counts)} blocks of {block} cf32 samples @ {fs} Sa/s over {n_thr} threads in {el:.1f} s (oracle/fm_oracle.c, one demodulator per thread)"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--channels", type=int, default=4096, help="channels PER GPU (BASELINE configs[2]: 4096)")
+    ap.add_argument("--fs", type=int, default=256000, choices=[256000, 1024000, 2048000])
+    ap.add_argument("--block", type=int, default=0, help="baseband samples per channel per step (default: 64 ms)")
+    ap.add_argument("--u8", action="store_true", help="u8 IQ ingest (2 B/sample) instead of cf32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the per-step audio all-gather at N>1")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import fmradio_loader
+    pkg = fmradio_loader.load()
+    pkg.load_library()  # raises when the HIP extension is missing: there is no fallback to measure
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    fs = args.fs
+    block = args.block or (fs * 64 // 1000)
+    C = args.channels
+    K, W = args.steps, args.warmup
+    n_blocks_resident = min(K + W, 8)  # distinct consecutive blocks kept in HBM, cycled
+    x = synth_block_device(torch, C, n_blocks_resident * block, float(fs), 1234 + rank, device, args.u8)
+    x = x.view(C, n_blocks_resident, block, 2).permute(1, 0, 2, 3).contiguous()  # [blocks][C][N][2]
+    dm = pkg.BatchDemod(C, block, fs, device=local_rank)
+    stream = torch.cuda.current_stream(device)
+
+    do_gather = world > 1 and not args.no_gather
+    if do_gather:
+        n_audio = dm.rates.n_audio
+        stage = [torch.empty((C, n_audio, 2), dtype=torch.float32, device=device) for _ in range(2)]
+        gathered = [torch.empty((world * C, n_audio, 2), dtype=torch.float32, device=device) for _ in range(2)]
+        handles = [None, None]
+        audio_view = dm.audio_tensor()
+
+    def step(k: int):
+        dm.process(x[k % n_blocks_resident])
+        if do_gather:
+            s = k & 1
+            if handles[s] is not None:
+                handles[s].wait()
+            stage[s].copy_(audio_view, non_blocking=True)
+            handles[s] = dist.all_gather_into_tensor(gathered[s], stage[s], async_op=True)
+
+    def drain():
+        if do_gather:
+            for i in range(2):
+                if handles[i] is not None:
+                    handles[i].wait()
+                    handles[i] = None
+
+    for k in range(W):
+        step(k)
+    drain()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    dm.profile(True)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        step(k)
+    drain()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    el = time.perf_counter() - t0
+    dm.profile(False)
+    if world > 1:
+        tmax = torch.tensor([el], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+    ktimes = dm.profile_read()
+
+    samples_per_step = C * block * world
+    value = samples_per_step * K / el / 1e6
+    bps = algorithmic_bytes_per_sample(fs, args.u8)
+
+    # dominant kernel by accumulated HIP-event time on this rank
+    dom = max(ktimes.items(), key=lambda kv: kv[1][0]) if ktimes else (None, (0.0, 0))
+    roofline = None
+    if dom[0]:
+        avg_ms = dom[1][0] / max(dom[1][1], 1)
+        algo_bytes = bps * C * block  # per launch: every kernel launch covers one block of all local channels
+        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = ROOT / "profiles" / "hbm_traffic.json"
+        if tf.exists():
+            try:
+                tj = json.loads(tf.read_text())
+                key = f"{dom[0]}|C={C}|fs={fs}|block={block}|{'u8' if args.u8 else 'cf32'}"
+                traffic = tj.get(key)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
+                    "algorithmic_bytes_per_launch": algo_bytes,
+                    "whole_step_frac": (bps * C * block * K / el / 1e9) / HBM_PEAK_GBS if world == 1 else None,
+                    "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in ktimes.items()}}
+
+    out = {
+        "metric": "IQ MSamples/sec demodulated to stereo+RDS per GPU; channels @ real-time",
+        "value": value,
+        "unit": "MSa/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": el / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[2]: {C} synthetic FM channels/GPU @ {fs} Sa/s, {block}-sample blocks, "
+                               f"{'u8' if args.u8 else 'cf32'} IQ resident in HBM, full stereo + pilot PLL + RDS",
+                   "channels_per_gpu": C, "fs_baseband": fs, "block_size": block, "ingest": "u8" if args.u8 else "cf32",
+                   "parallelism": f"channel-sharded x{world}" + (", per-step audio all-gather (RCCL)" if do_gather else "")},
+        "channels_at_realtime": value * 1e6 / fs,
+        "msa_per_gpu": value / world,
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        dm.close()
+        del x
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline(fs, block)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,248 @@
+"""ctypes binding of libfmdemod.so (include/fmdemod.h) + a small batched-demodulator wrapper.
+
+`BatchDemod` mirrors the reference's `Broadcast_FM_Demod` usage (construct with a block size, call
+`process`, read audio / RDS symbols; reference src/fm_demod/broadcast_fm_demod.h:229-298) for C
+channels at once.  It only moves pointers: inputs may be torch CUDA tensors (zero-copy, device entry
+points) or numpy arrays (host entry points).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+ROOT = PKG_DIR.parent
+CSRC = PKG_DIR / "csrc"
+HEADER = ROOT / "include" / "fmdemod.h"
+
+FMD_AUDIO_LPR, FMD_AUDIO_LMR, FMD_AUDIO_STEREO = 0, 1, 2
+FMD_FLAG_KEEP_TAPS = 1
+FMD_OK, FMD_ERR_ARG, FMD_ERR_SIZE, FMD_ERR_DEVICE, FMD_ERR_NO_DEVICE, FMD_ERR_NAME = 0, -1, -2, -3, -4, -5
+
+
+class FmdError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"fmdemod status {status}: {msg}")
+        self.status = status
+
+
+class Config(C.Structure):
+    _fields_ = [("n_channels", C.c_int), ("block_size", C.c_int), ("fs_baseband", C.c_int), ("device", C.c_int), ("flags", C.c_uint)]
+
+
+class Controls(C.Structure):
+    _fields_ = [("audio_out", C.c_int), ("audio_stereo_mix_factor", C.c_float), ("use_deemphasis", C.c_int),
+                ("deemphasis_tus", C.c_int), ("lpr_cutoff_hz", C.c_int), ("lmr_cutoff_hz", C.c_int)]
+
+
+class Rates(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("fs_baseband", "fs_fm_in", "fs_fm_out", "fs_rds", "fs_audio",
+                                       "n_baseband", "n_fm_in", "n_fm_out", "n_rds", "n_audio")]
+
+
+class Coeffs(C.Structure):
+    _fields_ = [("fs_baseband", C.c_int), ("m_fm_in", C.c_int), ("b_fm_in", C.c_float * 64), ("b_fm_out", C.c_float * 64),
+                ("b_hilbert", C.c_float * 65), ("pilot_b", C.c_float * 3), ("pilot_a", C.c_float * 3),
+                ("pll_lpf_b", C.c_float * 2), ("pll_lpf_a", C.c_float * 2), ("deemph_b", C.c_float * 2), ("deemph_a", C.c_float * 2),
+                ("b_lpr", C.c_float * 128), ("b_lmr", C.c_float * 128), ("b_rds", C.c_float * 128),
+                ("ted_lpf_b", C.c_float * 2), ("ted_lpf_a", C.c_float * 2), ("bpsk_lpf_b", C.c_float * 2), ("bpsk_lpf_a", C.c_float * 2),
+                ("fm_gain", C.c_float)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_int)]
+
+
+def lib_path() -> Path:
+    return CSRC / "libfmdemod.so"
+
+
+def build_library(force: bool = False) -> Path:
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-s", "-C", str(CSRC), "clean"], check=True)
+    subprocess.run(["make", "-s", "-C", str(CSRC)], check=True)
+    return lib_path()
+
+
+def declared_symbols() -> list[str]:
+    """Every function include/fmdemod.h declares."""
+    text = HEADER.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fmd_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def load_library():
+    """Load libfmdemod.so; raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not p.exists():
+        raise FileNotFoundError(f"{p} missing: run __graft_entry__.build() / make -C {CSRC}")
+    L = C.CDLL(str(p))
+    H = C.c_void_p
+    L.fmd_api_version.restype = C.c_int
+    L.fmd_status_string.restype = C.c_char_p
+    L.fmd_status_string.argtypes = [C.c_int]
+    L.fmd_device_count.restype = C.c_int
+    L.fmd_default_controls.argtypes = [C.POINTER(Controls)]
+    L.fmd_create.argtypes = [C.POINTER(Config), C.POINTER(H)]
+    L.fmd_destroy.argtypes = [H]
+    L.fmd_reset.argtypes = [H]
+    L.fmd_set_controls.argtypes = [H, C.c_int, C.POINTER(Controls)]
+    L.fmd_get_controls.argtypes = [H, C.c_int, C.POINTER(Controls)]
+    L.fmd_get_rates.argtypes = [H, C.POINTER(Rates)]
+    L.fmd_get_coeffs.argtypes = [H, C.c_int, C.POINTER(Coeffs)]
+    for name in ("fmd_process_cf32_dev", "fmd_process_u8_dev"):
+        getattr(L, name).argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    for name in ("fmd_process_cf32_host", "fmd_process_u8_host"):
+        getattr(L, name).argtypes = [H, C.c_void_p, C.c_int, C.c_int]
+    L.fmd_synchronize.argtypes = [H]
+    L.fmd_audio_dev.argtypes = [H, C.POINTER(C.c_void_p)]
+    L.fmd_rds_dev.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.fmd_get_audio.argtypes = [H, C.c_void_p]
+    L.fmd_get_rds_symbols.argtypes = [H, C.c_void_p, C.c_void_p]
+    L.fmd_get_rds_bytes.argtypes = [H, C.c_void_p, C.c_int, C.c_void_p]
+    L.fmd_get_stream.argtypes = [H, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.fmd_profile_enable.argtypes = [H, C.c_int]
+    L.fmd_profile_read.argtypes = [H, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]
+    L.fmd_last_error.restype = C.c_char_p
+    L.fmd_last_error.argtypes = [H]
+    _lib = L
+    return L
+
+
+def default_controls() -> Controls:
+    c = Controls()
+    load_library().fmd_default_controls(C.byref(c))
+    return c
+
+
+class BatchDemod:
+    """C broadcast-FM demodulators advanced in lock-step on one MI355X."""
+
+    def __init__(self, n_channels: int, block_size: int = 65536, fs_baseband: int = 1_024_000, device: int = -1, keep_taps: bool = False):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        cfg = Config(n_channels, block_size, fs_baseband, device, FMD_FLAG_KEEP_TAPS if keep_taps else 0)
+        rc = self.L.fmd_create(C.byref(cfg), C.byref(self.h))
+        if rc != FMD_OK:
+            msg = self.L.fmd_last_error(None).decode()
+            self.h = None
+            raise FmdError(rc, msg or self.L.fmd_status_string(rc).decode())
+        self.n_channels, self.block_size, self.fs_baseband = n_channels, block_size, fs_baseband
+        r = Rates()
+        self._check(self.L.fmd_get_rates(self.h, C.byref(r)))
+        self.rates = r
+        self.bytes_cap = 16 * (r.n_rds // 256 + 1)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fmd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != FMD_OK:
+            raise FmdError(rc, self.L.fmd_last_error(self.h).decode() or self.L.fmd_status_string(rc).decode())
+
+    # -- controls (reference GetControls(), broadcast_fm_demod.h:294) --
+    def set_controls(self, controls: Controls, channel: int = -1):
+        self._check(self.L.fmd_set_controls(self.h, channel, C.byref(controls)))
+
+    def get_coeffs(self, channel: int = 0) -> Coeffs:
+        k = Coeffs()
+        self._check(self.L.fmd_get_coeffs(self.h, channel, C.byref(k)))
+        return k
+
+    def reset(self):
+        self._check(self.L.fmd_reset(self.h))
+
+    # -- Process (reference broadcast_fm_demod.cpp:309-328) --
+    def process(self, iq, stream=None) -> int:
+        """iq: [C, N, 2] float32 or uint8; torch CUDA tensor (device entry point) or numpy array (host entry point).
+        Returns the status code (FMD_ERR_SIZE for a dropped block) without raising for size mismatches."""
+        is_torch = hasattr(iq, "data_ptr")
+        shape = tuple(iq.shape)
+        if len(shape) != 3 or shape[2] != 2:
+            raise ValueError("iq must be [C, N, 2]")
+        if is_torch:
+            import torch
+            if not iq.is_cuda or not iq.is_contiguous():
+                raise ValueError("torch input must be a contiguous CUDA tensor")
+            if stream is None:
+                stream = torch.cuda.current_stream(iq.device).cuda_stream
+            fn = {torch.float32: self.L.fmd_process_cf32_dev, torch.uint8: self.L.fmd_process_u8_dev}[iq.dtype]
+            rc = fn(self.h, iq.data_ptr(), shape[0], shape[1], C.c_void_p(stream))
+        else:
+            a = np.ascontiguousarray(iq)
+            fn = {np.dtype(np.float32): self.L.fmd_process_cf32_host, np.dtype(np.uint8): self.L.fmd_process_u8_host}[a.dtype]
+            rc = fn(self.h, a.ctypes.data_as(C.c_void_p), shape[0], shape[1])
+        if rc not in (FMD_OK, FMD_ERR_SIZE):
+            self._check(rc)
+        return rc
+
+    def synchronize(self):
+        self._check(self.L.fmd_synchronize(self.h))
+
+    # -- outputs --
+    def audio(self) -> np.ndarray:
+        out = np.empty((self.n_channels, self.rates.n_audio, 2), np.float32)
+        self._check(self.L.fmd_get_audio(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def rds_symbols(self) -> tuple[np.ndarray, np.ndarray]:
+        syms = np.empty((self.n_channels, self.rates.n_rds), np.float32)
+        counts = np.empty(self.n_channels, np.int32)
+        self._check(self.L.fmd_get_rds_symbols(self.h, syms.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p)))
+        return syms, counts
+
+    def rds_bytes(self) -> tuple[np.ndarray, np.ndarray]:
+        b = np.zeros((self.n_channels, self.bytes_cap), np.uint8)
+        counts = np.empty(self.n_channels, np.int32)
+        self._check(self.L.fmd_get_rds_bytes(self.h, b.ctypes.data_as(C.c_void_p), self.bytes_cap, counts.ctypes.data_as(C.c_void_p)))
+        return b, counts
+
+    def stream(self, name: str) -> np.ndarray:
+        n = C.c_size_t(0)
+        probe = np.empty(1, np.float32)
+        self.L.fmd_get_stream(self.h, name.encode(), probe.ctypes.data_as(C.c_void_p), 0, C.byref(n))
+        if n.value == 0:
+            self._check(self.L.fmd_get_stream(self.h, name.encode(), probe.ctypes.data_as(C.c_void_p), 0, C.byref(n)))
+        out = np.empty(n.value, np.float32)
+        self._check(self.L.fmd_get_stream(self.h, name.encode(), out.ctypes.data_as(C.c_void_p), out.size, C.byref(n)))
+        return out.reshape(self.n_channels, -1)
+
+    def profile(self, on: bool):
+        self._check(self.L.fmd_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self) -> dict:
+        """{kernel name: (total ms, launches)} since the last read (HIP events on the processing stream)."""
+        arr = (KernelTime * 16)()
+        n = C.c_int(0)
+        self._check(self.L.fmd_profile_read(self.h, arr, 16, C.byref(n)))
+        return {arr[i].name.decode(): (arr[i].total_ms, arr[i].launches) for i in range(n.value)}
+
+    def audio_tensor(self):
+        """Zero-copy torch view of the device audio buffer [C, n_audio, 2] (valid until the next process())."""
+        import torch
+        p = C.c_void_p()
+        self._check(self.L.fmd_audio_dev(self.h, C.byref(p)))
+        n = self.n_channels * self.rates.n_audio * 2
+
+        class _Arr:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (p.value, False), "version": 2}
+        return torch.as_tensor(_Arr(), device="cuda").view(self.n_channels, self.rates.n_audio, 2)

@@ -1,0 +1,516 @@
+// C ABI of libfmdemod.so (include/fmdemod.h): handle management, coefficient design, per-channel
+// controls, device buffers and the per-block kernel launch sequence.  Host side only; the kernels are
+// in fmd_kernels.hip.  There is no CPU fallback: without a gfx950 device every call fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fmd_design.h"
+#include "fmd_kernels.h"
+#include "fmdemod.h"
+
+using namespace fmd;
+
+struct fmd_handle_s {
+    fmd_config cfg{};
+    LaunchCtx ctx{};
+    fmd_coeffs base{};                       // coefficients common to all channels (+ channel-0 control designs)
+    std::vector<fmd_controls> controls;      // per channel
+    bool controls_dirty = true;
+    bool deemph_on = false;                  // some channel uses the de-emphasis IIR
+    bool deemph_linger = false;              // keep that path one more block after the last channel leaves it, so the
+                                             // Hilbert FIR sees the de-emphasised history the reference would hold
+    std::vector<void*> allocs;
+    void* d_in = nullptr;                    // staging for the host-pointer entry points
+    size_t d_in_bytes = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t last_stream = nullptr;
+    int device = 0;
+    int bytes_cap = 0;
+    std::string err;
+    std::map<int, std::vector<float>> lpf_cache;  // cut-off Hz -> 128 taps
+    bool profiling = false;
+    std::vector<ProfileMarks*> marks;        // one per profiled block, drained by fmd_profile_read
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+int fail(fmd_handle h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail((h), FMD_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(fmd_handle h, T** p, size_t count) {
+    void* q = nullptr;
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    HIP_TRY(h, hipMalloc(&q, bytes));
+    HIP_TRY(h, hipMemset(q, 0, bytes));
+    h->allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return FMD_OK;
+}
+
+bool config_ok(const fmd_config* c, int* m) {
+    if (!c || c->n_channels <= 0) return false;
+    if (c->fs_baseband != 256000 && c->fs_baseband != 1024000 && c->fs_baseband != 2048000) return false;
+    *m = c->fs_baseband / 256000;
+    if (c->block_size <= 0 || (c->block_size % (1024 * *m)) != 0) return false;
+    return true;
+}
+
+const std::vector<float>& lpf_taps(fmd_handle h, int hz) {
+    auto it = h->lpf_cache.find(hz);
+    if (it != h->lpf_cache.end()) return it->second;
+    fmd_controls c;
+    fmd_default_controls(&c);
+    c.lpr_cutoff_hz = hz;
+    fmd_coeffs k{};
+    design_controls(&k, &c);
+    return h->lpf_cache.emplace(hz, std::vector<float>(k.b_lpr, k.b_lpr + 128)).first->second;
+}
+
+// reference UpdateFilters() (broadcast_fm_demod.cpp:330-389), for every channel whose controls changed
+int upload_controls(fmd_handle h, hipStream_t s) {
+    const int C = h->cfg.n_channels;
+    std::vector<float> lpr((size_t)C * 128), lmr((size_t)C * 128), de((size_t)C * 4), mix((size_t)C * 2);
+    int any = 0;
+    for (int c = 0; c < C; c++) {
+        const fmd_controls& k = h->controls[c];
+        const auto& a = lpf_taps(h, k.lpr_cutoff_hz);
+        const auto& b = lpf_taps(h, k.lmr_cutoff_hz);
+        std::copy(a.begin(), a.end(), lpr.begin() + (size_t)c * 128);
+        std::copy(b.begin(), b.end(), lmr.begin() + (size_t)c * 128);
+        fmd_coeffs kk{};
+        design_controls(&kk, &k);  // cheap: two cached-size designs would be overkill to cache for the 1-pole
+        de[4 * c + 0] = kk.deemph_b[0]; de[4 * c + 1] = kk.deemph_b[1]; de[4 * c + 2] = kk.deemph_a[0];
+        de[4 * c + 3] = k.use_deemphasis ? 1.0f : 0.0f;
+        any |= k.use_deemphasis ? 1 : 0;
+        mix[2 * c] = (float)k.audio_out; mix[2 * c + 1] = k.audio_stereo_mix_factor;
+    }
+    Buffers& b = h->ctx.b;
+    HIP_TRY(h, hipMemcpyAsync(b.b_lpr, lpr.data(), lpr.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(b.b_lmr, lmr.data(), lmr.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(b.deemph, de.data(), de.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(b.mix, mix.data(), mix.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipStreamSynchronize(s));  // the host vectors die here
+    if (any) { h->ctx.any_deemph = 1; h->deemph_linger = false; }
+    else if (h->deemph_on) { h->ctx.any_deemph = 1; h->deemph_linger = true; }
+    else if (!h->deemph_linger) h->ctx.any_deemph = 0;
+    h->deemph_on = any != 0;
+    h->controls_dirty = false;
+    return FMD_OK;
+}
+
+void fill_ctx_coeffs(fmd_handle h) {
+    const fmd_coeffs& k = h->base;
+    LaunchCtx& x = h->ctx;
+    std::memcpy(x.front.b_fm_in, k.b_fm_in, sizeof(k.b_fm_in));
+    std::memcpy(x.front.b_fm_out, k.b_fm_out, sizeof(k.b_fm_out));
+    for (int i = 0; i < 32; i++) x.front.b_hilbert_odd[i] = k.b_hilbert[2 * i + 1];
+    x.front.fm_gain = k.fm_gain;
+    std::memcpy(x.rds_taps.b, k.b_rds, sizeof(k.b_rds));
+    x.loops.pilot_k = k.pilot_b[0]; x.loops.pilot_a0 = k.pilot_a[0]; x.loops.pilot_a1 = k.pilot_a[1];
+    x.loops.pll_b0 = k.pll_lpf_b[0]; x.loops.pll_b1 = k.pll_lpf_b[1]; x.loops.pll_a0 = k.pll_lpf_a[0];
+    x.loops.ted_b0 = k.ted_lpf_b[0]; x.loops.ted_b1 = k.ted_lpf_b[1]; x.loops.ted_a0 = k.ted_lpf_a[0];
+    x.loops.bpsk_b0 = k.bpsk_lpf_b[0]; x.loops.bpsk_b1 = k.bpsk_lpf_b[1]; x.loops.bpsk_a0 = k.bpsk_lpf_a[0];
+}
+
+int zero_history(fmd_handle h, hipStream_t s) {
+    const Dims& d = h->ctx.d;
+    Buffers& b = h->ctx.b;
+    for (int p = 0; p < 2; p++) {
+        HIP_TRY(h, hipMemsetAsync(b.base_tail[p], 0, sizeof(float2) * (size_t)d.C * d.tail_base, s));
+        HIP_TRY(h, hipMemsetAsync(b.iq_tail[p], 0, sizeof(float2) * (size_t)d.C * 128, s));
+        HIP_TRY(h, hipMemsetAsync(b.dt_tail[p], 0, sizeof(float) * (size_t)d.C * 128, s));
+        HIP_TRY(h, hipMemsetAsync(b.fo_tail[p], 0, sizeof(float) * (size_t)d.C * 64, s));
+    }
+    HIP_TRY(h, hipMemsetAsync(b.rds_count, 0, sizeof(int) * (size_t)d.C, s));
+    HIP_TRY(h, hipMemsetAsync(b.rds_bytes_count, 0, sizeof(int) * (size_t)d.C, s));
+    HIP_TRY(h, launch_reset_state(h->ctx, s));
+    h->ctx.parity = 0;
+    return FMD_OK;
+}
+
+template <typename InT>
+int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, void* stream) {
+    if (!h) return FMD_ERR_ARG;
+    if (!d_iq) return fail(h, FMD_ERR_ARG, "null input pointer");
+    if (n_channels != h->cfg.n_channels || n_samples != h->cfg.block_size)
+        return fail(h, FMD_ERR_SIZE, "block dropped: got %d x %d, handle is %d x %d", n_channels, n_samples, h->cfg.n_channels, h->cfg.block_size);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->controls_dirty) { int rc = upload_controls(h, s); if (rc) return rc; }
+    ProfileMarks* pm = nullptr;
+    if (h->profiling) {
+        pm = new ProfileMarks();
+        for (auto& ev : pm->ev) HIP_TRY(h, hipEventCreate(&ev));
+        h->marks.push_back(pm);
+    }
+    hipError_t e;
+    if constexpr (sizeof(InT) == 8) e = launch_block_cf32(h->ctx, reinterpret_cast<const float2*>(d_iq), s, pm);
+    else e = launch_block_u8(h->ctx, reinterpret_cast<const uchar2*>(d_iq), s, pm);
+    if (e != hipSuccess) return fail(h, FMD_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
+    h->ctx.parity ^= 1;
+    if (h->deemph_linger) { h->deemph_linger = false; h->ctx.any_deemph = 0; }
+    h->last_stream = s;
+    return FMD_OK;
+}
+
+template <typename InT>
+int process_host(fmd_handle h, const InT* iq, int n_channels, int n_samples) {
+    if (!h) return FMD_ERR_ARG;
+    if (!iq) return fail(h, FMD_ERR_ARG, "null input pointer");
+    if (n_channels != h->cfg.n_channels || n_samples != h->cfg.block_size)
+        return fail(h, FMD_ERR_SIZE, "block dropped: got %d x %d, handle is %d x %d", n_channels, n_samples, h->cfg.n_channels, h->cfg.block_size);
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bytes = sizeof(InT) * (size_t)n_channels * n_samples;
+    if (h->d_in_bytes < bytes) {
+        if (h->d_in) HIP_TRY(h, hipFree(h->d_in));
+        h->d_in = nullptr; h->d_in_bytes = 0;
+        HIP_TRY(h, hipMalloc(&h->d_in, bytes));
+        h->d_in_bytes = bytes;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_in, iq, bytes, hipMemcpyHostToDevice, h->own_stream));
+    int rc = process_dev<InT>(h, static_cast<const InT*>(h->d_in), n_channels, n_samples, h->own_stream);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->own_stream));
+    return FMD_OK;
+}
+
+void free_marks(fmd_handle h) {
+    for (ProfileMarks* pm : h->marks) {
+        for (auto& ev : pm->ev) (void)hipEventDestroy(ev);
+        delete pm;
+    }
+    h->marks.clear();
+}
+
+}  // namespace
+
+extern "C" {
+
+int fmd_api_version(void) { return FMD_API_VERSION; }
+
+const char* fmd_status_string(int s) {
+    switch (s) {
+        case FMD_OK: return "ok";
+        case FMD_ERR_ARG: return "bad argument";
+        case FMD_ERR_SIZE: return "block size mismatch (block dropped)";
+        case FMD_ERR_DEVICE: return "HIP runtime error";
+        case FMD_ERR_NO_DEVICE: return "no gfx950 device (no CPU fallback)";
+        case FMD_ERR_NAME: return "unknown stream name";
+        default: return "unknown status";
+    }
+}
+
+int fmd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+
+void fmd_default_controls(fmd_controls* c) {
+    // reference Broadcast_FM_Demod_Controls defaults (broadcast_fm_demod.h:82-88) and the SetValue() calls of the
+    // constructor (broadcast_fm_demod.cpp:189,248,260)
+    c->audio_out = FMD_AUDIO_STEREO;
+    c->audio_stereo_mix_factor = 1.0f;
+    c->use_deemphasis = 0;
+    c->deemphasis_tus = 1;
+    c->lpr_cutoff_hz = 15000;
+    c->lmr_cutoff_hz = 15000;
+}
+
+int fmd_create(const fmd_config* cfg, fmd_handle* out) {
+    if (!out) return FMD_ERR_ARG;
+    *out = nullptr;
+    int m = 0;
+    if (!config_ok(cfg, &m)) return fail(nullptr, FMD_ERR_ARG, "unsupported configuration");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, FMD_ERR_NO_DEVICE, "no HIP device");
+    int dev = cfg->device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) return fail(nullptr, FMD_ERR_NO_DEVICE, "hipGetDevice failed"); }
+    if (dev >= ndev) return fail(nullptr, FMD_ERR_ARG, "device %d out of range", dev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, FMD_ERR_NO_DEVICE, "device %d is not gfx950", dev);
+
+    fmd_handle h = new (std::nothrow) fmd_handle_s();
+    if (!h) return FMD_ERR_ARG;
+    h->cfg = *cfg;
+    h->cfg.device = dev;
+    h->device = dev;
+    auto bail = [&](int rc) { g_create_error = h->err; fmd_destroy(h); return rc; };
+    if (hipSetDevice(dev) != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "hipSetDevice failed"));
+    { hipError_t e = prepare_kernels(); if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "prepare_kernels: %s", hipGetErrorString(e))); }
+    { hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking); if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e))); }
+
+    Dims& d = h->ctx.d;
+    d.C = cfg->n_channels; d.N = cfg->block_size; d.m = m;
+    d.n_fm_in = d.N / m; d.n_fm_out = d.n_fm_in / 2; d.n_rds = d.n_fm_out / 8; d.n_audio = d.n_fm_out / 4;
+    d.n_est = (d.n_audio + 9) / 10;
+    d.tail_base = front_tail_len(m);
+    h->bytes_cap = 16 * (d.n_rds / 256 + 1);
+    h->ctx.keep_taps = (cfg->flags & FMD_FLAG_KEEP_TAPS) ? 1 : 0;
+
+    fmd_controls def;
+    fmd_default_controls(&def);
+    h->controls.assign((size_t)d.C, def);
+    design_all(&h->base, cfg->fs_baseband, &def);
+    fill_ctx_coeffs(h);
+
+    Buffers& b = h->ctx.b;
+    const size_t C = (size_t)d.C;
+    int rc = FMD_OK;
+    for (int p = 0; p < 2 && !rc; p++) {
+        rc = dev_alloc(h, &b.base_tail[p], C * d.tail_base);
+        if (!rc) rc = dev_alloc(h, &b.iq_tail[p], C * 128);
+        if (!rc) rc = dev_alloc(h, &b.dt_tail[p], C * 128);
+        if (!rc) rc = dev_alloc(h, &b.fo_tail[p], C * 64);
+    }
+    if (!rc) rc = dev_alloc(h, &b.fm_out_iq, C * d.n_fm_out);
+    if (!rc) rc = dev_alloc(h, &b.fm_out, C * d.n_fm_out);
+    if (!rc) rc = dev_alloc(h, &b.pll_dt, C * d.n_fm_out);
+    if (!rc) rc = dev_alloc(h, &b.rds, C * d.n_rds);
+    if (!rc) rc = dev_alloc(h, &b.lmr_est, C * d.n_est);
+    if (!rc) rc = dev_alloc(h, &b.audio, C * d.n_audio * 2);
+    if (!rc) rc = dev_alloc(h, &b.rds_sym, C * d.n_rds);
+    if (!rc) rc = dev_alloc(h, &b.rds_raw_sym, h->ctx.keep_taps ? C * d.n_rds : 4);
+    if (!rc) rc = dev_alloc(h, &b.rds_count, C);
+    if (!rc) rc = dev_alloc(h, &b.lpr, h->ctx.keep_taps ? C * d.n_audio : 4);
+    if (!rc) rc = dev_alloc(h, &b.lmr, h->ctx.keep_taps ? C * d.n_audio : 4);
+    if (!rc) rc = dev_alloc(h, &b.rds_bytes, C * h->bytes_cap);
+    if (!rc) rc = dev_alloc(h, &b.rds_bytes_count, C);
+    if (!rc) rc = dev_alloc(h, &b.b_lpr, C * 128);
+    if (!rc) rc = dev_alloc(h, &b.b_lmr, C * 128);
+    if (!rc) rc = dev_alloc(h, &b.deemph, C * 4);
+    if (!rc) rc = dev_alloc(h, &b.mix, C * 2);
+    if (!rc) rc = dev_alloc(h, &b.state, (size_t)S_NUM_FIELDS * C);
+    if (rc) return bail(rc);
+    rc = zero_history(h, h->own_stream);
+    if (!rc) rc = upload_controls(h, h->own_stream);
+    if (rc) return bail(rc);
+    if (hipStreamSynchronize(h->own_stream) != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "sync failed"));
+    *out = h;
+    return FMD_OK;
+}
+
+int fmd_destroy(fmd_handle h) {
+    if (!h) return FMD_ERR_ARG;
+    (void)hipSetDevice(h->device);
+    if (h->last_stream) (void)hipStreamSynchronize(h->last_stream);
+    free_marks(h);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->d_in) (void)hipFree(h->d_in);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return FMD_OK;
+}
+
+int fmd_reset(fmd_handle h) {
+    if (!h) return FMD_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->last_stream) HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    int rc = zero_history(h, h->own_stream);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->own_stream));
+    h->deemph_on = false; h->deemph_linger = false; h->ctx.any_deemph = 0;
+    h->controls_dirty = true;
+    return FMD_OK;
+}
+
+int fmd_set_controls(fmd_handle h, int channel, const fmd_controls* c) {
+    if (!h || !c) return FMD_ERR_ARG;
+    if (channel >= h->cfg.n_channels) return fail(h, FMD_ERR_ARG, "channel %d out of range", channel);
+    if (c->audio_out < FMD_AUDIO_LPR || c->audio_out > FMD_AUDIO_STEREO || c->deemphasis_tus <= 0)
+        return fail(h, FMD_ERR_ARG, "bad controls");
+    if (channel < 0) std::fill(h->controls.begin(), h->controls.end(), *c);
+    else h->controls[(size_t)channel] = *c;
+    h->controls_dirty = true;
+    return FMD_OK;
+}
+
+int fmd_get_controls(fmd_handle h, int channel, fmd_controls* c) {
+    if (!h || !c) return FMD_ERR_ARG;
+    if (channel >= h->cfg.n_channels) return fail(h, FMD_ERR_ARG, "channel %d out of range", channel);
+    *c = h->controls[(size_t)std::max(channel, 0)];
+    return FMD_OK;
+}
+
+int fmd_get_rates(fmd_handle h, fmd_rates* r) {
+    if (!h || !r) return FMD_ERR_ARG;
+    const Dims& d = h->ctx.d;
+    r->fs_baseband = h->cfg.fs_baseband; r->fs_fm_in = 256000; r->fs_fm_out = 128000; r->fs_rds = 16000; r->fs_audio = 32000;
+    r->n_baseband = d.N; r->n_fm_in = d.n_fm_in; r->n_fm_out = d.n_fm_out; r->n_rds = d.n_rds; r->n_audio = d.n_audio;
+    return FMD_OK;
+}
+
+int fmd_get_coeffs(fmd_handle h, int channel, fmd_coeffs* k) {
+    if (!h || !k) return FMD_ERR_ARG;
+    if (channel >= h->cfg.n_channels) return fail(h, FMD_ERR_ARG, "channel %d out of range", channel);
+    *k = h->base;
+    design_controls(k, &h->controls[(size_t)std::max(channel, 0)]);
+    return FMD_OK;
+}
+
+int fmd_process_cf32_dev(fmd_handle h, const float* d_iq, int n_channels, int n_samples, void* stream) {
+    return process_dev<float2>(h, reinterpret_cast<const float2*>(d_iq), n_channels, n_samples, stream);
+}
+int fmd_process_u8_dev(fmd_handle h, const uint8_t* d_iq, int n_channels, int n_samples, void* stream) {
+    return process_dev<uchar2>(h, reinterpret_cast<const uchar2*>(d_iq), n_channels, n_samples, stream);
+}
+int fmd_process_cf32_host(fmd_handle h, const float* iq, int n_channels, int n_samples) {
+    return process_host<float2>(h, reinterpret_cast<const float2*>(iq), n_channels, n_samples);
+}
+int fmd_process_u8_host(fmd_handle h, const uint8_t* iq, int n_channels, int n_samples) {
+    return process_host<uchar2>(h, reinterpret_cast<const uchar2*>(iq), n_channels, n_samples);
+}
+
+int fmd_synchronize(fmd_handle h) {
+    if (!h) return FMD_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    return FMD_OK;
+}
+
+int fmd_audio_dev(fmd_handle h, const float** d_audio) {
+    if (!h || !d_audio) return FMD_ERR_ARG;
+    *d_audio = h->ctx.b.audio;
+    return FMD_OK;
+}
+
+int fmd_rds_dev(fmd_handle h, const float** d_syms, const int** d_counts) {
+    if (!h || !d_syms || !d_counts) return FMD_ERR_ARG;
+    *d_syms = h->ctx.b.rds_sym;
+    *d_counts = h->ctx.b.rds_count;
+    return FMD_OK;
+}
+
+int fmd_get_audio(fmd_handle h, float* audio) {
+    if (!h || !audio) return FMD_ERR_ARG;
+    int rc = fmd_synchronize(h);
+    if (rc) return rc;
+    const Dims& d = h->ctx.d;
+    HIP_TRY(h, hipMemcpy(audio, h->ctx.b.audio, sizeof(float) * 2 * (size_t)d.C * d.n_audio, hipMemcpyDeviceToHost));
+    return FMD_OK;
+}
+
+int fmd_get_rds_symbols(fmd_handle h, float* syms, int* counts) {
+    if (!h || !syms || !counts) return FMD_ERR_ARG;
+    int rc = fmd_synchronize(h);
+    if (rc) return rc;
+    const Dims& d = h->ctx.d;
+    HIP_TRY(h, hipMemcpy(syms, h->ctx.b.rds_sym, sizeof(float) * (size_t)d.C * d.n_rds, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(counts, h->ctx.b.rds_count, sizeof(int) * (size_t)d.C, hipMemcpyDeviceToHost));
+    return FMD_OK;
+}
+
+int fmd_get_rds_bytes(fmd_handle h, uint8_t* bytes, int cap_bytes_per_channel, int* counts) {
+    if (!h || !bytes || !counts || cap_bytes_per_channel < 0) return FMD_ERR_ARG;
+    int rc = fmd_synchronize(h);
+    if (rc) return rc;
+    const Dims& d = h->ctx.d;
+    std::vector<uint8_t> tmp((size_t)d.C * h->bytes_cap);
+    HIP_TRY(h, hipMemcpy(tmp.data(), h->ctx.b.rds_bytes, tmp.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(counts, h->ctx.b.rds_bytes_count, sizeof(int) * (size_t)d.C, hipMemcpyDeviceToHost));
+    for (int c = 0; c < d.C; c++) {
+        counts[c] = std::min(counts[c], std::min(cap_bytes_per_channel, h->bytes_cap));
+        std::memcpy(bytes + (size_t)c * cap_bytes_per_channel, tmp.data() + (size_t)c * h->bytes_cap, (size_t)counts[c]);
+    }
+    return FMD_OK;
+}
+
+int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats, size_t* n_floats) {
+    if (!h || !name || !out) return FMD_ERR_ARG;
+    const Dims& d = h->ctx.d;
+    const Buffers& b = h->ctx.b;
+    const size_t C = (size_t)d.C;
+    const bool keep = h->ctx.keep_taps != 0;
+    const void* p = nullptr;
+    size_t n = 0;
+    bool from_state = false;
+    int field = 0;
+    const std::string s(name);
+    if (s == "fm_out_iq") { p = b.fm_out_iq; n = 2 * C * d.n_fm_out; }
+    else if (s == "pll_dt") { p = b.pll_dt; n = C * d.n_fm_out; }
+    else if (s == "audio") { p = b.audio; n = 2 * C * d.n_audio; }
+    else if (s == "rds_sym") { p = b.rds_sym; n = C * d.n_rds; }
+    else if (s == "lmr_est") { p = b.lmr_est; n = C * d.n_est; }
+    else if (s == "rds" ) { p = b.rds; n = 2 * C * d.n_rds; }
+    else if (s == "lpr" && keep) { p = b.lpr; n = C * d.n_audio; }
+    else if (s == "lmr" && keep) { p = b.lmr; n = C * d.n_audio; }
+    else if (s == "rds_raw_sym" && keep) { p = b.rds_raw_sym; n = 2 * C * d.n_rds; }
+    else if (s == "lmr_phase") { from_state = true; field = S_LMR_PHASE_CUR; }
+    else if (s == "agc_pilot_gain") { from_state = true; field = S_AGC_PILOT_GAIN; }
+    else if (s == "agc_rds_gain") { from_state = true; field = S_AGC_RDS_GAIN; }
+    else if (s == "lpr" || s == "lmr" || s == "rds_raw_sym") return fail(h, FMD_ERR_NAME, "stream '%s' needs FMD_FLAG_KEEP_TAPS", name);
+    else return fail(h, FMD_ERR_NAME, "unknown stream '%s'", name);
+    if (from_state) { p = b.state + (size_t)field * C; n = C; }
+    if (n_floats) *n_floats = n;
+    if (cap_floats < n) return fail(h, FMD_ERR_ARG, "stream '%s' needs %zu floats", name, n);
+    int rc = fmd_synchronize(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpy(out, p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return FMD_OK;
+}
+
+int fmd_profile_enable(fmd_handle h, int on) {
+    if (!h) return FMD_ERR_ARG;
+    h->profiling = on != 0;
+    return FMD_OK;
+}
+
+int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out) {
+    if (!h || !out || !n_out || cap <= 0) return FMD_ERR_ARG;
+    int rc = fmd_synchronize(h);
+    if (rc) return rc;
+    int n = 0;
+    for (ProfileMarks* pm : h->marks) {
+        for (int i = 0; i < pm->n; i++) {
+            float ms = 0.0f;
+            HIP_TRY(h, hipEventElapsedTime(&ms, pm->ev[i], pm->ev[i + 1]));
+            int slot = -1;
+            for (int j = 0; j < n; j++) if (std::strncmp(out[j].name, pm->name[i], sizeof(out[j].name)) == 0) { slot = j; break; }
+            if (slot < 0) {
+                if (n >= cap) continue;
+                slot = n++;
+                std::memset(&out[slot], 0, sizeof(out[slot]));
+                std::strncpy(out[slot].name, pm->name[i], sizeof(out[slot].name) - 1);
+            }
+            out[slot].total_ms += ms;
+            out[slot].launches += 1;
+        }
+    }
+    free_marks(h);
+    *n_out = n;
+    return FMD_OK;
+}
+
+const char* fmd_last_error(fmd_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+}  // extern "C"

@@ -1,0 +1,772 @@
+// Hand-written CDNA4 (gfx950) kernels of the batched broadcast-FM demodulator.
+//
+// One `Broadcast_FM_Demod::Process` call of the reference (src/fm_demod/broadcast_fm_demod.cpp:309-328)
+// for C independent stations becomes this kernel sequence:
+//
+//   k_front        [parallel]  a0 u8->f32, a1 decimating FIR, a2 arctan discriminator, a3 decimating FIR,
+//                              a5 Hilbert FIR  -> fm_out_iq            (LDS-staged, halo recomputed per tile)
+//   k_pilot_power  [serial]    a6 pilot peak IIR + a7 AGC power sum     (lane per channel, LDS transpose)
+//   k_pilot_pll    [serial]    a6 (recomputed) a7 gain, a8 PLL loop     -> pll_dt
+//   k_extract      [parallel]  a9 x2/x3 harmonic mixers fused into a10/a12 decimating FIRs, a11 phase
+//                              estimates, a15 audio mix                -> audio, rds, lmr_est
+//   k_rds_sync     [serial]    a11 phase integrate, a13 AGC, a14 BPSK synchroniser, Manchester decode
+//
+// Arithmetic contract: this file is compiled with -ffp-contract=off; every fused multiply-add is an
+// explicit fmaf() and every sum is associated exactly as the reference's AVX2+FMA build associates it
+// (8 / 4 lane accumulators per dot product, horizontal sums in the x86 order), so results are
+// bit-identical to the CPU path.  No MFMA: the FIRs are VALU work staged through LDS.
+#include "fmd_kernels.h"
+#include "fmd_math.h"
+
+namespace fmd {
+
+static constexpr int kWave = 64;
+
+__device__ __forceinline__ float& st(float* state, int field, int C, int c) { return state[(size_t)field * C + c]; }
+
+// =============================================================================================
+// k_front — reference Run_FM_Demodulate (broadcast_fm_demod.cpp:391-416) without the optional IIR:
+//   PolyphaseDownsampler<cf32> M x 64 taps (polyphase_filter.h:41-64, c32_f32_cum_mul.cpp:70-111)
+//   FM_Demod::Process (fm_demod.cpp:30-45)
+//   PolyphaseDownsampler<float> 2 x 64 taps (f32_cum_mul.cpp:52-78)
+//   Hilbert_FIR_Filter<float> 65 taps (hilbert_fir_filter.h:26-46), 33 zero taps skipped
+// One workgroup = one channel x T output samples (128 kHz).  The halo each stage needs is
+// recomputed from `tail ++ block` so tiles are independent; the baseband tile is staged in LDS
+// split into M decimation phases, which makes every FIR read unit-stride across lanes.
+// =============================================================================================
+template <int M>
+struct FrontGeom {
+    static constexpr int T = (M == 8) ? 256 : 512;
+    static constexpr int NW = 2 * T + 191;                               // fm_in samples (incl. one for prev_theta)
+    static constexpr int TAIL = (M == 1) ? 191 : (190 * M + 64);         // history samples of the input stream
+    static constexpr int NB = (M == 1) ? NW : (2 * M * T + TAIL);        // input samples staged per tile
+    static constexpr int Q = (M == 1) ? 0 : (NB / M);                    // entries per phase
+    static constexpr int PSR = (M == 1) ? 0 : (16 / M);                  // wanted residue of the phase stride mod 16
+    static constexpr int PS = (M == 1) ? 0 : (((Q - PSR + 15) / 16) * 16 + PSR);
+    static constexpr int LDS_FLOATS = 2 * M * PS * (M > 1) + NW + (NW + 1) + (T + 64);
+};
+
+__device__ __forceinline__ float2 load_iq(const float2* p, size_t i) { return p[i]; }
+__device__ __forceinline__ float2 load_iq(const uchar2* p, size_t i) {
+    const uchar2 v = p[i];
+    return make_float2((float)v.x - 127.0f, (float)v.y - 127.0f);  // reference src/app.cpp:56-62
+}
+
+template <int M, typename InT>
+__global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
+                                               float2* __restrict__ tail_out, float2* __restrict__ fm_out_iq,
+                                               float* __restrict__ fm_out_plain, float* __restrict__ fo_tail_out, FrontTaps taps,
+                                               int deemph_path) {
+    using G = FrontGeom<M>;
+    constexpr int T = G::T, NW = G::NW, NB = G::NB, PS = G::PS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float2* ph = reinterpret_cast<float2*>(smem);                 // [M][PS]
+    float* theta = smem + 2 * M * PS * (M > 1);                   // [NW]
+    float* dem = theta + NW;                                      // [NW-1] (+pad)
+    float* fo = dem + NW + 1;                                     // [T+64]
+    (void)ph;
+
+    const int tiles = d.n_fm_out / T;
+    const int c = blockIdx.x / tiles;
+    const int tile = blockIdx.x % tiles;
+    const int o0 = tile * T;
+    const int tid = threadIdx.x;
+    const long g_lo = (long)2 * M * o0 - G::TAIL;                 // first input index of the tile (block relative)
+    const InT* in_c = in + (size_t)c * d.N;
+    const float2* tail_c = tail_in + (size_t)c * G::TAIL;
+
+    auto fetch = [&](int idx) -> float2 {
+        const long g = g_lo + idx;
+        return (g < 0) ? tail_c[G::TAIL + g] : load_iq(in_c, (size_t)g);
+    };
+
+    if constexpr (M > 1) {
+        // stage the baseband tile, de-interleaved into M phases
+        for (int idx = tid; idx < NB; idx += 256) {
+            const float2 v = fetch(idx);
+            ph[(idx % M) * PS + (idx / M)] = v;
+        }
+        __syncthreads();
+        // a1 + a2: fm_in[w] then theta[w] = atan2(Q, I)
+        for (int i = tid; i < NW; i += 256) {
+            float ar[4] = {0.f, 0.f, 0.f, 0.f}, ai[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < 64 / M; jj++) {
+#pragma unroll
+                for (int p = 0; p < M; p++) {
+                    const float2 x = ph[p * PS + i + jj];
+                    const float b = taps.b_fm_in[M * jj + p];
+                    ar[p & 3] = fmaf(x.x, b, ar[p & 3]);
+                    ai[p & 3] = fmaf(x.y, b, ai[p & 3]);
+                }
+            }
+            const float re = (ar[0] + ar[2]) + (ar[1] + ar[3]);
+            const float im = (ai[0] + ai[2]) + (ai[1] + ai[3]);
+            theta[i] = fmd_atan2f(im, re);
+        }
+    } else {
+        for (int i = tid; i < NW; i += 256) {
+            const float2 v = fetch(i);
+            theta[i] = fmd_atan2f(v.y, v.x);
+        }
+    }
+    __syncthreads();
+    // a2: phase difference, wrap, scale
+    {
+        const float pi = bits_f32(kPiBits), two_pi = bits_f32(kTwoPiBits);
+        for (int j = tid; j < NW - 1; j += 256) {
+            float dlt = theta[j + 1] - theta[j];
+            if (dlt >= pi) dlt = dlt - two_pi;
+            else if (dlt <= -pi) dlt = dlt + two_pi;
+            dem[j] = dlt * taps.fm_gain;
+        }
+    }
+    __syncthreads();
+    // a3: decimate-by-2 FIR, 8 lane accumulators
+    for (int uu = tid; uu < T + 64; uu += 256) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float2* w2 = reinterpret_cast<const float2*>(dem + 2 * uu);
+#pragma unroll
+        for (int n = 0; n < 64; n += 2) {
+            const float2 v = w2[n / 2];
+            acc[n & 7] = fmaf(v.x, taps.b_fm_out[n], acc[n & 7]);
+            acc[(n + 1) & 7] = fmaf(v.y, taps.b_fm_out[n + 1], acc[(n + 1) & 7]);
+        }
+        const float a0 = acc[0] + acc[4], a1 = acc[1] + acc[5], a2 = acc[2] + acc[6], a3 = acc[3] + acc[7];
+        const float y = (a0 + a2) + (a1 + a3);
+        fo[uu] = y;
+        if (deemph_path && uu >= 64) fm_out_plain[(size_t)c * d.n_fm_out + o0 + (uu - 64)] = y;
+    }
+    __syncthreads();
+    // a5: Hilbert FIR; only lanes 1,3,5,7 of the reference's 8-lane accumulator see non-zero taps
+    if (!deemph_path) {
+        for (int oo = tid; oo < T; oo += 256) {
+            float l1 = 0.f, l3 = 0.f, l5 = 0.f, l7 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                l1 = fmaf(fo[oo + 1 + 8 * k], taps.b_hilbert_odd[4 * k + 0], l1);
+                l3 = fmaf(fo[oo + 3 + 8 * k], taps.b_hilbert_odd[4 * k + 1], l3);
+                l5 = fmaf(fo[oo + 5 + 8 * k], taps.b_hilbert_odd[4 * k + 2], l5);
+                l7 = fmaf(fo[oo + 7 + 8 * k], taps.b_hilbert_odd[4 * k + 3], l7);
+            }
+            const float im = (0.0f + ((l1 + l5) + (l3 + l7))) + 0.0f;
+            fm_out_iq[(size_t)c * d.n_fm_out + o0 + oo] = make_float2(fo[oo + 32], im);
+        }
+    }
+    // keep the last TAIL input samples of the stream for the next block (and, when the de-emphasis path is
+    // not the one maintaining it, the last 64 fm_out samples = the Hilbert FIR history the reference holds)
+    if (tile == tiles - 1) {
+        float2* tout = tail_out + (size_t)c * G::TAIL;
+        for (int idx = tid; idx < G::TAIL; idx += 256) tout[idx] = load_iq(in_c, (size_t)(d.N - G::TAIL + idx));
+        if (!deemph_path && tid < 64) fo_tail_out[(size_t)c * 64 + tid] = fo[T + tid];
+    }
+}
+
+// =============================================================================================
+// Lane-per-channel serial kernels.  A wavefront owns 64 adjacent channels; time runs in chunks of
+// 32 samples that are loaded row-wise (coalesced, 16 B per lane) and transposed through LDS so each
+// lane then walks its own channel.  The next chunk's global loads are in flight while the current
+// chunk is processed.
+// =============================================================================================
+static constexpr int kChunk = 32;
+static constexpr int kRowC = kChunk + 2;   // float2 row stride (272 B) of a transposed cf32 chunk
+static constexpr int kRowF = kChunk + 4;   // float row stride (144 B) of an f32 output chunk
+
+// 16 x float4 per lane = one 64-channel x 32-sample cf32 chunk in flight per wavefront
+struct ChunkRegsC { float4 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15; };
+
+#define FMD_FOR16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+
+__device__ __forceinline__ ChunkRegsC chunk_load_c(const float2* __restrict__ base, int n, int c0, int C, int t0) {
+    const int lane = threadIdx.x, row = lane >> 4, col = lane & 15;
+    ChunkRegsC r;
+#define FMD_LD(k) { int ch = c0 + 4 * k + row; ch = ch < C ? ch : C - 1; \
+                    r.v##k = *reinterpret_cast<const float4*>(base + (size_t)ch * n + t0 + 2 * col); }
+    FMD_FOR16(FMD_LD)
+#undef FMD_LD
+    return r;
+}
+__device__ __forceinline__ void chunk_store_c(const ChunkRegsC& r, float2* lds) {
+    const int lane = threadIdx.x, row = lane >> 4, col = lane & 15;
+#define FMD_ST(k) *reinterpret_cast<float4*>(lds + (4 * k + row) * kRowC + 2 * col) = r.v##k;
+    FMD_FOR16(FMD_ST)
+#undef FMD_ST
+}
+// flush a [64][kRowF] f32 chunk to out[C][n] at t0
+__device__ __forceinline__ void chunk_flush_f(const float* lds, float* __restrict__ out, int n, int c0, int C, int t0) {
+    const int lane = threadIdx.x, row = lane >> 3, col = lane & 7;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int r = 8 * k + row, ch = c0 + r;
+        if (ch < C) *reinterpret_cast<float4*>(out + (size_t)ch * n + t0 + 4 * col) = *reinterpret_cast<const float4*>(lds + r * kRowF + 4 * col);
+    }
+}
+
+struct PilotIIR {
+    float x1r, x1i, x2r, x2i, y1r, y1i, y2r, y2i;
+    // reference IIR_Filter<complex<float>> K=3 (iir_filter.h:40-69) with b=[K,0,0], a=[-r^2, 2r cos, 1]:
+    // y = fma(a0, y[n-2], K x[n-2]) + a1 y[n-1]   (the zero-tap terms contribute +-0)
+    __device__ __forceinline__ float2 step(float2 x, const LoopCoeffs& k) {
+        const float yr = fmaf(k.pilot_a0, y2r, k.pilot_k * x2r) + k.pilot_a1 * y1r;
+        const float yi = fmaf(k.pilot_a0, y2i, k.pilot_k * x2i) + k.pilot_a1 * y1i;
+        x2r = x1r; x2i = x1i; x1r = x.x; x1i = x.y;
+        y2r = y1r; y2i = y1i; y1r = yr; y1i = yi;
+        return make_float2(yr, yi);
+    }
+    __device__ __forceinline__ void load(float* s, int base, int C, int c) {
+        x1r = st(s, base + 0, C, c); x1i = st(s, base + 1, C, c); x2r = st(s, base + 2, C, c); x2i = st(s, base + 3, C, c);
+        y1r = st(s, base + 4, C, c); y1i = st(s, base + 5, C, c); y2r = st(s, base + 6, C, c); y2i = st(s, base + 7, C, c);
+    }
+    __device__ __forceinline__ void store(float* s, int base, int C, int c) const {
+        st(s, base + 0, C, c) = x1r; st(s, base + 1, C, c) = x1i; st(s, base + 2, C, c) = x2r; st(s, base + 3, C, c) = x2i;
+        st(s, base + 4, C, c) = y1r; st(s, base + 5, C, c) = y1i; st(s, base + 6, C, c) = y2r; st(s, base + 7, C, c) = y2i;
+    }
+};
+
+// a6 + power sum of a7 — reference LockOntoPilot :421-423 (IIR) and AGC_Filter::calculate_average_power (agc.h:21-30)
+__global__ __launch_bounds__(kWave) void k_pilot_power(Dims d, const float2* __restrict__ fm_out_iq, float* __restrict__ state, LoopCoeffs k) {
+    __shared__ __attribute__((aligned(16))) float2 xin[2][kWave * kRowC];
+    const int lane = threadIdx.x, c0 = blockIdx.x * kWave, c = c0 + lane;
+    const bool live = c < d.C;
+    const int cs = live ? c : d.C - 1;
+    PilotIIR f; f.load(state, SA_X1R, d.C, cs);
+    float power = 0.0f;
+    const int n = d.n_fm_out, chunks = n / kChunk;
+    ChunkRegsC regs = chunk_load_c(fm_out_iq, n, c0, d.C, 0);
+    for (int ch = 0; ch < chunks; ch++) {
+        float2* buf = xin[ch & 1];
+        chunk_store_c(regs, buf);
+        __syncthreads();
+        regs = chunk_load_c(fm_out_iq, n, c0, d.C, (ch + 1 < chunks ? ch + 1 : ch) * kChunk);
+#pragma unroll 4
+        for (int t = 0; t < kChunk; t++) {
+            const float2 y = f.step(buf[lane * kRowC + t], k);
+            power = power + fmaf(y.x, y.x, y.y * y.y);
+        }
+    }
+    if (live) { f.store(state, SA_X1R, d.C, c); st(state, S_PILOT_POWER, d.C, c) = power; }
+}
+
+// a6 (recomputed) + a7 gain + a8 — reference LockOntoPilot :418-456, PLL_Mixer::Update (pll_mixer.cpp:12-21)
+__global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __restrict__ fm_out_iq, float* __restrict__ pll_dt,
+                                                     float* __restrict__ state, LoopCoeffs k) {
+    __shared__ __attribute__((aligned(16))) float2 xin[2][kWave * kRowC];
+    __shared__ __attribute__((aligned(16))) float dt_out[kWave * kRowF];
+    const int lane = threadIdx.x, c0 = blockIdx.x * kWave, c = c0 + lane;
+    const bool live = c < d.C;
+    const int cs = live ? c : d.C - 1;
+    const int n = d.n_fm_out, chunks = n / kChunk;
+    PilotIIR f; f.load(state, SB_X1R, d.C, cs);
+    // AGC_Filter::process (agc.h:12-19) as compiled: target_gain = sqrt((target/sum) * N)
+    float gain = st(state, S_AGC_PILOT_GAIN, d.C, cs);
+    {
+        const float sum = st(state, S_PILOT_POWER, d.C, cs);
+        const float target_gain = sqrtf((1.0f / sum) * (float)n);
+        gain = fmaf(target_gain - gain, 0.2f, gain);
+    }
+    float lx1 = st(state, S_PLL_X1, d.C, cs), ly1 = st(state, S_PLL_Y1, d.C, cs);
+    float integ = st(state, S_PLL_INT, d.C, cs), err = st(state, S_PLL_ERR, d.C, cs), tph = st(state, S_PLL_T, d.C, cs);
+    const float Ts = 1.0f / 128000.0f;
+    const float KTsI = 0.1f * Ts;
+    ChunkRegsC regs = chunk_load_c(fm_out_iq, n, c0, d.C, 0);
+    for (int ch = 0; ch < chunks; ch++) {
+        float2* buf = xin[ch & 1];
+        chunk_store_c(regs, buf);
+        __syncthreads();
+        regs = chunk_load_c(fm_out_iq, n, c0, d.C, (ch + 1 < chunks ? ch + 1 : ch) * kChunk);
+        for (int t = 0; t < kChunk; t++) {
+            const float2 y = f.step(buf[lane * kRowC + t], k);
+            const float p = gain * y.x, q = gain * y.y;
+            // loop filter IIR_Filter<float> K=2: t_i = fma(xn[i], b[i], yn[i]*a[i]); y += t_i
+            const float t0 = fmaf(lx1, k.pll_b0, ly1 * k.pll_a0);
+            const float t1 = fmaf(err, k.pll_b1, 0.0f);
+            const float lpf = (0.0f + t0) + t1;
+            lx1 = err; ly1 = lpf;
+            const float P = lpf * 0.01f;
+            integ = clampf(fmaf(err, KTsI, integ), -1.0f, 1.0f);
+            const float PI_error = integ + P;
+            // PLL_Mixer::Update
+            const float control = clampf(PI_error * 1.0f, -1.0f, 1.0f);
+            const float freq = fmaf(control, -100.0f, -19000.0f);
+            const float yy = fmaf(freq, Ts, tph);
+            tph = yy - round_half_away(yy);
+            float dt_cos = tph + 0.25f;
+            dt_cos = dt_cos - round_half_away(dt_cos);
+            const float ps = cheb_sine_scalar(tph);
+            const float pc = cheb_sine_scalar(dt_cos);
+            const float res_im = fmaf(ps, p, q * pc);
+            const float res_re = fmaf(p, pc, -(q * ps));
+            err = fmd_atan2f(res_im, res_re);
+            dt_out[lane * kRowF + t] = tph;
+        }
+        __syncthreads();
+        chunk_flush_f(dt_out, pll_dt, n, c0, d.C, ch * kChunk);
+    }
+    if (live) {
+        f.store(state, SB_X1R, d.C, c);
+        st(state, S_AGC_PILOT_GAIN, d.C, c) = gain;
+        st(state, S_PLL_X1, d.C, c) = lx1; st(state, S_PLL_Y1, d.C, c) = ly1;
+        st(state, S_PLL_INT, d.C, c) = integ; st(state, S_PLL_ERR, d.C, c) = err; st(state, S_PLL_T, d.C, c) = tph;
+    }
+}
+
+// =============================================================================================
+// k_extract — reference ExtractComponents (broadcast_fm_demod.cpp:463-536) + MixAudio (:549-585):
+//   apply_harmonic_pll_avx (apply_harmonic_pll.cpp:88-139) h=2 (+ L-R phase offset) and h=3, fused into
+//   PolyphaseDownsampler<cf32> 4x128 (L+R: real rail only, L-R) and 8x128 (RDS); per-sample phase
+//   estimates of every 10th L-R output (:496-510); stereo mix.
+// One workgroup = one channel x 128 audio samples (512 fm_out samples, 64 RDS samples).
+// =============================================================================================
+static constexpr int kTA = 128;                  // audio outputs per tile
+static constexpr int kXS = 4 * kTA + 124;        // fm_out samples staged (636)
+static constexpr int kQ4 = kXS / 4;              // 159 entries per phase (M=4)
+static constexpr int kP4 = 164;                  // phase stride, == 4 (mod 16)
+static constexpr int kQ8 = (kXS - 4) / 8;        // 79 entries per phase (M=8)
+static constexpr int kP8 = 82;                   // phase stride, == 2 (mod 16)
+
+__device__ __forceinline__ float2 harmonic_mix(float2 x, float dt, float harmonic, float off, float off_cos) {
+    float s = fmaf(dt, harmonic, off);
+    float c = fmaf(dt, harmonic, off_cos);
+    s = s - rintf(s);
+    c = c - rintf(c);
+    const float pc = cheb_sine_vector(c), ps = cheb_sine_vector(s);
+    return make_float2(fmaf(pc, x.x, -(x.y * ps)), fmaf(pc, x.y, x.x * ps));
+}
+
+__global__ __launch_bounds__(256) void k_extract(Dims d, const float2* __restrict__ fm_out_iq, const float* __restrict__ pll_dt,
+                                                 const float2* __restrict__ iq_tail_in, const float* __restrict__ dt_tail_in,
+                                                 float2* __restrict__ iq_tail_out, float* __restrict__ dt_tail_out,
+                                                 const float* __restrict__ b_lpr, const float* __restrict__ b_lmr, RdsTaps rds_taps,
+                                                 const float* __restrict__ mixctl, float* __restrict__ state,
+                                                 float* __restrict__ audio, float2* __restrict__ rds, float* __restrict__ lmr_est,
+                                                 float* __restrict__ lpr_out, float* __restrict__ lmr_out, int keep_taps) {
+    __shared__ float lpr_ph[4 * kP4];            // real part of fm_out_iq, 4 phases
+    __shared__ float2 lmr_ph[4 * kP4];           // x2-mixed signal, 4 phases
+    __shared__ float2 rds_ph[8 * kP8];           // x3-mixed signal, 8 phases
+    __shared__ float tap_lpr[128], tap_lmr[128];
+    __shared__ float lpr_res[kTA];
+
+    const int tiles = d.n_audio / kTA;
+    const int c = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int i0 = tile * kTA;
+    const int tid = threadIdx.x;
+    const int s_lo = 4 * i0 - 124;               // first fm_out sample staged (block relative)
+    const int n = d.n_fm_out;
+    const float2* x_c = fm_out_iq + (size_t)c * n;
+    const float* dt_c = pll_dt + (size_t)c * n;
+
+    if (tid < 128) { tap_lpr[tid] = b_lpr[(size_t)c * 128 + tid]; tap_lmr[tid] = b_lmr[(size_t)c * 128 + tid]; }
+    const float off_cur = st(state, S_LMR_PHASE_CUR, d.C, c), off_prev = st(state, S_LMR_PHASE_PREV, d.C, c);
+
+    for (int e = tid; e < kXS; e += 256) {
+        const int s = s_lo + e;
+        float2 x; float dt; float off;
+        if (s < 0) { x = iq_tail_in[(size_t)c * 128 + 128 + s]; dt = dt_tail_in[(size_t)c * 128 + 128 + s]; off = off_prev; }
+        else { x = x_c[s]; dt = dt_c[s]; off = off_cur; }
+        lpr_ph[(e & 3) * kP4 + (e >> 2)] = x.x;
+        lmr_ph[(e & 3) * kP4 + (e >> 2)] = harmonic_mix(x, dt, 2.0f, off, off + 0.25f);
+        if (e >= 4) {
+            const int e8 = e - 4;
+            rds_ph[(e8 & 7) * kP8 + (e8 >> 3)] = harmonic_mix(x, dt, 3.0f, 0.0f, 0.25f);
+        }
+    }
+    __syncthreads();
+
+    float lmr_re = 0.0f, lmr_im = 0.0f;
+    if (tid < 128) {
+        // L-R: complex dot over 128 taps, 4 lane accumulators per rail (c32_f32_cum_mul_avx order)
+        const int ii = tid;
+        float ar[4] = {0.f, 0.f, 0.f, 0.f}, ai[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int jj = 0; jj < 32; jj++) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const float2 v = lmr_ph[p * kP4 + ii + jj];
+                const float b = tap_lmr[4 * jj + p];
+                ar[p] = fmaf(v.x, b, ar[p]);
+                ai[p] = fmaf(v.y, b, ai[p]);
+            }
+        }
+        lmr_re = (ar[0] + ar[2]) + (ar[1] + ar[3]);
+        lmr_im = (ai[0] + ai[2]) + (ai[1] + ai[3]);
+    } else {
+        // L+R: real rail of the complex dot; RDS: one rail per thread
+        const int t2 = tid - 128;
+        {
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int jj = 0; jj < 32; jj++) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) a[p] = fmaf(lpr_ph[p * kP4 + t2 + jj], tap_lpr[4 * jj + p], a[p]);
+            }
+            lpr_res[t2] = (a[0] + a[2]) + (a[1] + a[3]);
+        }
+        {
+            const int rr = t2 & 63, rail = t2 >> 6;
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            const float* ph = reinterpret_cast<const float*>(rds_ph) + rail;
+#pragma unroll 4
+            for (int jj = 0; jj < 16; jj++) {
+#pragma unroll
+                for (int p = 0; p < 8; p++) a[p & 3] = fmaf(ph[2 * (p * kP8 + rr + jj)], rds_taps.b[8 * jj + p], a[p & 3]);
+            }
+            const float v = (a[0] + a[2]) + (a[1] + a[3]);
+            reinterpret_cast<float*>(rds)[2 * ((size_t)c * d.n_rds + i0 / 2 + rr) + rail] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int ii = tid, i = i0 + ii;
+        if ((i % 10) == 0) {
+            // reference :500-510: estimate against the +-pi/2 constellation
+            const float ph = fmd_atan2f(lmr_im, lmr_re);
+            const float half_pi = bits_f32(kHalfPiBits);
+            lmr_est[(size_t)c * d.n_est + i / 10] = (ph > 0.0f) ? (half_pi - ph) : (-half_pi - ph);
+        }
+        const float lpr = lpr_res[ii], lmr = lmr_im;
+        const int mode = (int)mixctl[2 * c];
+        const float kmix = mixctl[2 * c + 1];
+        float l, r;
+        if (mode == FMD_AUDIO_STEREO) { l = fmaf(lmr, kmix, lpr); r = fmaf(-lmr, kmix, lpr); }
+        else if (mode == FMD_AUDIO_LMR) { l = lmr; r = lmr; }
+        else { l = lpr; r = lpr; }
+        reinterpret_cast<float2*>(audio)[(size_t)c * d.n_audio + i] = make_float2(l + l, r + r);
+        if (keep_taps) { lpr_out[(size_t)c * d.n_audio + i] = lpr; lmr_out[(size_t)c * d.n_audio + i] = lmr; }
+    }
+    // history for the next block: last 128 fm_out_iq / pll_dt samples
+    if (tile == tiles - 1 && tid < 128) {
+        iq_tail_out[(size_t)c * 128 + tid] = x_c[n - 128 + tid];
+        dt_tail_out[(size_t)c * 128 + tid] = dt_c[n - 128 + tid];
+    }
+}
+
+// =============================================================================================
+// k_rds_sync — reference ExtractComponents :511-516 (phase integrate), SynchroniseRDS :538-547,
+// AGC_Filter (agc.h:12-30), BPSK_Synchroniser::Process (bpsk_synchroniser.cpp:94-186) with TED_Clock
+// (ted_clock.cpp:18-44), Zero_Crossing_Detector, Trigger_Cooldown, and the differential Manchester
+// decoder (rds_decoder/differential_manchester_decoder.h:32-60).  Lane per channel.
+// =============================================================================================
+__global__ __launch_bounds__(kWave) void k_rds_sync(Dims d, float2* __restrict__ rds, const float* __restrict__ lmr_est,
+                                                    float* __restrict__ state, LoopCoeffs k, float* __restrict__ rds_sym,
+                                                    float2* __restrict__ rds_raw_sym, int* __restrict__ rds_count,
+                                                    uint8_t* __restrict__ rds_bytes, int* __restrict__ rds_bytes_count,
+                                                    int bytes_cap, int keep_taps) {
+    __shared__ __attribute__((aligned(16))) float2 xin[2][kWave * kRowC];
+    const int lane = threadIdx.x, c0 = blockIdx.x * kWave, c = c0 + lane;
+    const bool live = c < d.C;
+    const int cs = live ? c : d.C - 1;
+    const int n = d.n_rds, chunks = n / kChunk;
+
+    // a11: integrate the mean L-R phase error (sequential sum in sample order)
+    {
+        float sum = 0.0f;
+        const float* e = lmr_est + (size_t)cs * d.n_est;
+        for (int i = 0; i < d.n_est; i++) sum = sum + e[i];
+        const float avg = sum / (float)d.n_est;
+        const float cur = st(state, S_LMR_PHASE_CUR, d.C, cs);
+        const float acc = fmaf(avg, 0.1f, cur);
+        const float nxt = fmodf(acc, bits_f32(kTwoPiBits));
+        if (live) { st(state, S_LMR_PHASE_PREV, d.C, c) = cur; st(state, S_LMR_PHASE_CUR, d.C, c) = nxt; }
+    }
+
+    // a13: AGC power pass
+    float power = 0.0f;
+    ChunkRegsC regs = chunk_load_c(rds, n, c0, d.C, 0);
+    for (int ch = 0; ch < chunks; ch++) {
+        float2* buf = xin[ch & 1];
+        chunk_store_c(regs, buf);
+        __syncthreads();
+        regs = chunk_load_c(rds, n, c0, d.C, (ch + 1 < chunks ? ch + 1 : 0) * kChunk);
+#pragma unroll 8
+        for (int t = 0; t < kChunk; t++) {
+            const float2 x = buf[lane * kRowC + t];
+            power = power + fmaf(x.x, x.x, x.y * x.y);
+        }
+    }
+    float gain = st(state, S_AGC_RDS_GAIN, d.C, cs);
+    {
+        const float target_gain = sqrtf((0.5f / power) * (float)n);
+        gain = fmaf(target_gain - gain, 0.2f, gain);
+    }
+
+    // a14: BPSK synchroniser state
+    float pll_x1 = st(state, S_B_PLL_X1, d.C, cs), pll_y1 = st(state, S_B_PLL_Y1, d.C, cs);
+    float pll_int = st(state, S_B_PLL_INT, d.C, cs), pll_err = st(state, S_B_PLL_ERR, d.C, cs), mix_t = st(state, S_B_MIX_T, d.C, cs);
+    float zcd_xn = st(state, S_B_ZCD_XN, d.C, cs);
+    int cooldown = __float_as_int(st(state, S_B_COOLDOWN, d.C, cs));
+    float ted_err = st(state, S_B_TED_ERR, d.C, cs), ted_x1 = st(state, S_B_TED_X1, d.C, cs), ted_y1 = st(state, S_B_TED_Y1, d.C, cs);
+    float ted_int = st(state, S_B_TED_INT, d.C, cs), clock = st(state, S_B_CLOCK, d.C, cs);
+    float dump_r = st(state, S_B_DUMP_R, d.C, cs), dump_i = st(state, S_B_DUMP_I, d.C, cs);
+    // Manchester decoder state: flags = is_read_bit | prev_bit<<1 | bit_index<<2 | byte_index<<5
+    unsigned mflags = __float_as_uint(st(state, S_M_FLAGS, d.C, cs));
+    unsigned mbuf[4] = {__float_as_uint(st(state, S_M_BUF0, d.C, cs)), __float_as_uint(st(state, S_M_BUF1, d.C, cs)),
+                        __float_as_uint(st(state, S_M_BUF2, d.C, cs)), __float_as_uint(st(state, S_M_BUF3, d.C, cs))};
+    int n_sym = 0, n_bytes = 0;
+
+    const float Ts = 1.0f / 16e3f;
+    const float KTs_pi = (10.0f * Ts) * (2e3f / 16e3f);
+    const float half_pi = bits_f32(kHalfPiBits), two_over_pi = bits_f32(kTwoOverPiBits);
+
+    // (the power pass left chunk 0 in `regs` again)
+    for (int ch = 0; ch < chunks; ch++) {
+        float2* buf = xin[ch & 1];
+        __syncthreads();
+        chunk_store_c(regs, buf);
+        __syncthreads();
+        regs = chunk_load_c(rds, n, c0, d.C, (ch + 1 < chunks ? ch + 1 : ch) * kChunk);
+        for (int t = 0; t < kChunk; t++) {
+            const float2 xr = buf[lane * kRowC + t];
+            const float p = gain * xr.x, q = gain * xr.y;
+            if (keep_taps) buf[lane * kRowC + t] = make_float2(p, q);
+            // carrier PLL PI controller
+            const float lt0 = fmaf(pll_x1, k.bpsk_b0, pll_y1 * k.bpsk_a0);
+            const float pll_lpf = (0.0f + lt0) + fmaf(pll_err, k.bpsk_b1, 0.0f);
+            pll_x1 = pll_err; pll_y1 = pll_lpf;
+            pll_int = clampf(fmaf(pll_err, KTs_pi, pll_int), -1.0f, 1.0f);
+            const float PI_pll = fmaf(pll_lpf, 0.3f, pll_int);
+            // PLL_Mixer::Update: f_center 0, f_gain 10
+            const float control = clampf(PI_pll * 1.0f, -1.0f, 1.0f);
+            const float freq = fmaf(control, 10.0f, 0.0f);
+            const float yy = fmaf(freq, Ts, mix_t);
+            mix_t = yy - round_half_away(yy);
+            float dt_cos = mix_t + 0.25f;
+            dt_cos = dt_cos - round_half_away(dt_cos);
+            const float ps = cheb_sine_scalar(mix_t), pc = cheb_sine_scalar(dt_cos);
+            const float iq_r = fmaf(pc, p, -(q * ps));
+            const float iq_i = fmaf(p, ps, q * pc);
+            // zero crossing on Q with hold-off
+            bool is_zcd = 0.0f > (iq_i * zcd_xn);
+            zcd_xn = iq_i;
+            if (is_zcd && cooldown == 0) { cooldown = 4; }
+            else { if (cooldown > 0) cooldown--; is_zcd = false; }
+            if (is_zcd) { float e2 = clock + clock; if (clock > 0.5f) e2 = e2 - 2.0f; ted_err = e2; }
+            // TED PI controller
+            const float tt0 = fmaf(ted_x1, k.ted_b0, ted_y1 * k.ted_a0);
+            const float ted_lpf = (0.0f + tt0) + fmaf(ted_err, k.ted_b1, 0.0f);
+            ted_x1 = ted_err; ted_y1 = ted_lpf;
+            ted_int = clampf(fmaf(ted_err, KTs_pi, ted_int), -1.0f, 1.0f);
+            const float PI_ted = fmaf(ted_lpf, 0.3f, ted_int);
+            // integrate and dump
+            dump_r = fmaf(0.25f, iq_r, dump_r);
+            dump_i = fmaf(0.25f, iq_i, dump_i);
+            // TED_Clock::update: fcenter 2000, fgain 1500
+            const float ccontrol = clampf((-PI_ted) * 1.0f, -1.0f, 1.0f);
+            const float cfreq = fmaf(ccontrol, 1.5e3f, 2e3f);
+            const float dd = cfreq * Ts;
+            const float cy = dd + clock;
+            const float thr = fmaf(-dd, 0.5f, 1.0f);
+            if (thr > cy) {
+                clock = cy;
+            } else {
+                clock = 0.0f;
+                const float sr = dump_r, si = dump_i;
+                dump_r = 0.0f; dump_i = 0.0f;
+                const float phs = fmd_atan2f(si, sr);
+                const float est = (phs > 0.0f) ? (half_pi - phs) : (-half_pi - phs);
+                pll_err = est * two_over_pi;
+                if (live) {
+                    rds_sym[(size_t)c * n + n_sym] = si;
+                    if (keep_taps) rds_raw_sym[(size_t)c * n + n_sym] = make_float2(sr, si);
+                }
+                n_sym++;
+                // differential Manchester: every second symbol, bit = sign(cur) xor sign(prev), MSB first
+                mflags ^= 1u;
+                if (mflags & 1u) {
+                    const unsigned cur = (si > 0.0f) ? 1u : 0u;
+                    const unsigned bit = cur ^ ((mflags >> 1) & 1u);
+                    mflags = (mflags & ~2u) | (cur << 1);
+                    unsigned bit_index = (mflags >> 2) & 7u, byte_index = (mflags >> 5) & 31u;
+                    const unsigned word = byte_index >> 2, shift = (byte_index & 3u) * 8u;
+                    if (bit_index == 0u) mbuf[word] &= ~(0xffu << shift);
+                    mbuf[word] |= (bit << (7u - bit_index)) << shift;
+                    bit_index++;
+                    byte_index += bit_index >> 3;
+                    bit_index &= 7u;
+                    if (byte_index == 16u) {
+                        byte_index = 0u;
+                        if (live && n_bytes + 16 <= bytes_cap) {
+                            uint32_t* o = reinterpret_cast<uint32_t*>(rds_bytes + (size_t)c * bytes_cap + n_bytes);
+                            o[0] = mbuf[0]; o[1] = mbuf[1]; o[2] = mbuf[2]; o[3] = mbuf[3];
+                        }
+                        n_bytes += 16;
+                    }
+                    mflags = (mflags & 3u) | (bit_index << 2) | (byte_index << 5);
+                }
+            }
+        }
+        if (keep_taps) {
+            // write the post-AGC RDS signal back (reference GetRDSOutput)
+            __syncthreads();
+            const int row = lane >> 4, col = lane & 15;
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) {
+                const int r = 4 * kk + row, chn = c0 + r;
+                if (chn < d.C) *reinterpret_cast<float4*>(rds + (size_t)chn * n + ch * kChunk + 2 * col) =
+                    *reinterpret_cast<const float4*>(buf + r * kRowC + 2 * col);
+            }
+        }
+    }
+    if (live) {
+        st(state, S_AGC_RDS_GAIN, d.C, c) = gain;
+        st(state, S_B_PLL_X1, d.C, c) = pll_x1; st(state, S_B_PLL_Y1, d.C, c) = pll_y1; st(state, S_B_PLL_INT, d.C, c) = pll_int;
+        st(state, S_B_PLL_ERR, d.C, c) = pll_err; st(state, S_B_MIX_T, d.C, c) = mix_t; st(state, S_B_ZCD_XN, d.C, c) = zcd_xn;
+        st(state, S_B_COOLDOWN, d.C, c) = __int_as_float(cooldown);
+        st(state, S_B_TED_ERR, d.C, c) = ted_err; st(state, S_B_TED_X1, d.C, c) = ted_x1; st(state, S_B_TED_Y1, d.C, c) = ted_y1;
+        st(state, S_B_TED_INT, d.C, c) = ted_int; st(state, S_B_CLOCK, d.C, c) = clock;
+        st(state, S_B_DUMP_R, d.C, c) = dump_r; st(state, S_B_DUMP_I, d.C, c) = dump_i;
+        st(state, S_M_FLAGS, d.C, c) = __uint_as_float(mflags);
+        st(state, S_M_BUF0, d.C, c) = __uint_as_float(mbuf[0]); st(state, S_M_BUF1, d.C, c) = __uint_as_float(mbuf[1]);
+        st(state, S_M_BUF2, d.C, c) = __uint_as_float(mbuf[2]); st(state, S_M_BUF3, d.C, c) = __uint_as_float(mbuf[3]);
+        rds_count[c] = n_sym;
+        rds_bytes_count[c] = n_bytes;
+    }
+}
+
+// =============================================================================================
+// optional de-emphasis path — reference Run_FM_Demodulate :403-410: IIR_Filter<float> K=2 in place on
+// fm_out (serial per channel), then the Hilbert FIR.  k_front writes fm_out when any channel asks for it.
+// =============================================================================================
+__global__ __launch_bounds__(kWave) void k_deemphasis(Dims d, float* __restrict__ fm_out, const float* __restrict__ deemph, float* __restrict__ state) {
+    const int c = blockIdx.x * kWave + threadIdx.x;
+    if (c >= d.C) return;
+    const float b0 = deemph[4 * c + 0], b1 = deemph[4 * c + 1], a0 = deemph[4 * c + 2];
+    if (deemph[4 * c + 3] == 0.0f) return;
+    float x1 = st(state, S_DE_X1, d.C, c), y1 = st(state, S_DE_Y1, d.C, c);
+    float* row = fm_out + (size_t)c * d.n_fm_out;
+    for (int i = 0; i < d.n_fm_out; i++) {
+        const float x = row[i];
+        const float t0 = fmaf(x1, b0, y1 * a0);
+        const float y = (0.0f + t0) + fmaf(x, b1, 0.0f);
+        x1 = x; y1 = y;
+        row[i] = y;
+    }
+    st(state, S_DE_X1, d.C, c) = x1; st(state, S_DE_Y1, d.C, c) = y1;
+}
+
+__global__ __launch_bounds__(256) void k_hilbert(Dims d, const float* __restrict__ fm_out, const float* __restrict__ fo_tail_in,
+                                                 float* __restrict__ fo_tail_out, float2* __restrict__ fm_out_iq, FrontTaps taps) {
+    constexpr int T = 256;
+    __shared__ float fo[T + 64];
+    const int tiles = d.n_fm_out / T;
+    const int c = blockIdx.x / tiles, tile = blockIdx.x % tiles, o0 = tile * T, tid = threadIdx.x;
+    const float* row = fm_out + (size_t)c * d.n_fm_out;
+    for (int uu = tid; uu < T + 64; uu += 256) {
+        const int u = o0 - 64 + uu;
+        fo[uu] = (u < 0) ? fo_tail_in[(size_t)c * 64 + 64 + u] : row[u];
+    }
+    __syncthreads();
+    const int oo = tid;
+    float l1 = 0.f, l3 = 0.f, l5 = 0.f, l7 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        l1 = fmaf(fo[oo + 1 + 8 * k], taps.b_hilbert_odd[4 * k + 0], l1);
+        l3 = fmaf(fo[oo + 3 + 8 * k], taps.b_hilbert_odd[4 * k + 1], l3);
+        l5 = fmaf(fo[oo + 5 + 8 * k], taps.b_hilbert_odd[4 * k + 2], l5);
+        l7 = fmaf(fo[oo + 7 + 8 * k], taps.b_hilbert_odd[4 * k + 3], l7);
+    }
+    const float im = (0.0f + ((l1 + l5) + (l3 + l7))) + 0.0f;
+    fm_out_iq[(size_t)c * d.n_fm_out + o0 + oo] = make_float2(fo[oo + 32], im);
+    if (tile == tiles - 1 && tid < 64) fo_tail_out[(size_t)c * 64 + tid] = row[d.n_fm_out - 64 + tid];
+}
+
+// fresh-construction state (reference constructors: AGC gain 0.1 agc.h:10, everything else zero)
+__global__ void k_reset(Dims d, float* __restrict__ state) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.C) return;
+    for (int f = 0; f < S_NUM_FIELDS; f++) st(state, f, d.C, c) = 0.0f;
+    st(state, S_AGC_PILOT_GAIN, d.C, c) = 0.1f;
+    st(state, S_AGC_RDS_GAIN, d.C, c) = 0.1f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launch sequence
+// ---------------------------------------------------------------------------------------------
+template <int M, typename InT>
+static hipError_t launch_front(const LaunchCtx& ctx, const InT* d_iq, hipStream_t s) {
+    using G = FrontGeom<M>;
+    const Dims& d = ctx.d;
+    const int tiles = d.n_fm_out / G::T;
+    const size_t lds = sizeof(float) * G::LDS_FLOATS;
+    auto kern = k_front<M, InT>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * d.C)), dim3(256), lds, s, d, d_iq, ctx.b.base_tail[ctx.parity],
+                       ctx.b.base_tail[ctx.parity ^ 1], ctx.b.fm_out_iq, ctx.b.fm_out, ctx.b.fo_tail[ctx.parity ^ 1], ctx.front,
+                       ctx.any_deemph);
+    return hipGetLastError();
+}
+
+template <typename InT>
+static hipError_t launch_block(const LaunchCtx& ctx, const InT* d_iq, hipStream_t s, ProfileMarks* marks) {
+    const Dims& d = ctx.d;
+    const Buffers& b = ctx.b;
+    hipError_t e = hipSuccess;
+    auto mark = [&](const char* name) {
+        if (!marks) return;
+        if (marks->n == 0) (void)hipEventRecord(marks->ev[0], s);
+        (void)name;
+    };
+    auto done = [&](const char* name) {
+        if (!marks || marks->n >= ProfileMarks::kMax) return;
+        marks->name[marks->n] = name;
+        marks->n++;
+        (void)hipEventRecord(marks->ev[marks->n], s);
+    };
+    if (marks) marks->n = 0;
+    mark("begin");
+    if (d.m == 1) e = launch_front<1, InT>(ctx, d_iq, s);
+    else if (d.m == 4) e = launch_front<4, InT>(ctx, d_iq, s);
+    else e = launch_front<8, InT>(ctx, d_iq, s);
+    if (e != hipSuccess) return e;
+    done("k_front");
+    const unsigned waves = (unsigned)((d.C + kWave - 1) / kWave);
+    if (ctx.any_deemph) {
+        hipLaunchKernelGGL(k_deemphasis, dim3(waves), dim3(kWave), 0, s, d, b.fm_out, b.deemph, b.state);
+        hipLaunchKernelGGL(k_hilbert, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, b.fm_out, b.fo_tail[ctx.parity],
+                           b.fo_tail[ctx.parity ^ 1], b.fm_out_iq, ctx.front);
+        done("k_deemphasis+k_hilbert");
+    }
+    hipLaunchKernelGGL(k_pilot_power, dim3(waves), dim3(kWave), 0, s, d, b.fm_out_iq, b.state, ctx.loops);
+    done("k_pilot_power");
+    hipLaunchKernelGGL(k_pilot_pll, dim3(waves), dim3(kWave), 0, s, d, b.fm_out_iq, b.pll_dt, b.state, ctx.loops);
+    done("k_pilot_pll");
+    hipLaunchKernelGGL(k_extract, dim3((unsigned)(d.n_audio / kTA * d.C)), dim3(256), 0, s, d, b.fm_out_iq, b.pll_dt,
+                       b.iq_tail[ctx.parity], b.dt_tail[ctx.parity], b.iq_tail[ctx.parity ^ 1], b.dt_tail[ctx.parity ^ 1],
+                       b.b_lpr, b.b_lmr, ctx.rds_taps, b.mix, b.state, b.audio, b.rds, b.lmr_est, b.lpr, b.lmr, ctx.keep_taps);
+    done("k_extract");
+    hipLaunchKernelGGL(k_rds_sync, dim3(waves), dim3(kWave), 0, s, d, b.rds, b.lmr_est, b.state, ctx.loops, b.rds_sym,
+                       b.rds_raw_sym, b.rds_count, b.rds_bytes, b.rds_bytes_count, 16 * (d.n_rds / 256 + 1), ctx.keep_taps);
+    done("k_rds_sync");
+    return hipGetLastError();
+}
+
+hipError_t launch_block_cf32(const LaunchCtx& ctx, const float2* d_iq, hipStream_t stream, ProfileMarks* marks) {
+    return launch_block<float2>(ctx, d_iq, stream, marks);
+}
+hipError_t launch_block_u8(const LaunchCtx& ctx, const uchar2* d_iq, hipStream_t stream, ProfileMarks* marks) {
+    return launch_block<uchar2>(ctx, d_iq, stream, marks);
+}
+
+template <int M, typename InT>
+static hipError_t prepare_front() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_front<M, InT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(sizeof(float) * FrontGeom<M>::LDS_FLOATS));
+}
+
+hipError_t prepare_kernels() {
+    hipError_t e;
+    if ((e = prepare_front<1, float2>()) != hipSuccess) return e;
+    if ((e = prepare_front<4, float2>()) != hipSuccess) return e;
+    if ((e = prepare_front<8, float2>()) != hipSuccess) return e;
+    if ((e = prepare_front<1, uchar2>()) != hipSuccess) return e;
+    if ((e = prepare_front<4, uchar2>()) != hipSuccess) return e;
+    if ((e = prepare_front<8, uchar2>()) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+int front_tail_len(int m) { return m == 1 ? FrontGeom<1>::TAIL : (m == 4 ? FrontGeom<4>::TAIL : FrontGeom<8>::TAIL); }
+
+hipError_t launch_reset_state(const LaunchCtx& ctx, hipStream_t stream) {
+    hipLaunchKernelGGL(k_reset, dim3((unsigned)((ctx.d.C + 255) / 256)), dim3(256), 0, stream, ctx.d, ctx.b.state);
+    return hipGetLastError();
+}
+
+}  // namespace fmd

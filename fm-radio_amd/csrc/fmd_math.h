@@ -1,0 +1,178 @@
+// Device math for the FM demodulation kernels.
+//
+// Everything here is written so that every operation rounds exactly once, in a fixed order:
+// the translation units that include this header are compiled with -ffp-contract=off and all
+// fused multiply-adds are explicit fmaf() calls.  The orders are those of the reference's
+// AVX2+FMA build (see DESIGN.md "Arithmetic contract"), so the GPU results can be compared
+// bit-for-bit with the CPU path.
+//
+// The header also compiles as plain host C++ (FMD_HD empty) so tests can check fmd_atan2f
+// against the host libm over large random sweeps without a GPU.
+#pragma once
+
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define FMD_HD __host__ __device__ __forceinline__
+#else
+#define FMD_HD static inline
+#endif
+
+namespace fmd {
+
+FMD_HD float bits_f32(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f; memcpy(&f, &u, 4); return f;
+#endif
+}
+FMD_HD uint32_t f32_bits(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    uint32_t u; memcpy(&u, &f, 4); return u;
+#endif
+}
+
+constexpr uint32_t kPiBits = 0x40490fdbu;         // (float)M_PI
+constexpr uint32_t kTwoPiBits = 0x40c90fdbu;      // 2*pi
+constexpr uint32_t kHalfPiBits = 0x3fc90fdbu;     // pi/2
+constexpr uint32_t kTwoOverPiBits = 0x3f22f983u;  // 2/pi
+constexpr uint32_t kPredHalfBits = 0x3effffffu;   // nextafter(0.5, 0)
+
+// ---------------------------------------------------------------------------------------------
+// atan2f / atanf — the FDLIBM float algorithm (Sun Microsystems; e_atan2f.c / s_atanf.c) that the
+// host C library the reference links against implements (glibc 2.35, sysdeps/ieee754/flt-32).
+// The reference calls std::atan2 in its discriminator (reference src/fm_demod/fm_demod.cpp:40),
+// pilot PLL (broadcast_fm_demod.cpp:450), L-R phase tracker (:502) and BPSK synchroniser
+// (bpsk_synchroniser.cpp:159); reproducing the same sequence of IEEE operations keeps those
+// feedback loops bit-identical on the GPU.  The argument reduction is written branch-free
+// (one select per range, ONE division) so a wavefront never diverges on it.
+// ---------------------------------------------------------------------------------------------
+FMD_HD float atanf_core(float x) {
+    const uint32_t hx = f32_bits(x);
+    const uint32_t ix = hx & 0x7fffffffu;
+    const bool neg = (hx >> 31) != 0;
+    if (ix >= 0x4c000000u) {  // |x| >= 2^25 (or NaN)
+        if (ix > 0x7f800000u) return x + x;
+        const float r = bits_f32(0x3fc90fdau) + bits_f32(0x33a22168u);
+        return neg ? -r : r;
+    }
+    const float ax = fabsf(x);
+    // id: -1 (|x| < 7/16), 0 (< 11/16), 1 (< 19/16), 2 (< 39/16), 3 (else)
+    const bool r_small = ix < 0x3ee00000u;
+    const bool r0 = ix < 0x3f300000u;
+    const bool r1 = ix < 0x3f980000u;
+    const bool r2 = ix < 0x401c0000u;
+    // numerators / denominators of the reduced argument, each rounded as the C expression would
+    const float two_x = 2.0f * ax;
+    const float n0 = two_x - 1.0f, d0 = 2.0f + ax;
+    const float n1 = ax - 1.0f, d1 = ax + 1.0f;
+    const float n2 = ax - 1.5f, d2 = 1.0f + 1.5f * ax;
+    float num = r2 ? n2 : -1.0f, den = r2 ? d2 : ax;
+    num = r1 ? n1 : num; den = r1 ? d1 : den;
+    num = r0 ? n0 : num; den = r0 ? d0 : den;
+    float hi = r2 ? bits_f32(0x3f7b985eu) : bits_f32(0x3fc90fdau);
+    float lo = r2 ? bits_f32(0x33140fb4u) : bits_f32(0x33a22168u);
+    hi = r1 ? bits_f32(0x3f490fdau) : hi; lo = r1 ? bits_f32(0x33222168u) : lo;
+    hi = r0 ? bits_f32(0x3eed6338u) : hi; lo = r0 ? bits_f32(0x31ac3769u) : lo;
+    const float xr = r_small ? x : (num / den);
+    if (r_small && ix < 0x31000000u) return x;  // |x| < 2^-29
+    const float z = xr * xr;
+    const float w = z * z;
+    // odd / even halves of sum aT[i] z^(i+1), plain multiply-add chain (no fusing)
+    float s1 = bits_f32(0x3d4bda59u) + w * bits_f32(0x3c8569d7u);   // aT[8] + w*aT[10]
+    s1 = bits_f32(0x3d886b35u) + w * s1;                             // aT[6]
+    s1 = bits_f32(0x3dba2e6eu) + w * s1;                             // aT[4]
+    s1 = bits_f32(0x3e124925u) + w * s1;                             // aT[2]
+    s1 = bits_f32(0x3eaaaaabu) + w * s1;                             // aT[0]
+    s1 = z * s1;
+    float s2 = bits_f32(0xbd6ef16bu) + w * bits_f32(0xbd15a221u);   // aT[7] + w*aT[9]
+    s2 = bits_f32(0xbd9d8795u) + w * s2;                             // aT[5]
+    s2 = bits_f32(0xbde38e38u) + w * s2;                             // aT[3]
+    s2 = bits_f32(0xbe4ccccdu) + w * s2;                             // aT[1]
+    s2 = w * s2;
+    const float p = xr * (s1 + s2);
+    if (r_small) return xr - p;
+    const float r = hi - ((p - lo) - xr);
+    return neg ? -r : r;
+}
+
+FMD_HD float fmd_atan2f(float y, float x) {
+    const uint32_t hx = f32_bits(x), hy = f32_bits(y);
+    const uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+    const float pi = bits_f32(kPiBits), pi_o_2 = bits_f32(kHalfPiBits), pi_lo = bits_f32(0xb3bbbd2eu);
+    const float tiny = 1.0e-30f;
+    if (ix > 0x7f800000u || iy > 0x7f800000u) return x + y;  // NaN
+    if (hx == 0x3f800000u) return atanf_core(y);              // x == 1
+    const uint32_t m = ((hy >> 31) & 1u) | ((hx >> 30) & 2u);
+    if (iy == 0u) {  // y == 0
+        if (m < 2u) return y;
+        return (m == 2u) ? (pi + tiny) : (-pi - tiny);
+    }
+    if (ix == 0u) return (hy >> 31) ? (-pi_o_2 - tiny) : (pi_o_2 + tiny);  // x == 0
+    if (ix == 0x7f800000u) {  // x == inf
+        const float pi_o_4 = bits_f32(0x3f490fdbu);
+        if (iy == 0x7f800000u) {
+            switch (m) {
+                case 0: return pi_o_4 + tiny;
+                case 1: return -pi_o_4 - tiny;
+                case 2: return 3.0f * pi_o_4 + tiny;
+                default: return -3.0f * pi_o_4 - tiny;
+            }
+        }
+        switch (m) {
+            case 0: return 0.0f;
+            case 1: return -0.0f;
+            case 2: return pi + tiny;
+            default: return -pi - tiny;
+        }
+    }
+    if (iy == 0x7f800000u) return (hy >> 31) ? (-pi_o_2 - tiny) : (pi_o_2 + tiny);
+    const int32_t k = ((int32_t)iy - (int32_t)ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if ((hx >> 31) && k < -60) z = 0.0f;
+    else z = atanf_core(fabsf(y / x));
+    switch (m) {
+        case 0: return z;
+        case 1: return bits_f32(f32_bits(z) ^ 0x80000000u);
+        case 2: return pi - (z - pi_lo);
+        default: return (z - pi_lo) - pi;
+    }
+}
+
+// std::round as the reference build inlines it: trunc(x + copysign(pred(0.5), x))
+FMD_HD float round_half_away(float x) { return truncf(x + copysignf(bits_f32(kPredHalfBits), x)); }
+
+// reference src/dsp/clamp.h:3-8
+FMD_HD float clampf(float x, float lo, float hi) {
+    float y = (x > lo) ? x : lo;
+    y = (y < hi) ? y : hi;
+    return y;
+}
+
+// chebyshev sine, reference src/dsp/simd/chebyshev_sine.h:13-41 / :78-104.
+FMD_HD float cheb_poly(float z) {
+    float p = fmaf(3.20396066f, z, -14.07150173f);
+    p = fmaf(p, z, 38.50016403f);
+    p = fmaf(p, z, -67.07687378f);
+    p = fmaf(p, z, 64.83583069f);
+    p = fmaf(p, z, -25.13274193f);
+    return p;
+}
+// scalar call sites (PLL loops): ((z - 1/4) x) g(z)
+FMD_HD float cheb_sine_scalar(float x) {
+    const float z = x * x;
+    return ((z - 0.25f) * x) * cheb_poly(z);
+}
+// vector call site (harmonic mixer): (x g(z)) (z + -1/4)
+FMD_HD float cheb_sine_vector(float x) {
+    const float z = x * x;
+    return (x * cheb_poly(z)) * (z + -0.25f);
+}
+
+}  // namespace fmd

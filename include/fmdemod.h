@@ -1,0 +1,156 @@
+/* fmdemod.h — C ABI of the MI355X-native batched broadcast-FM demodulator (libfmdemod.so).
+ *
+ * Drop-in boundary for the demodulator API of williamyang98/FM-Radio (reference src/fm_demod):
+ * one fmd_handle is C independent `Broadcast_FM_Demod` instances (reference
+ * src/fm_demod/broadcast_fm_demod.h:91-299) advanced in lock-step on one GPU.  Every entry point
+ * names the reference member it replaces.  Plain pointers and sizes only; no C++ / torch types.
+ *
+ * Threading (same contract as the reference): one caller thread per handle; outputs are views
+ * that stay valid until the next fmd_process_* call on that handle.
+ *
+ * Data layouts (channel-major, time contiguous per channel):
+ *   IQ in      cf32 [C][N][2] float  (or u8 [C][N][2], RTL-SDR style, converted as `(float)u8 - 127`,
+ *              reference src/app.cpp:56-62)
+ *   audio out  f32  [C][N_audio][2]  interleaved L,R   (reference Frame<float>, src/audio/frame.h:6-8)
+ *   RDS syms   f32  [C][N_rds]  first counts[c] entries valid (reference GetRDSPredSymbols(), .h:253)
+ */
+#ifndef FMDEMOD_H
+#define FMDEMOD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMD_API_VERSION 1
+
+typedef struct fmd_handle_s* fmd_handle;
+
+enum {
+    FMD_OK = 0,
+    FMD_ERR_ARG = -1,        /* bad argument / unsupported configuration */
+    FMD_ERR_SIZE = -2,       /* n_samples != block_size or n_channels mismatch: block dropped, nothing emitted
+                                (reference Process(): silent return, broadcast_fm_demod.cpp:311-313) */
+    FMD_ERR_DEVICE = -3,     /* HIP runtime error, see fmd_last_error */
+    FMD_ERR_NO_DEVICE = -4,  /* no usable MI355X: the library has NO CPU fallback */
+    FMD_ERR_NAME = -5        /* unknown stream name */
+};
+
+/* reference Broadcast_FM_Demod_Controls::AudioOut (broadcast_fm_demod.h:80) */
+enum { FMD_AUDIO_LPR = 0, FMD_AUDIO_LMR = 1, FMD_AUDIO_STEREO = 2 };
+
+/* reference Broadcast_FM_Demod(int block_size) (broadcast_fm_demod.h:229) + the hard-wired
+ * Fs_baseband (broadcast_fm_demod.cpp:68), made a parameter. */
+typedef struct {
+    int n_channels;    /* independent stations on this GPU */
+    int block_size;    /* baseband samples per channel per fmd_process call; multiple of 1024*(fs_baseband/256000) */
+    int fs_baseband;   /* 256000 (no first decimator), 1024000 (reference), 2048000 */
+    int device;        /* HIP device ordinal, -1 = current */
+    unsigned flags;    /* FMD_FLAG_* */
+} fmd_config;
+
+#define FMD_FLAG_KEEP_TAPS 1u  /* keep the intermediate streams readable through fmd_get_stream */
+
+/* reference Broadcast_FM_Demod_Controls (broadcast_fm_demod.h:64-89); defaults in fmd_default_controls */
+typedef struct {
+    int   audio_out;               /* FMD_AUDIO_* */
+    float audio_stereo_mix_factor;
+    int   use_deemphasis;
+    int   deemphasis_tus;          /* microseconds */
+    int   lpr_cutoff_hz;
+    int   lmr_cutoff_hz;
+} fmd_controls;
+
+/* reference GetBasebandSampleRate() .. GetAudioSampleRate() (broadcast_fm_demod.h:284-288) + block sizes */
+typedef struct {
+    int fs_baseband, fs_fm_in, fs_fm_out, fs_rds, fs_audio;
+    int n_baseband, n_fm_in, n_fm_out, n_rds, n_audio;
+} fmd_rates;
+
+/* Every designed coefficient the chain uses (reference filter objects, broadcast_fm_demod.cpp:127-291,
+ * bpsk_synchroniser.cpp:26-48).  Same layout as oracle/fm_oracle.h:fmo_coeffs so tests can hand the
+ * library's coefficients to the CPU oracle. */
+typedef struct {
+    int   fs_baseband, m_fm_in;
+    float b_fm_in[64], b_fm_out[64], b_hilbert[65];
+    float pilot_b[3], pilot_a[3];
+    float pll_lpf_b[2], pll_lpf_a[2];
+    float deemph_b[2], deemph_a[2];
+    float b_lpr[128], b_lmr[128], b_rds[128];
+    float ted_lpf_b[2], ted_lpf_a[2];
+    float bpsk_lpf_b[2], bpsk_lpf_a[2];
+    float fm_gain;
+} fmd_coeffs;
+
+int         fmd_api_version(void);
+const char* fmd_status_string(int status);
+/* number of usable gfx950 devices; <= 0 means every other call fails with FMD_ERR_NO_DEVICE */
+int         fmd_device_count(void);
+
+void fmd_default_controls(fmd_controls* c);
+
+/* Broadcast_FM_Demod::Broadcast_FM_Demod (broadcast_fm_demod.cpp:59-305) x n_channels */
+int fmd_create(const fmd_config* cfg, fmd_handle* out);
+/* ~Broadcast_FM_Demod */
+int fmd_destroy(fmd_handle h);
+/* back to the freshly constructed state (zero histories, AGC gain 0.1, PLLs at rest) */
+int fmd_reset(fmd_handle h);
+
+/* GetControls() (broadcast_fm_demod.h:294): channel >= 0 addresses one station, -1 all of them.
+ * Takes effect at the next block boundary, like UpdateFilters() (broadcast_fm_demod.cpp:330-389). */
+int fmd_set_controls(fmd_handle h, int channel, const fmd_controls* c);
+int fmd_get_controls(fmd_handle h, int channel, fmd_controls* c);
+int fmd_get_rates(fmd_handle h, fmd_rates* r);
+int fmd_get_coeffs(fmd_handle h, int channel, fmd_coeffs* k);
+
+/* Broadcast_FM_Demod::Process (broadcast_fm_demod.cpp:309-328) for all channels.
+ * *_dev: `iq` is a DEVICE pointer, work is queued on `stream` (hipStream_t, NULL = default stream) and
+ * the call returns without synchronising.  *_host: `iq` is a host pointer; copies, runs, synchronises. */
+int fmd_process_cf32_dev(fmd_handle h, const float* d_iq, int n_channels, int n_samples, void* stream);
+int fmd_process_u8_dev(fmd_handle h, const uint8_t* d_iq, int n_channels, int n_samples, void* stream);
+int fmd_process_cf32_host(fmd_handle h, const float* iq, int n_channels, int n_samples);
+int fmd_process_u8_host(fmd_handle h, const uint8_t* iq, int n_channels, int n_samples);
+int fmd_synchronize(fmd_handle h);
+
+/* OnAudioOut() / GetAudioOut() (broadcast_fm_demod.h:256,297): device views of the current block */
+int fmd_audio_dev(fmd_handle h, const float** d_audio /* [C][n_audio][2] */);
+/* OnRDSOut() / GetRDSPredSymbols() (broadcast_fm_demod.h:253,298) */
+int fmd_rds_dev(fmd_handle h, const float** d_syms /* [C][n_rds] */, const int** d_counts /* [C] */);
+/* host copies (synchronise first) */
+int fmd_get_audio(fmd_handle h, float* audio /* [C][n_audio][2] */);
+int fmd_get_rds_symbols(fmd_handle h, float* syms /* [C][n_rds] */, int* counts /* [C] */);
+
+/* Parity / GUI taps, the reference's buffer getters (broadcast_fm_demod.h:242-256, :291):
+ *   "fm_out_iq" GetFMOutIQ [C][n_fm_out][2] | "pll_dt" [C][n_fm_out] | "lpr" GetLPRAudioOutput [C][n_audio]
+ *   "lmr" GetLMRAudioOutput [C][n_audio] | "rds" GetRDSOutput (post-AGC) [C][n_rds][2]
+ *   "rds_raw_sym" GetRDSRawSymbols [C][n_rds][2] | "lmr_phase" GetAudioLMRPhaseError [C]
+ *   "agc_pilot_gain" [C] | "agc_rds_gain" [C]
+ * Copies the current block's values to `out` (host); *n_floats receives the float count.  Needs
+ * FMD_FLAG_KEEP_TAPS for the streams a fused pipeline would not otherwise materialise. */
+int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats, size_t* n_floats);
+
+const char* fmd_last_error(fmd_handle h);
+
+/* Differential Manchester decode of the RDS symbol stream on the GPU, one decoder per channel
+ * (reference src/rds_decoder/differential_manchester_decoder.h:25-60; the 16-byte buffer size is the
+ * one src/app.cpp:13-20 uses).  bytes: [C][cap_bytes]; counts[c] = bytes appended for channel c this
+ * block (multiples of 16). */
+int fmd_get_rds_bytes(fmd_handle h, uint8_t* bytes, int cap_bytes_per_channel, int* counts);
+
+/* Per-kernel timing with HIP events recorded on the processing stream (for bench.py's roofline figures).
+ * While enabled, every fmd_process_* call brackets each kernel of the sequence with events; fmd_profile_read
+ * synchronises, accumulates and clears them. */
+typedef struct {
+    char   name[32];     /* kernel name as it appears in rocprofv3 kernel traces (prefix match) */
+    double total_ms;     /* sum of launch durations since the last read */
+    int    launches;
+} fmd_kernel_time;
+int fmd_profile_enable(fmd_handle h, int on);
+int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
