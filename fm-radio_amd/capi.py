@@ -87,6 +87,12 @@ def load_library():
     p = lib_path()
     if not p.exists():
         raise FileNotFoundError(f"{p} missing: run __graft_entry__.build() / make -C {CSRC}")
+    try:
+        # torch bundles its own HIP runtime; load it FIRST so this process ends up with a single libamdhip64
+        # (two runtimes in one process do not see each other's devices, streams or allocations)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(str(p))
     H = C.c_void_p
     L.fmd_api_version.restype = C.c_int
