@@ -10,5 +10,5 @@ The directory name contains a hyphen, so import it through `fmradio_loader.load(
 """
 from .capi import (  # noqa: F401
     FMD_AUDIO_LMR, FMD_AUDIO_LPR, FMD_AUDIO_STEREO, FMD_FLAG_KEEP_TAPS, BatchDemod, Coeffs, Config, Controls, FmdError,
-    Rates, build_library, declared_symbols, lib_path, load_library,
+    Rates, build_library, declared_symbols, default_controls, lib_path, load_library, selftest_atan2,
 )

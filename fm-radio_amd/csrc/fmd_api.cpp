@@ -65,7 +65,9 @@ int dev_alloc(fmd_handle h, T** p, size_t count) {
     void* q = nullptr;
     const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
     HIP_TRY(h, hipMalloc(&q, bytes));
-    HIP_TRY(h, hipMemset(q, 0, bytes));
+    // on the handle's own stream: a null-stream hipMemset is not ordered against the (non-blocking) own_stream, and
+    // could land after the k_reset / control uploads that follow
+    HIP_TRY(h, hipMemsetAsync(q, 0, bytes, h->own_stream));
     h->allocs.push_back(q);
     *p = static_cast<T*>(q);
     return FMD_OK;
@@ -477,6 +479,22 @@ int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats
     if (rc) return rc;
     HIP_TRY(h, hipMemcpy(out, p, sizeof(float) * n, hipMemcpyDeviceToHost));
     return FMD_OK;
+}
+
+int fmd_selftest_atan2(const float* y, const float* x, float* out, size_t n) {
+    if (!y || !x || !out) return FMD_ERR_ARG;
+    if (fmd_device_count() <= 0) return fail(nullptr, FMD_ERR_NO_DEVICE, "no gfx950 device");
+    float *dy = nullptr, *dx = nullptr, *dout = nullptr;
+    const size_t bytes = n * sizeof(float);
+    int rc = FMD_OK;
+    if (hipMalloc(&dy, bytes) != hipSuccess || hipMalloc(&dx, bytes) != hipSuccess || hipMalloc(&dout, bytes) != hipSuccess) rc = FMD_ERR_DEVICE;
+    if (!rc && (hipMemcpy(dy, y, bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice) != hipSuccess)) rc = FMD_ERR_DEVICE;
+    if (!rc && selftest_atan2(dy, dx, dout, n, nullptr) != hipSuccess) rc = FMD_ERR_DEVICE;
+    if (!rc && hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = FMD_ERR_DEVICE;
+    if (dy) (void)hipFree(dy);
+    if (dx) (void)hipFree(dx);
+    if (dout) (void)hipFree(dout);
+    return rc ? fail(nullptr, rc, "selftest_atan2 failed") : FMD_OK;
 }
 
 int fmd_profile_enable(fmd_handle h, int on) {

@@ -107,6 +107,7 @@ struct ProfileMarks {
 hipError_t launch_block_cf32(const LaunchCtx& ctx, const float2* d_iq, hipStream_t stream, ProfileMarks* marks = nullptr);
 hipError_t launch_block_u8(const LaunchCtx& ctx, const uchar2* d_iq, hipStream_t stream, ProfileMarks* marks = nullptr);
 hipError_t launch_reset_state(const LaunchCtx& ctx, hipStream_t stream);
+hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, size_t n, hipStream_t s);
 hipError_t prepare_kernels();          // one-time function attributes (dynamic LDS sizes)
 int front_tail_len(int m);             // input-history samples k_front needs per channel
 

@@ -669,6 +669,16 @@ __global__ __launch_bounds__(256) void k_hilbert(Dims d, const float* __restrict
     if (tile == tiles - 1 && tid < 64) fo_tail_out[(size_t)c * 64 + tid] = row[d.n_fm_out - 64 + tid];
 }
 
+__global__ void k_selftest_atan2(const float* __restrict__ y, const float* __restrict__ x, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fmd_atan2f(y[i], x[i]);
+}
+
+hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_selftest_atan2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_y, d_x, d_out, n);
+    return hipGetLastError();
+}
+
 // fresh-construction state (reference constructors: AGC gain 0.1 agc.h:10, everything else zero)
 __global__ void k_reset(Dims d, float* __restrict__ state) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -101,7 +101,8 @@ FMD_HD float atanf_core(float x) {
     return neg ? -r : r;
 }
 
-FMD_HD float fmd_atan2f(float y, float x) {
+// The algorithm exactly as published, special cases included (NaN, zeros, infinities, |y/x| beyond 2^+-60).
+FMD_HD float fmd_atan2f_full(float y, float x) {
     const uint32_t hx = f32_bits(x), hy = f32_bits(y);
     const uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
     const float pi = bits_f32(kPiBits), pi_o_2 = bits_f32(kHalfPiBits), pi_lo = bits_f32(0xb3bbbd2eu);
@@ -145,14 +146,75 @@ FMD_HD float fmd_atan2f(float y, float x) {
     }
 }
 
+// atanf of a non-negative finite-or-infinite argument, same operations as atanf_core but with every range
+// decision turned into a select: ONE division, no branches, so a wavefront never diverges on it.
+FMD_HD float atanf_pos_branchless(float ax) {
+    const uint32_t ix = f32_bits(ax);
+    const bool r_small = ix < 0x3ee00000u;
+    const bool r0 = ix < 0x3f300000u;
+    const bool r1 = ix < 0x3f980000u;
+    const bool r2 = ix < 0x401c0000u;
+    const float two_x = 2.0f * ax;
+    const float n0 = two_x - 1.0f, d0 = 2.0f + ax;
+    const float n1 = ax - 1.0f, d1 = ax + 1.0f;
+    const float n2 = ax - 1.5f, d2 = 1.0f + 1.5f * ax;
+    float num = r2 ? n2 : -1.0f, den = r2 ? d2 : ax;
+    num = r1 ? n1 : num; den = r1 ? d1 : den;
+    num = r0 ? n0 : num; den = r0 ? d0 : den;
+    float hi = r2 ? bits_f32(0x3f7b985eu) : bits_f32(0x3fc90fdau);
+    float lo = r2 ? bits_f32(0x33140fb4u) : bits_f32(0x33a22168u);
+    hi = r1 ? bits_f32(0x3f490fdau) : hi; lo = r1 ? bits_f32(0x33222168u) : lo;
+    hi = r0 ? bits_f32(0x3eed6338u) : hi; lo = r0 ? bits_f32(0x31ac3769u) : lo;
+    const float quot = num / den;
+    const float xr = r_small ? ax : quot;
+    const float z = xr * xr;
+    const float w = z * z;
+    float s1 = bits_f32(0x3d4bda59u) + w * bits_f32(0x3c8569d7u);
+    s1 = bits_f32(0x3d886b35u) + w * s1;
+    s1 = bits_f32(0x3dba2e6eu) + w * s1;
+    s1 = bits_f32(0x3e124925u) + w * s1;
+    s1 = bits_f32(0x3eaaaaabu) + w * s1;
+    s1 = z * s1;
+    float s2 = bits_f32(0xbd6ef16bu) + w * bits_f32(0xbd15a221u);
+    s2 = bits_f32(0xbd9d8795u) + w * s2;
+    s2 = bits_f32(0xbde38e38u) + w * s2;
+    s2 = bits_f32(0xbe4ccccdu) + w * s2;
+    s2 = w * s2;
+    const float p = xr * (s1 + s2);
+    float r = r_small ? (xr - p) : (hi - ((p - lo) - xr));
+    r = (ix < 0x31000000u) ? ax : r;                                   // |x| < 2^-29: atan x = x
+    r = (ix >= 0x4c000000u) ? bits_f32(kHalfPiBits) : r;               // |x| >= 2^25: atanhi[3]+atanlo[3] = fl(pi/2)
+    return r;
+}
+
+// atan2f used by the kernels.  For finite non-zero x and y (everything a live signal produces) the published
+// algorithm reduces to: z = atanf(|y/x|), then one of four sign/quadrant fix-ups — evaluated here with
+// selects.  Its |y/x| > 2^60 and |y|/x < -2^-60 shortcuts give the same floats as the general path (the
+// shortcut constants equal atanf's own saturation values after rounding; checked exhaustively around the
+// thresholds by tests/test_capi_cpu.py), and x == 1 is atanf(y) which is odd-symmetric in this algorithm.
+// Zeros, infinities and NaNs take the (rare, wave-uniformly skipped) full version.
+FMD_HD float fmd_atan2f(float y, float x) {
+    const uint32_t hx = f32_bits(x), hy = f32_bits(y);
+    const uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+    const bool special = (ix == 0u) | (iy == 0u) | (ix >= 0x7f800000u) | (iy >= 0x7f800000u);
+    const float pi = bits_f32(kPiBits), pi_lo = bits_f32(0xb3bbbd2eu);
+    const float z = atanf_pos_branchless(fabsf(y / x));
+    const float zl = z - pi_lo;
+    const bool sx = (hx >> 31) != 0, sy = (hy >> 31) != 0;
+    const float rpos = sy ? bits_f32(f32_bits(z) ^ 0x80000000u) : z;
+    const float rneg = sy ? (zl - pi) : (pi - zl);
+    float r = sx ? rneg : rpos;
+    if (special) r = fmd_atan2f_full(y, x);
+    return r;
+}
+
 // std::round as the reference build inlines it: trunc(x + copysign(pred(0.5), x))
 FMD_HD float round_half_away(float x) { return truncf(x + copysignf(bits_f32(kPredHalfBits), x)); }
 
 // reference src/dsp/clamp.h:3-8
 FMD_HD float clampf(float x, float lo, float hi) {
-    float y = (x > lo) ? x : lo;
-    y = (y < hi) ? y : hi;
-    return y;
+    // == (x > lo ? x : lo), then (y < hi ? y : hi) for every non-NaN x (vmaxss / vminss in the reference build)
+    return fminf(fmaxf(x, lo), hi);
 }
 
 // chebyshev sine, reference src/dsp/simd/chebyshev_sine.h:13-41 / :78-104.

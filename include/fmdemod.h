@@ -147,6 +147,10 @@ typedef struct {
     double total_ms;     /* sum of launch durations since the last read */
     int    launches;
 } fmd_kernel_time;
+/* Self-test hook: evaluates the kernels' atan2f on the device for n host-side (y, x) pairs, so tests can compare
+ * the device math bit-for-bit with the host libm the reference links (std::atan2, reference fm_demod.cpp:40). */
+int fmd_selftest_atan2(const float* y, const float* x, float* out, size_t n);
+
 int fmd_profile_enable(fmd_handle h, int on);
 int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out);
 

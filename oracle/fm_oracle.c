@@ -196,6 +196,11 @@ float fmo_agc(float* gain, float target_power, float beta, const fmo_cf32* x, fm
     return g;
 }
 
+/* the host libm atan2f over arrays (what std::atan2 resolves to in the reference build); used by tests to pin the device math */
+void fmo_atan2f_array(const float* y, const float* x, float* out, long n) {
+    for (long i = 0; i < n; i++) out[i] = atan2f(y[i], x[i]);
+}
+
 /* FM discriminator — reference src/fm_demod/fm_demod.cpp:30-45 */
 void fmo_discriminator(float* prev_theta, float gain, const fmo_cf32* x, float* y, int n) {
     float prev = *prev_theta;

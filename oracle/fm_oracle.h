@@ -82,6 +82,7 @@ int fmo_manchester_push(fmo_manchester* m, const float* sym, int n, uint8_t* out
 
 /* primitives exported for unit tests */
 float fmo_chebyshev_sine(float x);
+void fmo_atan2f_array(const float* y, const float* x, float* out, long n);
 float fmo_dot_f32(const float* x, const float* b, int n);
 fmo_cf32 fmo_dot_c32(const fmo_cf32* x, const float* b, int n);
 void fmo_decim_c32(fmo_cf32* hist, const float* b, int nn, int m, const fmo_cf32* x, fmo_cf32* y, int n_out);

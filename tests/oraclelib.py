@@ -100,6 +100,7 @@ def lib():
     L.fmo_manchester_push.argtypes = [C.POINTER(Manchester), C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.fmo_chebyshev_sine.restype = C.c_float
     L.fmo_chebyshev_sine.argtypes = [C.c_float]
+    L.fmo_atan2f_array.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
     L.fmo_dot_f32.restype = C.c_float
     L.fmo_dot_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.fmo_dot_c32.restype = CF32
@@ -123,6 +124,14 @@ def lib():
 
 def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def libm_atan2f(y: np.ndarray, x: np.ndarray) -> np.ndarray:
+    """Host libm atan2f (glibc), elementwise."""
+    y = np.ascontiguousarray(y, np.float32); x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(y)
+    lib().fmo_atan2f_array(_ptr(y), _ptr(x), _ptr(out), y.size)
+    return out
 
 
 def default_controls() -> Controls:

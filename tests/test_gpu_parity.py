@@ -177,3 +177,36 @@ def test_roundtrip_properties_at_scale(pkg):
     assert np.array_equal(audio.view(np.uint32), ref_last[idx].view(np.uint32))
     assert np.all(np.isfinite(audio))
     dm.close()
+
+
+def test_device_atan2_equals_host_libm(pkg):
+    """The device atan2f (FDLIBM restatement, branch-free) against the host libm the reference calls: bit-identical
+    over random bit patterns, signal-range values, the range-reduction boundaries and every special value."""
+    rng = np.random.default_rng(5)
+    n = 8_000_000
+    bits = rng.integers(0, 2**32, size=(2, n), dtype=np.uint64).astype(np.uint32)
+    ys = [bits[0].view(np.float32), rng.uniform(-200, 200, n).astype(np.float32), rng.uniform(-1.5, 1.5, n).astype(np.float32)]
+    xs = [bits[1].view(np.float32), rng.uniform(-200, 200, n).astype(np.float32), rng.uniform(-1.5, 1.5, n).astype(np.float32)]
+    # ratios straddling the argument-reduction thresholds and the 2^+-60 / 2^25 shortcuts
+    base = np.array([0.4375, 0.6875, 1.1875, 2.4375, 1.0, 2.0 ** -29, 2.0 ** 25, 2.0 ** 60, 2.0 ** -60, 2.0 ** 61, 2.0 ** -61], np.float32)
+    r = np.concatenate([np.nextafter(b, np.float32(np.inf)) * (1 + np.arange(-2000, 2000, dtype=np.float32) * np.float32(6e-8)) for b in base]).astype(np.float32)
+    xv = rng.choice(np.array([1.0, -1.0, 3.3, -0.77, 100.0, -2.0 ** -10], np.float32), r.size)
+    ys.append((r * xv).astype(np.float32)); xs.append(xv)
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e38, -1e38, 1e-38, 3e-39], np.float32)
+    gy, gx = np.meshgrid(sp, sp)
+    ys.append(gy.reshape(-1)); xs.append(gx.reshape(-1))
+    y = np.concatenate(ys); x = np.concatenate(xs)
+    dev = pkg.selftest_atan2(y, x)
+    host = O.libm_atan2f(y, x)
+    nan = np.isnan(host) & np.isnan(dev)
+    neq = (dev.view(np.uint32) != host.view(np.uint32)) & ~nan
+    assert not neq.any(), f"{int(neq.sum())} mismatches, first: y={y[neq][0]!r} x={x[neq][0]!r} dev={dev[neq][0]!r} host={host[neq][0]!r}"
+
+
+def test_gpu_runs_are_deterministic(pkg):
+    caps = _caps(3, 6 * 65536, seed=17, u8=True)
+    a = run_gpu(pkg, caps, 65536, 1_024_000)
+    b = run_gpu(pkg, caps, 65536, 1_024_000)
+    for k in ("audio", "fm_out_iq", "pll_dt", "rds"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    assert np.array_equal(a["rds_count"], b["rds_count"])
