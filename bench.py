@@ -25,6 +25,8 @@ from pathlib import Path
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP initialises: one hardware queue per pipeline stream
+
 ROOT = Path(__file__).resolve().parent
 for p in (ROOT, ROOT / "tests", ROOT / "oracle"):
     if str(p) not in sys.path:
@@ -125,6 +127,7 @@ def main() -> None:
     ap.add_argument("--u8", action="store_true", help="u8 IQ ingest (2 B/sample) instead of cf32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step audio all-gather at N>1")
+    ap.add_argument("--no-pipeline", action="store_true", help="run the stages of a block back to back on one stream")
     args = ap.parse_args()
 
     import torch
@@ -153,8 +156,7 @@ def main() -> None:
     n_blocks_resident = min(K + W, 8)  # distinct consecutive blocks kept in HBM, cycled
     x = synth_block_device(torch, C, n_blocks_resident * block, float(fs), 1234 + rank, device, args.u8)
     x = x.view(C, n_blocks_resident, block, 2).permute(1, 0, 2, 3).contiguous()  # [blocks][C][N][2]
-    dm = pkg.BatchDemod(C, block, fs, device=local_rank)
-    stream = torch.cuda.current_stream(device)
+    dm = pkg.BatchDemod(C, block, fs, device=local_rank, pipelined=not args.no_pipeline)
 
     do_gather = world > 1 and not args.no_gather
     if do_gather:
@@ -162,23 +164,28 @@ def main() -> None:
         stage = [torch.empty((C, n_audio, 2), dtype=torch.float32, device=device) for _ in range(2)]
         gathered = [torch.empty((world * C, n_audio, 2), dtype=torch.float32, device=device) for _ in range(2)]
         handles = [None, None]
-        audio_view = dm.audio_tensor()
+        gstream = torch.cuda.Stream(device)   # consumes outputs; the submitting stream never waits on them
 
     def step(k: int):
         dm.process(x[k % n_blocks_resident])
         if do_gather:
             s = k & 1
-            if handles[s] is not None:
-                handles[s].wait()
-            stage[s].copy_(audio_view, non_blocking=True)
-            handles[s] = dist.all_gather_into_tensor(gathered[s], stage[s], async_op=True)
+            with torch.cuda.stream(gstream):
+                if handles[s] is not None:
+                    handles[s].wait()
+                dm.wait_outputs(gstream)
+                stage[s].copy_(dm.audio_tensor(), non_blocking=True)
+                handles[s] = dist.all_gather_into_tensor(gathered[s], stage[s], async_op=True)
 
     def drain():
         if do_gather:
-            for i in range(2):
-                if handles[i] is not None:
-                    handles[i].wait()
-                    handles[i] = None
+            with torch.cuda.stream(gstream):
+                for i in range(2):
+                    if handles[i] is not None:
+                        handles[i].wait()
+                        handles[i] = None
+            gstream.synchronize()
+        dm.synchronize()
 
     for k in range(W):
         step(k)

@@ -9,6 +9,6 @@ The directory name contains a hyphen, so import it through `fmradio_loader.load(
 `importlib` with the module name `fm_radio_amd`.
 """
 from .capi import (  # noqa: F401
-    FMD_AUDIO_LMR, FMD_AUDIO_LPR, FMD_AUDIO_STEREO, FMD_FLAG_KEEP_TAPS, BatchDemod, Coeffs, Config, Controls, FmdError,
+    FMD_AUDIO_LMR, FMD_AUDIO_LPR, FMD_AUDIO_STEREO, FMD_FLAG_KEEP_TAPS, FMD_FLAG_NO_PIPELINE, BatchDemod, Coeffs, Config, Controls, FmdError,
     Rates, build_library, declared_symbols, default_controls, lib_path, load_library, selftest_atan2,
 )

@@ -8,6 +8,7 @@ points) or numpy arrays (host entry points).
 from __future__ import annotations
 
 import ctypes as C
+import os
 import re
 import subprocess
 from pathlib import Path
@@ -21,6 +22,7 @@ HEADER = ROOT / "include" / "fmdemod.h"
 
 FMD_AUDIO_LPR, FMD_AUDIO_LMR, FMD_AUDIO_STEREO = 0, 1, 2
 FMD_FLAG_KEEP_TAPS = 1
+FMD_FLAG_NO_PIPELINE = 2
 FMD_OK, FMD_ERR_ARG, FMD_ERR_SIZE, FMD_ERR_DEVICE, FMD_ERR_NO_DEVICE, FMD_ERR_NAME = 0, -1, -2, -3, -4, -5
 
 
@@ -87,6 +89,8 @@ def load_library():
     p = lib_path()
     if not p.exists():
         raise FileNotFoundError(f"{p} missing: run __graft_entry__.build() / make -C {CSRC}")
+    # the pipeline uses 5 streams beside the caller's: give them their own hardware queues (default is 4 per process)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     try:
         # torch bundles its own HIP runtime; load it FIRST so this process ends up with a single libamdhip64
         # (two runtimes in one process do not see each other's devices, streams or allocations)
@@ -112,6 +116,7 @@ def load_library():
     for name in ("fmd_process_cf32_host", "fmd_process_u8_host"):
         getattr(L, name).argtypes = [H, C.c_void_p, C.c_int, C.c_int]
     L.fmd_synchronize.argtypes = [H]
+    L.fmd_wait_outputs.argtypes = [H, C.c_void_p]
     L.fmd_audio_dev.argtypes = [H, C.POINTER(C.c_void_p)]
     L.fmd_rds_dev.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.fmd_get_audio.argtypes = [H, C.c_void_p]
@@ -146,10 +151,12 @@ def default_controls() -> Controls:
 class BatchDemod:
     """C broadcast-FM demodulators advanced in lock-step on one MI355X."""
 
-    def __init__(self, n_channels: int, block_size: int = 65536, fs_baseband: int = 1_024_000, device: int = -1, keep_taps: bool = False):
+    def __init__(self, n_channels: int, block_size: int = 65536, fs_baseband: int = 1_024_000, device: int = -1, keep_taps: bool = False,
+                 pipelined: bool = True):
         self.L = load_library()
         self.h = C.c_void_p()
-        cfg = Config(n_channels, block_size, fs_baseband, device, FMD_FLAG_KEEP_TAPS if keep_taps else 0)
+        flags = (FMD_FLAG_KEEP_TAPS if keep_taps else 0) | (0 if pipelined else FMD_FLAG_NO_PIPELINE)
+        cfg = Config(n_channels, block_size, fs_baseband, device, flags)
         rc = self.L.fmd_create(C.byref(cfg), C.byref(self.h))
         if rc != FMD_OK:
             msg = self.L.fmd_last_error(None).decode()
@@ -215,6 +222,15 @@ class BatchDemod:
     def synchronize(self):
         self._check(self.L.fmd_synchronize(self.h))
 
+    def wait_outputs(self, stream=None):
+        """Make `stream` (torch stream or raw handle; default: torch current stream) wait for the newest block's outputs."""
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        elif hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+        self._check(self.L.fmd_wait_outputs(self.h, C.c_void_p(stream)))
+
     # -- outputs --
     def audio(self) -> np.ndarray:
         out = np.empty((self.n_channels, self.rates.n_audio, 2), np.float32)
@@ -254,7 +270,8 @@ class BatchDemod:
         return {arr[i].name.decode(): (arr[i].total_ms, arr[i].launches) for i in range(n.value)}
 
     def audio_tensor(self):
-        """Zero-copy torch view of the device audio buffer [C, n_audio, 2] (valid until the next process())."""
+        """Zero-copy torch view of the newest block's device audio buffer [C, n_audio, 2] (the library alternates
+        between two buffers: call again after each process(); contents are complete after wait_outputs/synchronize)."""
         import torch
         p = C.c_void_p()
         self._check(self.L.fmd_audio_dev(self.h, C.byref(p)))

@@ -18,6 +18,14 @@
 
 using namespace fmd;
 
+// Stage placement: k_front on sF, k_pilot_power on sA, k_pilot_pll on sB, k_extract + k_rds_sync on sX.
+// Blocks alternate between two buffer slots, so in steady state the serial PLL stage of block b runs while the
+// front end of block b+1 and the extract/RDS stages of block b-1 use the rest of the chip.
+enum Stage { ST_FRONT = 0, ST_DEEMPH, ST_POWER, ST_PLL, ST_EXTRACT, ST_RDS, ST_COUNT };
+static const char* const kStageName[ST_COUNT] = {"k_front", "k_deemphasis+k_hilbert", "k_pilot_power", "k_pilot_pll", "k_extract", "k_rds_sync"};
+
+struct ProfiledBlock { hipEvent_t t0[ST_COUNT], t1[ST_COUNT]; bool used[ST_COUNT]; };
+
 struct fmd_handle_s {
     fmd_config cfg{};
     LaunchCtx ctx{};
@@ -30,14 +38,20 @@ struct fmd_handle_s {
     std::vector<void*> allocs;
     void* d_in = nullptr;                    // staging for the host-pointer entry points
     size_t d_in_bytes = 0;
-    hipStream_t own_stream = nullptr;
+    hipStream_t own_stream = nullptr;        // host-pointer entry points, uploads, resets
     hipStream_t last_stream = nullptr;
+    hipStream_t sF = nullptr, sA = nullptr, sB = nullptr, sX = nullptr;
+    hipEvent_t ev_in = nullptr, ev_F[2] = {}, ev_A[2] = {}, ev_B[2] = {}, ev_X[2] = {};
+    bool slot_used[2] = {false, false};
+    bool pipelined = true;
+    long n_blocks = 0;                       // blocks submitted since create/reset; slot = n_blocks & 1
+    int out_slot = 0;                        // slot holding the newest block's outputs
     int device = 0;
     int bytes_cap = 0;
     std::string err;
     std::map<int, std::vector<float>> lpf_cache;  // cut-off Hz -> 128 taps
     bool profiling = false;
-    std::vector<ProfileMarks*> marks;        // one per profiled block, drained by fmd_profile_read
+    std::vector<ProfiledBlock*> marks;       // one per profiled block, drained by fmd_profile_read
 };
 
 namespace {
@@ -147,10 +161,21 @@ int zero_history(fmd_handle h, hipStream_t s) {
         HIP_TRY(h, hipMemsetAsync(b.dt_tail[p], 0, sizeof(float) * (size_t)d.C * 128, s));
         HIP_TRY(h, hipMemsetAsync(b.fo_tail[p], 0, sizeof(float) * (size_t)d.C * 64, s));
     }
-    HIP_TRY(h, hipMemsetAsync(b.rds_count, 0, sizeof(int) * (size_t)d.C, s));
-    HIP_TRY(h, hipMemsetAsync(b.rds_bytes_count, 0, sizeof(int) * (size_t)d.C, s));
+    for (int p = 0; p < 2; p++) {
+        HIP_TRY(h, hipMemsetAsync(b.rds_count[p], 0, sizeof(int) * (size_t)d.C, s));
+        HIP_TRY(h, hipMemsetAsync(b.rds_bytes_count[p], 0, sizeof(int) * (size_t)d.C, s));
+    }
     HIP_TRY(h, launch_reset_state(h->ctx, s));
-    h->ctx.parity = 0;
+    h->n_blocks = 0;
+    h->out_slot = 0;
+    h->slot_used[0] = h->slot_used[1] = false;
+    return FMD_OK;
+}
+
+int sync_all(fmd_handle h) {
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (hipStream_t st : {h->sF, h->sA, h->sB, h->sX, h->own_stream}) if (st) HIP_TRY(h, hipStreamSynchronize(st));
+    if (!h->pipelined && h->n_blocks > 0) HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     return FMD_OK;
 }
 
@@ -162,18 +187,62 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         return fail(h, FMD_ERR_SIZE, "block dropped: got %d x %d, handle is %d x %d", n_channels, n_samples, h->cfg.n_channels, h->cfg.block_size);
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->controls_dirty) { int rc = upload_controls(h, s); if (rc) return rc; }
-    ProfileMarks* pm = nullptr;
+    if (h->controls_dirty) {
+        int rc = sync_all(h);          // control tables are read by in-flight stages: drain before rewriting them
+        if (!rc) rc = upload_controls(h, h->own_stream);
+        if (rc) return rc;
+    }
+    const int slot = (int)(h->n_blocks & 1);
+    const bool u8 = sizeof(InT) == 2;
+    const bool pipe = h->pipelined;
+    hipStream_t sF = pipe ? h->sF : s, sA = pipe ? h->sA : s, sB = pipe ? h->sB : s, sX = pipe ? h->sX : s;
+    ProfiledBlock* pm = nullptr;
     if (h->profiling) {
-        pm = new ProfileMarks();
-        for (auto& ev : pm->ev) HIP_TRY(h, hipEventCreate(&ev));
+        pm = new ProfiledBlock();
+        for (int i = 0; i < ST_COUNT; i++) { pm->used[i] = false; HIP_TRY(h, hipEventCreate(&pm->t0[i])); HIP_TRY(h, hipEventCreate(&pm->t1[i])); }
         h->marks.push_back(pm);
     }
-    hipError_t e;
-    if constexpr (sizeof(InT) == 8) e = launch_block_cf32(h->ctx, reinterpret_cast<const float2*>(d_iq), s, pm);
-    else e = launch_block_u8(h->ctx, reinterpret_cast<const uchar2*>(d_iq), s, pm);
-    if (e != hipSuccess) return fail(h, FMD_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
-    h->ctx.parity ^= 1;
+    auto run = [&](Stage st, hipStream_t on, hipError_t (*fn)(const LaunchCtx&, int, hipStream_t)) -> hipError_t {
+        if (pm) { (void)hipEventRecord(pm->t0[st], on); pm->used[st] = true; }
+        hipError_t e = fn(h->ctx, slot, on);
+        if (pm) (void)hipEventRecord(pm->t1[st], on);
+        return e;
+    };
+    hipError_t e = hipSuccess;
+    if (pipe) {
+        // input is ready once everything queued so far on the caller's stream has run
+        HIP_TRY(h, hipEventRecord(h->ev_in, s));
+        HIP_TRY(h, hipStreamWaitEvent(sF, h->ev_in, 0));
+        // WAR: this slot's fm_out_iq / pll_dt were last read by the extract stage two blocks ago
+        if (h->slot_used[slot]) HIP_TRY(h, hipStreamWaitEvent(sF, h->ev_X[slot], 0));
+    }
+    if (pm) { (void)hipEventRecord(pm->t0[ST_FRONT], sF); pm->used[ST_FRONT] = true; }
+    e = launch_stage_front(h->ctx, slot, d_iq, u8, sF);
+    if (pm) (void)hipEventRecord(pm->t1[ST_FRONT], sF);
+    if (e != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_front launch: %s", hipGetErrorString(e));
+    if (h->ctx.any_deemph && (e = run(ST_DEEMPH, sF, launch_stage_deemph)) != hipSuccess)
+        return fail(h, FMD_ERR_DEVICE, "de-emphasis launch: %s", hipGetErrorString(e));
+    if (pipe) {
+        HIP_TRY(h, hipEventRecord(h->ev_F[slot], sF));
+        HIP_TRY(h, hipStreamWaitEvent(s, h->ev_F[slot], 0));    // the caller may reuse `iq` in stream order after this call
+        HIP_TRY(h, hipStreamWaitEvent(sA, h->ev_F[slot], 0));
+    }
+    if ((e = run(ST_POWER, sA, launch_stage_power)) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_pilot_power launch: %s", hipGetErrorString(e));
+    if (pipe) {
+        HIP_TRY(h, hipEventRecord(h->ev_A[slot], sA));
+        HIP_TRY(h, hipStreamWaitEvent(sB, h->ev_A[slot], 0));
+    }
+    if ((e = run(ST_PLL, sB, launch_stage_pll)) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_pilot_pll launch: %s", hipGetErrorString(e));
+    if (pipe) {
+        HIP_TRY(h, hipEventRecord(h->ev_B[slot], sB));
+        HIP_TRY(h, hipStreamWaitEvent(sX, h->ev_B[slot], 0));
+    }
+    if ((e = run(ST_EXTRACT, sX, launch_stage_extract)) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_extract launch: %s", hipGetErrorString(e));
+    if ((e = run(ST_RDS, sX, launch_stage_rds)) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_rds_sync launch: %s", hipGetErrorString(e));
+    if (pipe) HIP_TRY(h, hipEventRecord(h->ev_X[slot], sX));
+    h->slot_used[slot] = true;
+    h->out_slot = slot;
+    h->n_blocks++;
     if (h->deemph_linger) { h->deemph_linger = false; h->ctx.any_deemph = 0; }
     h->last_stream = s;
     return FMD_OK;
@@ -196,13 +265,12 @@ int process_host(fmd_handle h, const InT* iq, int n_channels, int n_samples) {
     HIP_TRY(h, hipMemcpyAsync(h->d_in, iq, bytes, hipMemcpyHostToDevice, h->own_stream));
     int rc = process_dev<InT>(h, static_cast<const InT*>(h->d_in), n_channels, n_samples, h->own_stream);
     if (rc) return rc;
-    HIP_TRY(h, hipStreamSynchronize(h->own_stream));
-    return FMD_OK;
+    return sync_all(h);
 }
 
 void free_marks(fmd_handle h) {
-    for (ProfileMarks* pm : h->marks) {
-        for (auto& ev : pm->ev) (void)hipEventDestroy(ev);
+    for (ProfiledBlock* pm : h->marks) {
+        for (int i = 0; i < ST_COUNT; i++) { (void)hipEventDestroy(pm->t0[i]); (void)hipEventDestroy(pm->t1[i]); }
         delete pm;
     }
     h->marks.clear();
@@ -272,12 +340,25 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     { hipError_t e = prepare_kernels(); if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "prepare_kernels: %s", hipGetErrorString(e))); }
     { hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking); if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e))); }
 
+    h->pipelined = (cfg->flags & FMD_FLAG_NO_PIPELINE) == 0;
+    for (hipStream_t* st : {&h->sF, &h->sA, &h->sB, &h->sX}) {
+        hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+        if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e)));
+    }
+    {
+        hipEvent_t* evs[] = {&h->ev_in, &h->ev_F[0], &h->ev_F[1], &h->ev_A[0], &h->ev_A[1], &h->ev_B[0], &h->ev_B[1], &h->ev_X[0], &h->ev_X[1]};
+        for (hipEvent_t* ev : evs) {
+            hipError_t e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+            if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "event: %s", hipGetErrorString(e)));
+        }
+    }
     Dims& d = h->ctx.d;
     d.C = cfg->n_channels; d.N = cfg->block_size; d.m = m;
     d.n_fm_in = d.N / m; d.n_fm_out = d.n_fm_in / 2; d.n_rds = d.n_fm_out / 8; d.n_audio = d.n_fm_out / 4;
     d.n_est = (d.n_audio + 9) / 10;
     d.tail_base = front_tail_len(m);
     h->bytes_cap = 16 * (d.n_rds / 256 + 1);
+    h->ctx.bytes_cap = h->bytes_cap;
     h->ctx.keep_taps = (cfg->flags & FMD_FLAG_KEEP_TAPS) ? 1 : 0;
 
     fmd_controls def;
@@ -295,19 +376,21 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
         if (!rc) rc = dev_alloc(h, &b.dt_tail[p], C * 128);
         if (!rc) rc = dev_alloc(h, &b.fo_tail[p], C * 64);
     }
-    if (!rc) rc = dev_alloc(h, &b.fm_out_iq, C * d.n_fm_out);
-    if (!rc) rc = dev_alloc(h, &b.fm_out, C * d.n_fm_out);
-    if (!rc) rc = dev_alloc(h, &b.pll_dt, C * d.n_fm_out);
+    for (int p = 0; p < 2 && !rc; p++) {
+        rc = dev_alloc(h, &b.fm_out_iq[p], C * d.n_fm_out);
+        if (!rc) rc = dev_alloc(h, &b.fm_out[p], C * d.n_fm_out);
+        if (!rc) rc = dev_alloc(h, &b.pll_dt[p], C * d.n_fm_out);
+        if (!rc) rc = dev_alloc(h, &b.audio[p], C * d.n_audio * 2);
+        if (!rc) rc = dev_alloc(h, &b.rds_sym[p], C * d.n_rds);
+        if (!rc) rc = dev_alloc(h, &b.rds_raw_sym[p], h->ctx.keep_taps ? C * d.n_rds : 4);
+        if (!rc) rc = dev_alloc(h, &b.rds_count[p], C);
+        if (!rc) rc = dev_alloc(h, &b.lpr[p], h->ctx.keep_taps ? C * d.n_audio : 4);
+        if (!rc) rc = dev_alloc(h, &b.lmr[p], h->ctx.keep_taps ? C * d.n_audio : 4);
+        if (!rc) rc = dev_alloc(h, &b.rds_bytes[p], C * h->bytes_cap);
+        if (!rc) rc = dev_alloc(h, &b.rds_bytes_count[p], C);
+    }
     if (!rc) rc = dev_alloc(h, &b.rds, C * d.n_rds);
     if (!rc) rc = dev_alloc(h, &b.lmr_est, C * d.n_est);
-    if (!rc) rc = dev_alloc(h, &b.audio, C * d.n_audio * 2);
-    if (!rc) rc = dev_alloc(h, &b.rds_sym, C * d.n_rds);
-    if (!rc) rc = dev_alloc(h, &b.rds_raw_sym, h->ctx.keep_taps ? C * d.n_rds : 4);
-    if (!rc) rc = dev_alloc(h, &b.rds_count, C);
-    if (!rc) rc = dev_alloc(h, &b.lpr, h->ctx.keep_taps ? C * d.n_audio : 4);
-    if (!rc) rc = dev_alloc(h, &b.lmr, h->ctx.keep_taps ? C * d.n_audio : 4);
-    if (!rc) rc = dev_alloc(h, &b.rds_bytes, C * h->bytes_cap);
-    if (!rc) rc = dev_alloc(h, &b.rds_bytes_count, C);
     if (!rc) rc = dev_alloc(h, &b.b_lpr, C * 128);
     if (!rc) rc = dev_alloc(h, &b.b_lmr, C * 128);
     if (!rc) rc = dev_alloc(h, &b.deemph, C * 4);
@@ -325,8 +408,13 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
 int fmd_destroy(fmd_handle h) {
     if (!h) return FMD_ERR_ARG;
     (void)hipSetDevice(h->device);
-    if (h->last_stream) (void)hipStreamSynchronize(h->last_stream);
+    (void)sync_all(h);
     free_marks(h);
+    for (hipStream_t st : {h->sF, h->sA, h->sB, h->sX}) if (st) (void)hipStreamDestroy(st);
+    {
+        hipEvent_t evs[] = {h->ev_in, h->ev_F[0], h->ev_F[1], h->ev_A[0], h->ev_A[1], h->ev_B[0], h->ev_B[1], h->ev_X[0], h->ev_X[1]};
+        for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
+    }
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->d_in) (void)hipFree(h->d_in);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -337,7 +425,7 @@ int fmd_destroy(fmd_handle h) {
 int fmd_reset(fmd_handle h) {
     if (!h) return FMD_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->last_stream) HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    { int rc0 = sync_all(h); if (rc0) return rc0; }
     int rc = zero_history(h, h->own_stream);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->own_stream));
@@ -395,21 +483,27 @@ int fmd_process_u8_host(fmd_handle h, const uint8_t* iq, int n_channels, int n_s
 
 int fmd_synchronize(fmd_handle h) {
     if (!h) return FMD_ERR_ARG;
+    return sync_all(h);
+}
+
+int fmd_wait_outputs(fmd_handle h, void* stream) {
+    if (!h) return FMD_ERR_ARG;
+    if (!h->pipelined || h->n_blocks == 0) return FMD_OK;   // unpipelined: the outputs are already ordered on the caller's stream
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    HIP_TRY(h, hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->ev_X[h->out_slot], 0));
     return FMD_OK;
 }
 
 int fmd_audio_dev(fmd_handle h, const float** d_audio) {
     if (!h || !d_audio) return FMD_ERR_ARG;
-    *d_audio = h->ctx.b.audio;
+    *d_audio = h->ctx.b.audio[h->out_slot];
     return FMD_OK;
 }
 
 int fmd_rds_dev(fmd_handle h, const float** d_syms, const int** d_counts) {
     if (!h || !d_syms || !d_counts) return FMD_ERR_ARG;
-    *d_syms = h->ctx.b.rds_sym;
-    *d_counts = h->ctx.b.rds_count;
+    *d_syms = h->ctx.b.rds_sym[h->out_slot];
+    *d_counts = h->ctx.b.rds_count[h->out_slot];
     return FMD_OK;
 }
 
@@ -418,7 +512,7 @@ int fmd_get_audio(fmd_handle h, float* audio) {
     int rc = fmd_synchronize(h);
     if (rc) return rc;
     const Dims& d = h->ctx.d;
-    HIP_TRY(h, hipMemcpy(audio, h->ctx.b.audio, sizeof(float) * 2 * (size_t)d.C * d.n_audio, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(audio, h->ctx.b.audio[h->out_slot], sizeof(float) * 2 * (size_t)d.C * d.n_audio, hipMemcpyDeviceToHost));
     return FMD_OK;
 }
 
@@ -427,8 +521,8 @@ int fmd_get_rds_symbols(fmd_handle h, float* syms, int* counts) {
     int rc = fmd_synchronize(h);
     if (rc) return rc;
     const Dims& d = h->ctx.d;
-    HIP_TRY(h, hipMemcpy(syms, h->ctx.b.rds_sym, sizeof(float) * (size_t)d.C * d.n_rds, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(counts, h->ctx.b.rds_count, sizeof(int) * (size_t)d.C, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(syms, h->ctx.b.rds_sym[h->out_slot], sizeof(float) * (size_t)d.C * d.n_rds, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(counts, h->ctx.b.rds_count[h->out_slot], sizeof(int) * (size_t)d.C, hipMemcpyDeviceToHost));
     return FMD_OK;
 }
 
@@ -438,8 +532,8 @@ int fmd_get_rds_bytes(fmd_handle h, uint8_t* bytes, int cap_bytes_per_channel, i
     if (rc) return rc;
     const Dims& d = h->ctx.d;
     std::vector<uint8_t> tmp((size_t)d.C * h->bytes_cap);
-    HIP_TRY(h, hipMemcpy(tmp.data(), h->ctx.b.rds_bytes, tmp.size(), hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(counts, h->ctx.b.rds_bytes_count, sizeof(int) * (size_t)d.C, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(tmp.data(), h->ctx.b.rds_bytes[h->out_slot], tmp.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(counts, h->ctx.b.rds_bytes_count[h->out_slot], sizeof(int) * (size_t)d.C, hipMemcpyDeviceToHost));
     for (int c = 0; c < d.C; c++) {
         counts[c] = std::min(counts[c], std::min(cap_bytes_per_channel, h->bytes_cap));
         std::memcpy(bytes + (size_t)c * cap_bytes_per_channel, tmp.data() + (size_t)c * h->bytes_cap, (size_t)counts[c]);
@@ -453,20 +547,21 @@ int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats
     const Buffers& b = h->ctx.b;
     const size_t C = (size_t)d.C;
     const bool keep = h->ctx.keep_taps != 0;
+    const int o = h->out_slot;
     const void* p = nullptr;
     size_t n = 0;
     bool from_state = false;
     int field = 0;
     const std::string s(name);
-    if (s == "fm_out_iq") { p = b.fm_out_iq; n = 2 * C * d.n_fm_out; }
-    else if (s == "pll_dt") { p = b.pll_dt; n = C * d.n_fm_out; }
-    else if (s == "audio") { p = b.audio; n = 2 * C * d.n_audio; }
-    else if (s == "rds_sym") { p = b.rds_sym; n = C * d.n_rds; }
+    if (s == "fm_out_iq") { p = b.fm_out_iq[o]; n = 2 * C * d.n_fm_out; }
+    else if (s == "pll_dt") { p = b.pll_dt[o]; n = C * d.n_fm_out; }
+    else if (s == "audio") { p = b.audio[o]; n = 2 * C * d.n_audio; }
+    else if (s == "rds_sym") { p = b.rds_sym[o]; n = C * d.n_rds; }
     else if (s == "lmr_est") { p = b.lmr_est; n = C * d.n_est; }
     else if (s == "rds" ) { p = b.rds; n = 2 * C * d.n_rds; }
-    else if (s == "lpr" && keep) { p = b.lpr; n = C * d.n_audio; }
-    else if (s == "lmr" && keep) { p = b.lmr; n = C * d.n_audio; }
-    else if (s == "rds_raw_sym" && keep) { p = b.rds_raw_sym; n = 2 * C * d.n_rds; }
+    else if (s == "lpr" && keep) { p = b.lpr[o]; n = C * d.n_audio; }
+    else if (s == "lmr" && keep) { p = b.lmr[o]; n = C * d.n_audio; }
+    else if (s == "rds_raw_sym" && keep) { p = b.rds_raw_sym[o]; n = 2 * C * d.n_rds; }
     else if (s == "lmr_phase") { from_state = true; field = S_LMR_PHASE_CUR; }
     else if (s == "agc_pilot_gain") { from_state = true; field = S_AGC_PILOT_GAIN; }
     else if (s == "agc_rds_gain") { from_state = true; field = S_AGC_RDS_GAIN; }
@@ -508,17 +603,18 @@ int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out) {
     int rc = fmd_synchronize(h);
     if (rc) return rc;
     int n = 0;
-    for (ProfileMarks* pm : h->marks) {
-        for (int i = 0; i < pm->n; i++) {
+    for (ProfiledBlock* pm : h->marks) {
+        for (int i = 0; i < ST_COUNT; i++) {
+            if (!pm->used[i]) continue;
             float ms = 0.0f;
-            HIP_TRY(h, hipEventElapsedTime(&ms, pm->ev[i], pm->ev[i + 1]));
+            HIP_TRY(h, hipEventElapsedTime(&ms, pm->t0[i], pm->t1[i]));
             int slot = -1;
-            for (int j = 0; j < n; j++) if (std::strncmp(out[j].name, pm->name[i], sizeof(out[j].name)) == 0) { slot = j; break; }
+            for (int j = 0; j < n; j++) if (std::strncmp(out[j].name, kStageName[i], sizeof(out[j].name)) == 0) { slot = j; break; }
             if (slot < 0) {
                 if (n >= cap) continue;
                 slot = n++;
                 std::memset(&out[slot], 0, sizeof(out[slot]));
-                std::strncpy(out[slot].name, pm->name[i], sizeof(out[slot].name) - 1);
+                std::strncpy(out[slot].name, kStageName[i], sizeof(out[slot].name) - 1);
             }
             out[slot].total_ms += ms;
             out[slot].launches += 1;

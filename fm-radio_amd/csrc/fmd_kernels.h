@@ -32,7 +32,7 @@ enum StateField : int {
     // pilot peak IIR (two copies: one advanced by the power pass, one by the PLL pass)
     SA_X1R, SA_X1I, SA_X2R, SA_X2I, SA_Y1R, SA_Y1I, SA_Y2R, SA_Y2I,
     SB_X1R, SB_X1I, SB_X2R, SB_X2I, SB_Y1R, SB_Y1I, SB_Y2R, SB_Y2I,
-    S_PILOT_POWER,                 // sum |pilot|^2 of the current block (power pass -> PLL pass)
+    S_PILOT_POWER0, S_PILOT_POWER1, // sum |pilot|^2 of the block in pipeline slot 0 / 1 (power pass -> PLL pass)
     S_AGC_PILOT_GAIN,
     S_PLL_X1, S_PLL_Y1, S_PLL_INT, S_PLL_ERR, S_PLL_T,
     S_LMR_PHASE_CUR, S_LMR_PHASE_PREV,
@@ -56,26 +56,29 @@ struct Dims {
     int tail_base;  // baseband (m>1) or fm_in (m==1) samples of history kept per channel
 };
 
+// Buffers indexed [2] are ping-pong by pipeline slot (= block index & 1): the stages of consecutive blocks run
+// concurrently on different streams, so a producer of block b+1 must not overwrite what a consumer of block b reads.
 struct Buffers {
-    // history tails, ping-pong by block parity
+    // history tails: stage of block b reads [slot], writes [slot^1]
     float2* base_tail[2];   // [C][tail_base]
     float2* iq_tail[2];     // [C][128]   last fm_out_iq samples of the previous block
     float*  dt_tail[2];     // [C][128]   last pll_dt samples of the previous block
     float*  fo_tail[2];     // [C][64]    last fm_out samples (Hilbert FIR history, de-emphasis path)
-    // streams of the current block
-    float2* fm_out_iq;      // [C][n_fm_out]
-    float*  fm_out;         // [C][n_fm_out]  (de-emphasis path only)
-    float*  pll_dt;         // [C][n_fm_out]
-    float2* rds;            // [C][n_rds]
+    // intermediate streams
+    float2* fm_out_iq[2];   // [C][n_fm_out]
+    float*  fm_out[2];      // [C][n_fm_out]  (de-emphasis path only)
+    float*  pll_dt[2];      // [C][n_fm_out]
+    float2* rds;            // [C][n_rds]      (extract -> rds_sync, same stream)
     float*  lmr_est;        // [C][n_est]
-    float*  audio;          // [C][n_audio][2]
-    float*  rds_sym;        // [C][n_rds]
-    float2* rds_raw_sym;    // [C][n_rds]      (KEEP_TAPS)
-    int*    rds_count;      // [C]
-    float*  lpr;            // [C][n_audio]    (KEEP_TAPS)
-    float*  lmr;            // [C][n_audio]    (KEEP_TAPS)
-    uint8_t* rds_bytes;     // [C][32]
-    int*    rds_bytes_count;// [C]
+    // outputs
+    float*  audio[2];       // [C][n_audio][2]
+    float*  rds_sym[2];     // [C][n_rds]
+    float2* rds_raw_sym[2]; // [C][n_rds]      (KEEP_TAPS)
+    int*    rds_count[2];   // [C]
+    float*  lpr[2];         // [C][n_audio]    (KEEP_TAPS)
+    float*  lmr[2];         // [C][n_audio]    (KEEP_TAPS)
+    uint8_t* rds_bytes[2];  // [C][bytes_cap]
+    int*    rds_bytes_count[2]; // [C]
     // per-channel controls
     float*  b_lpr;          // [C][128]
     float*  b_lmr;          // [C][128]
@@ -90,22 +93,19 @@ struct LaunchCtx {
     FrontTaps front;
     RdsTaps rds_taps;
     LoopCoeffs loops;
-    int parity;        // block parity selecting the tails to read (write goes to parity^1)
     int keep_taps;
     int any_deemph;
+    int bytes_cap;
 };
 
-// optional per-kernel event recording (fmd_profile_*): launch_block records events[0..n_marks) around the kernels
-struct ProfileMarks {
-    static constexpr int kMax = 8;
-    hipEvent_t ev[kMax + 1];
-    const char* name[kMax];
-    int n = 0;
-};
-
-// queue one block of the hot path on `stream`
-hipError_t launch_block_cf32(const LaunchCtx& ctx, const float2* d_iq, hipStream_t stream, ProfileMarks* marks = nullptr);
-hipError_t launch_block_u8(const LaunchCtx& ctx, const uchar2* d_iq, hipStream_t stream, ProfileMarks* marks = nullptr);
+// One launcher per pipeline stage of one block; `slot` = block index & 1.  The host (fmd_api.cpp) places the stages on
+// streams and orders them with events.
+hipError_t launch_stage_front(const LaunchCtx& ctx, int slot, const void* d_iq, bool u8, hipStream_t s);   // k_front
+hipError_t launch_stage_deemph(const LaunchCtx& ctx, int slot, hipStream_t s);                            // k_deemphasis + k_hilbert
+hipError_t launch_stage_power(const LaunchCtx& ctx, int slot, hipStream_t s);                             // k_pilot_power
+hipError_t launch_stage_pll(const LaunchCtx& ctx, int slot, hipStream_t s);                               // k_pilot_pll
+hipError_t launch_stage_extract(const LaunchCtx& ctx, int slot, hipStream_t s);                           // k_extract
+hipError_t launch_stage_rds(const LaunchCtx& ctx, int slot, hipStream_t s);                               // k_rds_sync
 hipError_t launch_reset_state(const LaunchCtx& ctx, hipStream_t stream);
 hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, size_t n, hipStream_t s);
 hipError_t prepare_kernels();          // one-time function attributes (dynamic LDS sizes)

@@ -43,13 +43,27 @@ struct FrontGeom {
     static constexpr int Q = (M == 1) ? 0 : (NB / M);                    // entries per phase
     static constexpr int PSR = (M == 1) ? 0 : (16 / M);                  // wanted residue of the phase stride mod 16
     static constexpr int PS = (M == 1) ? 0 : (((Q - PSR + 15) / 16) * 16 + PSR);
-    static constexpr int LDS_FLOATS = 2 * M * PS * (M > 1) + NW + (NW + 1) + (T + 64);
+    // LDS carve-up in floats; every sub-array starts on a 16-byte boundary (a ds_read_b64 that is only 4-byte
+    // aligned is replayed at ~64 cycles per wave instruction)
+    static constexpr int NWP = (NW + 3) & ~3;
+    static constexpr int OFF_THETA = 2 * M * PS * (M > 1);
+    static constexpr int OFF_DEM = OFF_THETA + NWP;
+    static constexpr int OFF_FO = OFF_DEM + NWP;
+    static constexpr int LDS_FLOATS = OFF_FO + (T + 64);
+    static_assert(OFF_THETA % 4 == 0 && OFF_DEM % 4 == 0 && OFF_FO % 4 == 0, "LDS sub-arrays must be 16-byte aligned");
 };
 
 __device__ __forceinline__ float2 load_iq(const float2* p, size_t i) { return p[i]; }
 __device__ __forceinline__ float2 load_iq(const uchar2* p, size_t i) {
     const uchar2 v = p[i];
     return make_float2((float)v.x - 127.0f, (float)v.y - 127.0f);  // reference src/app.cpp:56-62
+}
+
+// two consecutive samples with one load
+__device__ __forceinline__ float4 load_iq2(const float2* p, size_t i) { return *reinterpret_cast<const float4*>(p + i); }
+__device__ __forceinline__ float4 load_iq2(const uchar2* p, size_t i) {
+    const uchar4 v = *reinterpret_cast<const uchar4*>(p + i);
+    return make_float4((float)v.x - 127.0f, (float)v.y - 127.0f, (float)v.z - 127.0f, (float)v.w - 127.0f);
 }
 
 template <int M, typename InT>
@@ -61,9 +75,9 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
     constexpr int T = G::T, NW = G::NW, NB = G::NB, PS = G::PS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float2* ph = reinterpret_cast<float2*>(smem);                 // [M][PS]
-    float* theta = smem + 2 * M * PS * (M > 1);                   // [NW]
-    float* dem = theta + NW;                                      // [NW-1] (+pad)
-    float* fo = dem + NW + 1;                                     // [T+64]
+    float* theta = smem + G::OFF_THETA;                           // [NW]
+    float* dem = smem + G::OFF_DEM;                               // [NW-1]
+    float* fo = smem + G::OFF_FO;                                 // [T+64]
     (void)ph;
 
     const int tiles = d.n_fm_out / T;
@@ -75,16 +89,36 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
     const InT* in_c = in + (size_t)c * d.N;
     const float2* tail_c = tail_in + (size_t)c * G::TAIL;
 
-    auto fetch = [&](int idx) -> float2 {
-        const long g = g_lo + idx;
-        return (g < 0) ? tail_c[G::TAIL + g] : load_iq(in_c, (size_t)g);
-    };
-
+    // Input staging: every thread first issues ALL of its global loads (independent, 16 B per lane for cf32), then
+    // consumes them — the memory-level parallelism is what keeps this kernel off the HBM-latency floor.
     if constexpr (M > 1) {
-        // stage the baseband tile, de-interleaved into M phases
-        for (int idx = tid; idx < NB; idx += 256) {
-            const float2 v = fetch(idx);
-            ph[(idx % M) * PS + (idx / M)] = v;
+        constexpr int ITEMS = NB / 2;                       // items of 2 consecutive samples (g_lo and TAIL are even)
+        constexpr int PER = (ITEMS + 255) / 256;
+        float4 buf[PER];
+        if (tile != 0) {
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+                const int j = tid + 256 * r;
+                if (j < ITEMS) buf[r] = load_iq2(in_c, (size_t)(g_lo + 2 * j));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+                const int j = tid + 256 * r;
+                if (j < ITEMS) {
+                    const long g = g_lo + 2 * j;
+                    buf[r] = (g < 0) ? *reinterpret_cast<const float4*>(tail_c + (G::TAIL + g)) : load_iq2(in_c, (size_t)g);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int j = tid + 256 * r;
+            if (j < ITEMS) {
+                const int i0 = 2 * j, i1 = 2 * j + 1;
+                ph[(i0 % M) * PS + (i0 / M)] = make_float2(buf[r].x, buf[r].y);
+                ph[(i1 % M) * PS + (i1 / M)] = make_float2(buf[r].z, buf[r].w);
+            }
         }
         __syncthreads();
         // a1 + a2: fm_in[w] then theta[w] = atan2(Q, I)
@@ -105,9 +139,20 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
             theta[i] = fmd_atan2f(im, re);
         }
     } else {
-        for (int i = tid; i < NW; i += 256) {
-            const float2 v = fetch(i);
-            theta[i] = fmd_atan2f(v.y, v.x);
+        constexpr int PER = (NW + 255) / 256;
+        float2 buf[PER];
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int i = tid + 256 * r;
+            if (i < NW) {
+                const long g = g_lo + i;
+                buf[r] = (g < 0) ? tail_c[G::TAIL + g] : load_iq(in_c, (size_t)g);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int i = tid + 256 * r;
+            if (i < NW) theta[i] = fmd_atan2f(buf[r].y, buf[r].x);
         }
     }
     __syncthreads();
@@ -224,8 +269,10 @@ struct PilotIIR {
 };
 
 // a6 + power sum of a7 — reference LockOntoPilot :421-423 (IIR) and AGC_Filter::calculate_average_power (agc.h:21-30)
-__global__ __launch_bounds__(kWave) void k_pilot_power(Dims d, const float2* __restrict__ fm_out_iq, float* __restrict__ state, LoopCoeffs k) {
+__global__ __launch_bounds__(kWave) void k_pilot_power(Dims d, const float2* __restrict__ fm_out_iq, float* __restrict__ state, LoopCoeffs k,
+                                                       int power_field) {
     __shared__ __attribute__((aligned(16))) float2 xin[2][kWave * kRowC];
+    __builtin_amdgcn_s_setprio(3);  // latency-bound recurrence: win issue arbitration against co-resident FIR waves
     const int lane = threadIdx.x, c0 = blockIdx.x * kWave, c = c0 + lane;
     const bool live = c < d.C;
     const int cs = live ? c : d.C - 1;
@@ -244,14 +291,15 @@ __global__ __launch_bounds__(kWave) void k_pilot_power(Dims d, const float2* __r
             power = power + fmaf(y.x, y.x, y.y * y.y);
         }
     }
-    if (live) { f.store(state, SA_X1R, d.C, c); st(state, S_PILOT_POWER, d.C, c) = power; }
+    if (live) { f.store(state, SA_X1R, d.C, c); st(state, power_field, d.C, c) = power; }
 }
 
 // a6 (recomputed) + a7 gain + a8 — reference LockOntoPilot :418-456, PLL_Mixer::Update (pll_mixer.cpp:12-21)
 __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __restrict__ fm_out_iq, float* __restrict__ pll_dt,
-                                                     float* __restrict__ state, LoopCoeffs k) {
+                                                     float* __restrict__ state, LoopCoeffs k, int power_field) {
     __shared__ __attribute__((aligned(16))) float2 xin[2][kWave * kRowC];
     __shared__ __attribute__((aligned(16))) float dt_out[kWave * kRowF];
+    __builtin_amdgcn_s_setprio(3);  // latency-bound recurrence: win issue arbitration against co-resident FIR waves
     const int lane = threadIdx.x, c0 = blockIdx.x * kWave, c = c0 + lane;
     const bool live = c < d.C;
     const int cs = live ? c : d.C - 1;
@@ -260,7 +308,7 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
     // AGC_Filter::process (agc.h:12-19) as compiled: target_gain = sqrt((target/sum) * N)
     float gain = st(state, S_AGC_PILOT_GAIN, d.C, cs);
     {
-        const float sum = st(state, S_PILOT_POWER, d.C, cs);
+        const float sum = st(state, power_field, d.C, cs);
         const float target_gain = sqrtf((1.0f / sum) * (float)n);
         gain = fmaf(target_gain - gain, 0.2f, gain);
     }
@@ -452,6 +500,7 @@ __global__ __launch_bounds__(kWave) void k_rds_sync(Dims d, float2* __restrict__
                                                     uint8_t* __restrict__ rds_bytes, int* __restrict__ rds_bytes_count,
                                                     int bytes_cap, int keep_taps) {
     __shared__ __attribute__((aligned(16))) float2 xin[2][kWave * kRowC];
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x, c0 = blockIdx.x * kWave, c = c0 + lane;
     const bool live = c < d.C;
     const int cs = live ? c : d.C - 1;
@@ -689,70 +738,70 @@ __global__ void k_reset(Dims d, float* __restrict__ state) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// host-side launch sequence
+// host-side stage launchers
 // ---------------------------------------------------------------------------------------------
 template <int M, typename InT>
-static hipError_t launch_front(const LaunchCtx& ctx, const InT* d_iq, hipStream_t s) {
+static hipError_t launch_front(const LaunchCtx& ctx, int slot, const InT* d_iq, hipStream_t s) {
     using G = FrontGeom<M>;
     const Dims& d = ctx.d;
     const int tiles = d.n_fm_out / G::T;
     const size_t lds = sizeof(float) * G::LDS_FLOATS;
     auto kern = k_front<M, InT>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * d.C)), dim3(256), lds, s, d, d_iq, ctx.b.base_tail[ctx.parity],
-                       ctx.b.base_tail[ctx.parity ^ 1], ctx.b.fm_out_iq, ctx.b.fm_out, ctx.b.fo_tail[ctx.parity ^ 1], ctx.front,
-                       ctx.any_deemph);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * d.C)), dim3(256), lds, s, d, d_iq, ctx.b.base_tail[slot], ctx.b.base_tail[slot ^ 1],
+                       ctx.b.fm_out_iq[slot], ctx.b.fm_out[slot], ctx.b.fo_tail[slot ^ 1], ctx.front, ctx.any_deemph);
     return hipGetLastError();
 }
 
-template <typename InT>
-static hipError_t launch_block(const LaunchCtx& ctx, const InT* d_iq, hipStream_t s, ProfileMarks* marks) {
+hipError_t launch_stage_front(const LaunchCtx& ctx, int slot, const void* d_iq, bool u8, hipStream_t s) {
+    const int m = ctx.d.m;
+    if (u8) {
+        const uchar2* p = static_cast<const uchar2*>(d_iq);
+        return m == 1 ? launch_front<1, uchar2>(ctx, slot, p, s) : (m == 4 ? launch_front<4, uchar2>(ctx, slot, p, s) : launch_front<8, uchar2>(ctx, slot, p, s));
+    }
+    const float2* p = static_cast<const float2*>(d_iq);
+    return m == 1 ? launch_front<1, float2>(ctx, slot, p, s) : (m == 4 ? launch_front<4, float2>(ctx, slot, p, s) : launch_front<8, float2>(ctx, slot, p, s));
+}
+
+static unsigned serial_waves(const Dims& d) { return (unsigned)((d.C + kWave - 1) / kWave); }
+
+hipError_t launch_stage_deemph(const LaunchCtx& ctx, int slot, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
-    hipError_t e = hipSuccess;
-    auto mark = [&](const char* name) {
-        if (!marks) return;
-        if (marks->n == 0) (void)hipEventRecord(marks->ev[0], s);
-        (void)name;
-    };
-    auto done = [&](const char* name) {
-        if (!marks || marks->n >= ProfileMarks::kMax) return;
-        marks->name[marks->n] = name;
-        marks->n++;
-        (void)hipEventRecord(marks->ev[marks->n], s);
-    };
-    if (marks) marks->n = 0;
-    mark("begin");
-    if (d.m == 1) e = launch_front<1, InT>(ctx, d_iq, s);
-    else if (d.m == 4) e = launch_front<4, InT>(ctx, d_iq, s);
-    else e = launch_front<8, InT>(ctx, d_iq, s);
-    if (e != hipSuccess) return e;
-    done("k_front");
-    const unsigned waves = (unsigned)((d.C + kWave - 1) / kWave);
-    if (ctx.any_deemph) {
-        hipLaunchKernelGGL(k_deemphasis, dim3(waves), dim3(kWave), 0, s, d, b.fm_out, b.deemph, b.state);
-        hipLaunchKernelGGL(k_hilbert, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, b.fm_out, b.fo_tail[ctx.parity],
-                           b.fo_tail[ctx.parity ^ 1], b.fm_out_iq, ctx.front);
-        done("k_deemphasis+k_hilbert");
-    }
-    hipLaunchKernelGGL(k_pilot_power, dim3(waves), dim3(kWave), 0, s, d, b.fm_out_iq, b.state, ctx.loops);
-    done("k_pilot_power");
-    hipLaunchKernelGGL(k_pilot_pll, dim3(waves), dim3(kWave), 0, s, d, b.fm_out_iq, b.pll_dt, b.state, ctx.loops);
-    done("k_pilot_pll");
-    hipLaunchKernelGGL(k_extract, dim3((unsigned)(d.n_audio / kTA * d.C)), dim3(256), 0, s, d, b.fm_out_iq, b.pll_dt,
-                       b.iq_tail[ctx.parity], b.dt_tail[ctx.parity], b.iq_tail[ctx.parity ^ 1], b.dt_tail[ctx.parity ^ 1],
-                       b.b_lpr, b.b_lmr, ctx.rds_taps, b.mix, b.state, b.audio, b.rds, b.lmr_est, b.lpr, b.lmr, ctx.keep_taps);
-    done("k_extract");
-    hipLaunchKernelGGL(k_rds_sync, dim3(waves), dim3(kWave), 0, s, d, b.rds, b.lmr_est, b.state, ctx.loops, b.rds_sym,
-                       b.rds_raw_sym, b.rds_count, b.rds_bytes, b.rds_bytes_count, 16 * (d.n_rds / 256 + 1), ctx.keep_taps);
-    done("k_rds_sync");
+    hipLaunchKernelGGL(k_deemphasis, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.fm_out[slot], b.deemph, b.state);
+    hipLaunchKernelGGL(k_hilbert, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, b.fm_out[slot], b.fo_tail[slot],
+                       b.fo_tail[slot ^ 1], b.fm_out_iq[slot], ctx.front);
     return hipGetLastError();
 }
 
-hipError_t launch_block_cf32(const LaunchCtx& ctx, const float2* d_iq, hipStream_t stream, ProfileMarks* marks) {
-    return launch_block<float2>(ctx, d_iq, stream, marks);
+hipError_t launch_stage_power(const LaunchCtx& ctx, int slot, hipStream_t s) {
+    const Dims& d = ctx.d;
+    hipLaunchKernelGGL(k_pilot_power, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[slot], ctx.b.state, ctx.loops,
+                       slot ? (int)S_PILOT_POWER1 : (int)S_PILOT_POWER0);
+    return hipGetLastError();
 }
-hipError_t launch_block_u8(const LaunchCtx& ctx, const uchar2* d_iq, hipStream_t stream, ProfileMarks* marks) {
-    return launch_block<uchar2>(ctx, d_iq, stream, marks);
+
+hipError_t launch_stage_pll(const LaunchCtx& ctx, int slot, hipStream_t s) {
+    const Dims& d = ctx.d;
+    hipLaunchKernelGGL(k_pilot_pll, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[slot], ctx.b.pll_dt[slot], ctx.b.state,
+                       ctx.loops, slot ? (int)S_PILOT_POWER1 : (int)S_PILOT_POWER0);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_extract(const LaunchCtx& ctx, int slot, hipStream_t s) {
+    const Dims& d = ctx.d;
+    const Buffers& b = ctx.b;
+    hipLaunchKernelGGL(k_extract, dim3((unsigned)(d.n_audio / kTA * d.C)), dim3(256), 0, s, d, b.fm_out_iq[slot], b.pll_dt[slot],
+                       b.iq_tail[slot], b.dt_tail[slot], b.iq_tail[slot ^ 1], b.dt_tail[slot ^ 1], b.b_lpr, b.b_lmr, ctx.rds_taps, b.mix,
+                       b.state, b.audio[slot], b.rds, b.lmr_est, b.lpr[slot], b.lmr[slot], ctx.keep_taps);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_rds(const LaunchCtx& ctx, int slot, hipStream_t s) {
+    const Dims& d = ctx.d;
+    const Buffers& b = ctx.b;
+    hipLaunchKernelGGL(k_rds_sync, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.rds, b.lmr_est, b.state, ctx.loops, b.rds_sym[slot],
+                       b.rds_raw_sym[slot], b.rds_count[slot], b.rds_bytes[slot], b.rds_bytes_count[slot], ctx.bytes_cap, ctx.keep_taps);
+    return hipGetLastError();
 }
 
 template <int M, typename InT>

@@ -51,7 +51,8 @@ typedef struct {
     unsigned flags;    /* FMD_FLAG_* */
 } fmd_config;
 
-#define FMD_FLAG_KEEP_TAPS 1u  /* keep the intermediate streams readable through fmd_get_stream */
+#define FMD_FLAG_KEEP_TAPS   1u  /* keep the intermediate streams readable through fmd_get_stream */
+#define FMD_FLAG_NO_PIPELINE 2u  /* run every stage on the caller's stream, one after the other (debugging / profiling) */
 
 /* reference Broadcast_FM_Demod_Controls (broadcast_fm_demod.h:64-89); defaults in fmd_default_controls */
 typedef struct {
@@ -106,13 +107,19 @@ int fmd_get_rates(fmd_handle h, fmd_rates* r);
 int fmd_get_coeffs(fmd_handle h, int channel, fmd_coeffs* k);
 
 /* Broadcast_FM_Demod::Process (broadcast_fm_demod.cpp:309-328) for all channels.
- * *_dev: `iq` is a DEVICE pointer, work is queued on `stream` (hipStream_t, NULL = default stream) and
- * the call returns without synchronising.  *_host: `iq` is a host pointer; copies, runs, synchronises. */
+ * *_dev: `d_iq` is a DEVICE pointer.  The call returns without synchronising.  The block is read after everything
+ * already queued on `stream` (hipStream_t, NULL = default stream), and work queued on `stream` AFTER the call is
+ * ordered behind the library's last read of `d_iq`, so the buffer may be refilled in stream order.  The stages of
+ * the block run on the library's own streams and overlap with the neighbouring blocks' stages (two blocks in
+ * flight); outputs become readable after fmd_synchronize / fmd_wait_outputs and stay valid until the second
+ * next fmd_process_* call.  *_host: `iq` is a host pointer; copies, runs, synchronises. */
 int fmd_process_cf32_dev(fmd_handle h, const float* d_iq, int n_channels, int n_samples, void* stream);
 int fmd_process_u8_dev(fmd_handle h, const uint8_t* d_iq, int n_channels, int n_samples, void* stream);
 int fmd_process_cf32_host(fmd_handle h, const float* iq, int n_channels, int n_samples);
 int fmd_process_u8_host(fmd_handle h, const uint8_t* iq, int n_channels, int n_samples);
 int fmd_synchronize(fmd_handle h);
+/* make `stream` wait (on the device, no host block) until the newest block's outputs are complete */
+int fmd_wait_outputs(fmd_handle h, void* stream);
 
 /* OnAudioOut() / GetAudioOut() (broadcast_fm_demod.h:256,297): device views of the current block */
 int fmd_audio_dev(fmd_handle h, const float** d_audio /* [C][n_audio][2] */);
