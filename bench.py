@@ -160,30 +160,20 @@ def main() -> None:
 
     do_gather = world > 1 and not args.no_gather
     if do_gather:
-        n_audio = dm.rates.n_audio
-        stage = [torch.empty((C, n_audio, 2), dtype=torch.float32, device=device) for _ in range(2)]
-        gathered = [torch.empty((world * C, n_audio, 2), dtype=torch.float32, device=device) for _ in range(2)]
-        handles = [None, None]
+        gather = pkg.AudioGather(dist, torch, C, dm.rates.n_audio, world, device)
         gstream = torch.cuda.Stream(device)   # consumes outputs; the submitting stream never waits on them
 
     def step(k: int):
         dm.process(x[k % n_blocks_resident])
         if do_gather:
-            s = k & 1
             with torch.cuda.stream(gstream):
-                if handles[s] is not None:
-                    handles[s].wait()
                 dm.wait_outputs(gstream)
-                stage[s].copy_(dm.audio_tensor(), non_blocking=True)
-                handles[s] = dist.all_gather_into_tensor(gathered[s], stage[s], async_op=True)
+                gather.issue(k, dm.audio_tensor())
 
     def drain():
         if do_gather:
             with torch.cuda.stream(gstream):
-                for i in range(2):
-                    if handles[i] is not None:
-                        handles[i].wait()
-                        handles[i] = None
+                gather.drain()
             gstream.synchronize()
         dm.synchronize()
 

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -341,6 +342,9 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     { hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking); if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e))); }
 
     h->pipelined = (cfg->flags & FMD_FLAG_NO_PIPELINE) == 0;
+    // (A CU-mask split between the serial and the FIR streams was measured: it shields the PLL wave from FIR waves
+    //  sharing its SIMD — 3.06 -> 2.75 ms — but CU-masked streams did not overlap with each other on this runtime, so
+    //  the step got slower overall.  Plain streams + s_setprio in the serial kernels it is.)
     for (hipStream_t* st : {&h->sF, &h->sA, &h->sB, &h->sX}) {
         hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
         if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e)));

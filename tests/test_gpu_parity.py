@@ -210,3 +210,26 @@ def test_gpu_runs_are_deterministic(pkg):
     for k in ("audio", "fm_out_iq", "pll_dt", "rds"):
         assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
     assert np.array_equal(a["rds_count"], b["rds_count"])
+
+
+def test_cpp_host_adaptor_matches_oracle(pkg, tmp_path):
+    """The C++ adaptor (fm-radio_amd/host/broadcast_fm_demod_gpu.hpp: reference method names over the C ABI, App-style u8
+    re-blocking) driven like the reference's own mains, against the oracle."""
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "adaptor_main"
+    subprocess.run(["g++", "-O2", "-std=c++17", f"-I{root / 'include'}", f"-I{root / 'fm-radio_amd' / 'host'}", str(root / "tests" / "cpp" / "adaptor_main.cpp"),
+                    f"-L{root / 'fm-radio_amd' / 'csrc'}", "-lfmdemod", f"-Wl,-rpath,{root / 'fm-radio_amd' / 'csrc'}", "-o", str(exe)], check=True)
+    bs, nb = 16384, 8
+    cap = synth.to_u8(synth.fm_capture(bs * nb + 777, seed=31)["iq"])   # trailing partial block is never processed
+    cap.tofile(tmp_path / "cap.u8")
+    subprocess.run([str(exe), str(tmp_path / "cap.u8"), str(tmp_path), str(bs)], check=True)
+    dm = pkg.BatchDemod(1, bs, 1_024_000)
+    k = lib_coeffs_to_oracle(dm.get_coeffs(0))
+    dm.close()
+    o = O.run_chain(cap[: bs * nb], bs, 1_024_000, u8=True, coeffs=k, streams=["audio", "rds_sym", "lpr"])
+    for name, key in (("audio.f32", "audio"), ("rds_sym.f32", "rds_sym"), ("lpr.f32", "lpr")):
+        got = np.fromfile(tmp_path / name, dtype=np.float32)
+        assert np.array_equal(got.view(np.uint32), o[key].view(np.uint32)), name
+    assert np.array_equal(np.fromfile(tmp_path / "rds_bytes.u8", dtype=np.uint8), o["rds_bytes"])
