@@ -546,7 +546,7 @@ int fmd_get_rds_bytes(fmd_handle h, uint8_t* bytes, int cap_bytes_per_channel, i
 }
 
 int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats, size_t* n_floats) {
-    if (!h || !name || !out) return FMD_ERR_ARG;
+    if (!h || !name) return FMD_ERR_ARG;
     const Dims& d = h->ctx.d;
     const Buffers& b = h->ctx.b;
     const size_t C = (size_t)d.C;
@@ -573,7 +573,7 @@ int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats
     else return fail(h, FMD_ERR_NAME, "unknown stream '%s'", name);
     if (from_state) { p = b.state + (size_t)field * C; n = C; }
     if (n_floats) *n_floats = n;
-    if (cap_floats < n) return fail(h, FMD_ERR_ARG, "stream '%s' needs %zu floats", name, n);
+    if (!out || cap_floats < n) return fail(h, FMD_ERR_ARG, "stream '%s' needs %zu floats", name, n);  // size query: out may be NULL
     int rc = fmd_synchronize(h);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpy(out, p, sizeof(float) * n, hipMemcpyDeviceToHost));
