@@ -383,6 +383,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     for (int p = 0; p < 2 && !rc; p++) {
         rc = dev_alloc(h, &b.fm_out_iq[p], C * d.n_fm_out);
         if (!rc) rc = dev_alloc(h, &b.fm_out[p], C * d.n_fm_out);
+        if (!rc) rc = dev_alloc(h, &b.pilot[p], C * d.n_fm_out);
         if (!rc) rc = dev_alloc(h, &b.pll_dt[p], C * d.n_fm_out);
         if (!rc) rc = dev_alloc(h, &b.audio[p], C * d.n_audio * 2);
         if (!rc) rc = dev_alloc(h, &b.rds_sym[p], C * d.n_rds);

@@ -29,9 +29,8 @@ struct LoopCoeffs {
 // Per-channel serial state, structure-of-arrays ([field][C]) so a wavefront's 64 lanes (64 adjacent
 // channels) load and store it coalesced.  Field list = SURVEY.md A.8 / reference member variables.
 enum StateField : int {
-    // pilot peak IIR (two copies: one advanced by the power pass, one by the PLL pass)
+    // pilot peak IIR
     SA_X1R, SA_X1I, SA_X2R, SA_X2I, SA_Y1R, SA_Y1I, SA_Y2R, SA_Y2I,
-    SB_X1R, SB_X1I, SB_X2R, SB_X2I, SB_Y1R, SB_Y1I, SB_Y2R, SB_Y2I,
     S_PILOT_POWER0, S_PILOT_POWER1, // sum |pilot|^2 of the block in pipeline slot 0 / 1 (power pass -> PLL pass)
     S_AGC_PILOT_GAIN,
     S_PLL_X1, S_PLL_Y1, S_PLL_INT, S_PLL_ERR, S_PLL_T,
@@ -67,6 +66,7 @@ struct Buffers {
     // intermediate streams
     float2* fm_out_iq[2];   // [C][n_fm_out]
     float*  fm_out[2];      // [C][n_fm_out]  (de-emphasis path only)
+    float2* pilot[2];       // [C][n_fm_out]  pilot peak IIR output before AGC (k_pilot_power -> k_pilot_pll)
     float*  pll_dt[2];      // [C][n_fm_out]
     float2* rds;            // [C][n_rds]      (extract -> rds_sync, same stream)
     float*  lmr_est;        // [C][n_est]

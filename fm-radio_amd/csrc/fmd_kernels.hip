@@ -5,8 +5,8 @@
 //
 //   k_front        [parallel]  a0 u8->f32, a1 decimating FIR, a2 arctan discriminator, a3 decimating FIR,
 //                              a5 Hilbert FIR  -> fm_out_iq            (LDS-staged, halo recomputed per tile)
-//   k_pilot_power  [serial]    a6 pilot peak IIR + a7 AGC power sum     (lane per channel, LDS transpose)
-//   k_pilot_pll    [serial]    a6 (recomputed) a7 gain, a8 PLL loop     -> pll_dt
+//   k_pilot_power  [serial]    a6 pilot peak IIR + a7 AGC power sum     -> pilot   (lane per channel, LDS transpose)
+//   k_pilot_pll    [serial]    a7 gain, a8 PLL loop                     -> pll_dt
 //   k_extract      [parallel]  a9 x2/x3 harmonic mixers fused into a10/a12 decimating FIRs, a11 phase
 //                              estimates, a15 audio mix                -> audio, rds, lmr_est
 //   k_rds_sync     [serial]    a11 phase integrate, a13 AGC, a14 BPSK synchroniser, Manchester decode
@@ -237,6 +237,15 @@ __device__ __forceinline__ void chunk_store_c(const ChunkRegsC& r, float2* lds) 
     FMD_FOR16(FMD_ST)
 #undef FMD_ST
 }
+// flush a transposed cf32 chunk [64][kRowC] to out[C][n] at t0
+__device__ __forceinline__ void chunk_flush_c(const float2* lds, float2* __restrict__ out, int n, int c0, int C, int t0) {
+    const int lane = threadIdx.x, row = lane >> 4, col = lane & 15;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int r = 4 * k + row, ch = c0 + r;
+        if (ch < C) *reinterpret_cast<float4*>(out + (size_t)ch * n + t0 + 2 * col) = *reinterpret_cast<const float4*>(lds + r * kRowC + 2 * col);
+    }
+}
 // flush a [64][kRowF] f32 chunk to out[C][n] at t0
 __device__ __forceinline__ void chunk_flush_f(const float* lds, float* __restrict__ out, int n, int c0, int C, int t0) {
     const int lane = threadIdx.x, row = lane >> 3, col = lane & 7;
@@ -268,9 +277,10 @@ struct PilotIIR {
     }
 };
 
-// a6 + power sum of a7 — reference LockOntoPilot :421-423 (IIR) and AGC_Filter::calculate_average_power (agc.h:21-30)
-__global__ __launch_bounds__(kWave) void k_pilot_power(Dims d, const float2* __restrict__ fm_out_iq, float* __restrict__ state, LoopCoeffs k,
-                                                       int power_field) {
+// a6 + power sum of a7 — reference LockOntoPilot :421-423 (IIR -> pilot_buf) and AGC_Filter::calculate_average_power
+// (agc.h:21-30).  Writes the un-gained pilot so the latency-critical PLL kernel does not have to recompute the IIR.
+__global__ __launch_bounds__(kWave) void k_pilot_power(Dims d, const float2* __restrict__ fm_out_iq, float2* __restrict__ pilot,
+                                                       float* __restrict__ state, LoopCoeffs k, int power_field) {
     __shared__ __attribute__((aligned(16))) float2 xin[2][kWave * kRowC];
     __builtin_amdgcn_s_setprio(3);  // latency-bound recurrence: win issue arbitration against co-resident FIR waves
     const int lane = threadIdx.x, c0 = blockIdx.x * kWave, c = c0 + lane;
@@ -289,13 +299,16 @@ __global__ __launch_bounds__(kWave) void k_pilot_power(Dims d, const float2* __r
         for (int t = 0; t < kChunk; t++) {
             const float2 y = f.step(buf[lane * kRowC + t], k);
             power = power + fmaf(y.x, y.x, y.y * y.y);
+            buf[lane * kRowC + t] = y;
         }
+        __syncthreads();
+        chunk_flush_c(buf, pilot, n, c0, d.C, ch * kChunk);
     }
     if (live) { f.store(state, SA_X1R, d.C, c); st(state, power_field, d.C, c) = power; }
 }
 
-// a6 (recomputed) + a7 gain + a8 — reference LockOntoPilot :418-456, PLL_Mixer::Update (pll_mixer.cpp:12-21)
-__global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __restrict__ fm_out_iq, float* __restrict__ pll_dt,
+// a7 gain + a8 — reference LockOntoPilot :423-456, PLL_Mixer::Update (pll_mixer.cpp:12-21)
+__global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
                                                      float* __restrict__ state, LoopCoeffs k, int power_field) {
     __shared__ __attribute__((aligned(16))) float2 xin[2][kWave * kRowC];
     __shared__ __attribute__((aligned(16))) float dt_out[kWave * kRowF];
@@ -304,7 +317,6 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
     const bool live = c < d.C;
     const int cs = live ? c : d.C - 1;
     const int n = d.n_fm_out, chunks = n / kChunk;
-    PilotIIR f; f.load(state, SB_X1R, d.C, cs);
     // AGC_Filter::process (agc.h:12-19) as compiled: target_gain = sqrt((target/sum) * N)
     float gain = st(state, S_AGC_PILOT_GAIN, d.C, cs);
     {
@@ -316,14 +328,14 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
     float integ = st(state, S_PLL_INT, d.C, cs), err = st(state, S_PLL_ERR, d.C, cs), tph = st(state, S_PLL_T, d.C, cs);
     const float Ts = 1.0f / 128000.0f;
     const float KTsI = 0.1f * Ts;
-    ChunkRegsC regs = chunk_load_c(fm_out_iq, n, c0, d.C, 0);
+    ChunkRegsC regs = chunk_load_c(pilot, n, c0, d.C, 0);
     for (int ch = 0; ch < chunks; ch++) {
         float2* buf = xin[ch & 1];
         chunk_store_c(regs, buf);
         __syncthreads();
-        regs = chunk_load_c(fm_out_iq, n, c0, d.C, (ch + 1 < chunks ? ch + 1 : ch) * kChunk);
+        regs = chunk_load_c(pilot, n, c0, d.C, (ch + 1 < chunks ? ch + 1 : ch) * kChunk);
         for (int t = 0; t < kChunk; t++) {
-            const float2 y = f.step(buf[lane * kRowC + t], k);
+            const float2 y = buf[lane * kRowC + t];
             const float p = gain * y.x, q = gain * y.y;
             // loop filter IIR_Filter<float> K=2: t_i = fma(xn[i], b[i], yn[i]*a[i]); y += t_i
             const float t0 = fmaf(lx1, k.pll_b0, ly1 * k.pll_a0);
@@ -351,7 +363,6 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
         chunk_flush_f(dt_out, pll_dt, n, c0, d.C, ch * kChunk);
     }
     if (live) {
-        f.store(state, SB_X1R, d.C, c);
         st(state, S_AGC_PILOT_GAIN, d.C, c) = gain;
         st(state, S_PLL_X1, d.C, c) = lx1; st(state, S_PLL_Y1, d.C, c) = ly1;
         st(state, S_PLL_INT, d.C, c) = integ; st(state, S_PLL_ERR, d.C, c) = err; st(state, S_PLL_T, d.C, c) = tph;
@@ -775,14 +786,14 @@ hipError_t launch_stage_deemph(const LaunchCtx& ctx, int slot, hipStream_t s) {
 
 hipError_t launch_stage_power(const LaunchCtx& ctx, int slot, hipStream_t s) {
     const Dims& d = ctx.d;
-    hipLaunchKernelGGL(k_pilot_power, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[slot], ctx.b.state, ctx.loops,
-                       slot ? (int)S_PILOT_POWER1 : (int)S_PILOT_POWER0);
+    hipLaunchKernelGGL(k_pilot_power, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[slot], ctx.b.pilot[slot], ctx.b.state,
+                       ctx.loops, slot ? (int)S_PILOT_POWER1 : (int)S_PILOT_POWER0);
     return hipGetLastError();
 }
 
 hipError_t launch_stage_pll(const LaunchCtx& ctx, int slot, hipStream_t s) {
     const Dims& d = ctx.d;
-    hipLaunchKernelGGL(k_pilot_pll, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[slot], ctx.b.pll_dt[slot], ctx.b.state,
+    hipLaunchKernelGGL(k_pilot_pll, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.pilot[slot], ctx.b.pll_dt[slot], ctx.b.state,
                        ctx.loops, slot ? (int)S_PILOT_POWER1 : (int)S_PILOT_POWER0);
     return hipGetLastError();
 }

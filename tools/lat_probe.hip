@@ -1,0 +1,42 @@
+// Dependent-chain latency of individual VALU ops for ONE resident wavefront (development tool).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#define CHAIN_KERNEL(NAME, INIT, STEP)                                                     \
+__global__ void NAME(float* out, long long* cyc, int iters, float a, float b) {          \
+    INIT;                                                                                 \
+    long long t0 = __builtin_readcyclecounter();                                          \
+    for (int i = 0; i < iters; i++) {                                                     \
+        _Pragma("unroll") for (int u = 0; u < 16; u++) { STEP; }                          \
+    }                                                                                     \
+    long long t1 = __builtin_readcyclecounter();                                          \
+    out[threadIdx.x] = FIN;                                                               \
+    if (threadIdx.x == 0) cyc[0] = t1 - t0;                                               \
+}
+#define FIN x
+CHAIN_KERNEL(k_add, float x = threadIdx.x * 0.001f + 1.0f, x = x + a)
+CHAIN_KERNEL(k_mul, float x = threadIdx.x * 0.001f + 1.0f, x = x * a)
+CHAIN_KERNEL(k_fma, float x = threadIdx.x * 0.001f + 1.0f, x = __builtin_fmaf(x, a, b))
+CHAIN_KERNEL(k_rcp, float x = threadIdx.x * 0.001f + 1.5f, x = __builtin_amdgcn_rcpf(x))
+CHAIN_KERNEL(k_trunc, float x = threadIdx.x * 0.001f + 1.5f, x = __builtin_truncf(x) + a)
+CHAIN_KERNEL(k_med3, float x = threadIdx.x * 0.001f + 1.5f, x = __builtin_amdgcn_fmed3f(x, a, b))
+CHAIN_KERNEL(k_bfi, float x = threadIdx.x * 0.001f + 1.5f, x = __builtin_copysignf(a, x))
+CHAIN_KERNEL(k_sqrt, float x = threadIdx.x * 0.001f + 1.5f, x = __builtin_amdgcn_sqrtf(x))
+CHAIN_KERNEL(k_cmpsel, float x = threadIdx.x * 0.001f + 1.5f, x = (x > a) ? b : x)
+#undef FIN
+#define FIN (x.x + x.y)
+#define PK_INIT v2f x; x.x = threadIdx.x * 0.001f + 1.0f; x.y = 2.0f; v2f va; va.x = a; va.y = a; v2f vb; vb.x = b; vb.y = b
+CHAIN_KERNEL(k_pkfma, PK_INIT, x = __builtin_elementwise_fma(x, va, vb))
+CHAIN_KERNEL(k_pkmul, PK_INIT, x = x * va)
+#undef FIN
+
+int main() {
+    float* out; long long* cyc; hipMalloc(&out, 4096); hipMalloc(&cyc, 8);
+    long long h; const int iters = 20000;
+#define RUN(K, aa, bb) { K<<<1, 64>>>(out, cyc, iters, aa, bb); hipDeviceSynchronize(); K<<<1, 64>>>(out, cyc, iters, aa, bb); hipDeviceSynchronize(); \
+    hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost); printf("%-10s %6.2f cycles/op\n", #K, (double)h / ((double)iters * 16)); }
+    RUN(k_add, 0.001f, 0.f) RUN(k_mul, 0.9999f, 0.f) RUN(k_fma, 0.999f, 0.001f) RUN(k_rcp, 0.f, 0.f) RUN(k_trunc, 0.37f, 0.f)
+    RUN(k_med3, -1.f, 1.f) RUN(k_bfi, 0.5f, 0.f) RUN(k_sqrt, 0.f, 0.f) RUN(k_cmpsel, 2.0f, 1.7f) RUN(k_pkfma, 0.999f, 0.001f) RUN(k_pkmul, 0.9999f, 0.f)
+    return 0;
+}
