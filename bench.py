@@ -128,6 +128,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step audio all-gather at N>1")
     ap.add_argument("--no-pipeline", action="store_true", help="run the stages of a block back to back on one stream")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--share-gpu", action="store_true", help="plumbing test: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -143,11 +145,16 @@ def main() -> None:
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     fs = args.fs
     block = args.block or (fs * 64 // 1000)
