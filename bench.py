@@ -116,6 +116,33 @@ def cpu_baseline(fs: int, block: int, budget_s: float = 12.0) -> dict:
             "sample": f"{sum(counts)} blocks of {block} cf32 samples @ {fs} Sa/s over {n_thr} threads in {el:.1f} s (oracle/fm_oracle.c, one demodulator per thread)"}
 
 
+def cpu_reference(budget_s: float = 10.0) -> dict | None:
+    """The REAL reference (oracle/_ref/fm_demod_benchmark = reference src/fm_demod_benchmark.cpp built by `make -C oracle ref`)
+    at its only rate, 1.024 MSa/s u8: one process per host core, each on its own pass over a page-cached synthetic capture.
+    Reported beside cpu_baseline for orientation; None where the prebuilt binary is absent."""
+    import subprocess
+    import tempfile
+    import synth
+    exe = ROOT / "oracle" / "_ref" / "fm_demod_benchmark"
+    if not exe.exists():
+        return None
+    n_proc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_proc = max(1, n_proc // 2)  # one per physical core (SMT siblings share the FMA units)
+    n = int(1.024e6 * 20) // 65536 * 65536
+    cap = synth.to_u8(synth.fm_capture(n, seed=1234)["iq"])
+    with tempfile.TemporaryDirectory() as td:
+        f = Path(td) / "cap.u8"
+        cap.tofile(f)
+        subprocess.run([str(exe), "-i", str(f)], stderr=subprocess.DEVNULL, check=True)
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([str(exe), "-i", str(f)], stderr=subprocess.DEVNULL) for _ in range(n_proc)]
+        for p in procs:
+            p.wait()
+        el = time.perf_counter() - t0
+    return {"value": n * n_proc / el / 1e6, "unit": "MSa/s", "cores": n_proc, "kind": "reference",
+            "sample": f"{n_proc} processes x {n} u8 samples @ 1.024 MSa/s (20.5 s of signal each) in {el:.1f} s, reference fm_demod_benchmark incl. RDS decode"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,6 +287,9 @@ def main() -> None:
         del x
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline(fs, block)
+        ref = cpu_reference()
+        if ref is not None:
+            out["cpu_reference_1024k"] = ref
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

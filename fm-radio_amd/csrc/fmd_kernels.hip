@@ -372,16 +372,21 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
 // =============================================================================================
 // k_extract — reference ExtractComponents (broadcast_fm_demod.cpp:463-536) + MixAudio (:549-585):
 //   apply_harmonic_pll_avx (apply_harmonic_pll.cpp:88-139) h=2 (+ L-R phase offset) and h=3, fused into
-//   PolyphaseDownsampler<cf32> 4x128 (L+R: real rail only, L-R) and 8x128 (RDS); per-sample phase
-//   estimates of every 10th L-R output (:496-510); stereo mix.
-// One workgroup = one channel x 128 audio samples (512 fm_out samples, 64 RDS samples).
+//   PolyphaseDownsampler<cf32> 4x128 (L+R: real rail only; L-R: imaginary rail, plus the real rail of every 10th
+//   output for the phase estimate :496-510) and 8x128 (RDS); stereo mix.
+// One workgroup = one channel x TA audio samples (4 TA fm_out samples, TA/2 RDS samples), TA threads.
+// The mixed signals are staged in LDS split into decimation phases; every FIR thread produces FOUR consecutive
+// outputs from one sliding register window (ds_read_b128), so an LDS byte feeds ~4 FMAs instead of 1.
 // =============================================================================================
-static constexpr int kTA = 128;                  // audio outputs per tile
-static constexpr int kXS = 4 * kTA + 124;        // fm_out samples staged (636)
-static constexpr int kQ4 = kXS / 4;              // 159 entries per phase (M=4)
-static constexpr int kP4 = 164;                  // phase stride, == 4 (mod 16)
-static constexpr int kQ8 = (kXS - 4) / 8;        // 79 entries per phase (M=8)
-static constexpr int kP8 = 82;                   // phase stride, == 2 (mod 16)
+template <int TA>
+struct ExtractGeom {
+    static constexpr int XS = 4 * TA + 124;      // fm_out samples staged
+    static constexpr int P4 = TA + 40;           // phase stride (floats) for the decimate-by-4 signals: == 8 (mod 32), multiple of 4
+    static constexpr int P8 = TA / 2 + 20;       // phase stride for the decimate-by-8 signal: == 20 (mod 32), multiple of 4
+    static constexpr int NQ = TA / 4;            // threads per FIR job (each makes 4 outputs)
+    static constexpr int NEST = TA / 10 + 2;     // upper bound of phase-estimate outputs per tile
+    static_assert(P4 % 4 == 0 && P8 % 4 == 0 && P4 >= TA + 31 && P8 >= TA / 2 + 15, "phase strides");
+};
 
 __device__ __forceinline__ float2 harmonic_mix(float2 x, float dt, float harmonic, float off, float off_cos) {
     float s = fmaf(dt, harmonic, off);
@@ -392,97 +397,171 @@ __device__ __forceinline__ float2 harmonic_mix(float2 x, float dt, float harmoni
     return make_float2(fmaf(pc, x.x, -(x.y * ps)), fmaf(pc, x.y, x.x * ps));
 }
 
-__global__ __launch_bounds__(256) void k_extract(Dims d, const float2* __restrict__ fm_out_iq, const float* __restrict__ pll_dt,
-                                                 const float2* __restrict__ iq_tail_in, const float* __restrict__ dt_tail_in,
-                                                 float2* __restrict__ iq_tail_out, float* __restrict__ dt_tail_out,
-                                                 const float* __restrict__ b_lpr, const float* __restrict__ b_lmr, RdsTaps rds_taps,
-                                                 const float* __restrict__ mixctl, float* __restrict__ state,
-                                                 float* __restrict__ audio, float2* __restrict__ rds, float* __restrict__ lmr_est,
-                                                 float* __restrict__ lpr_out, float* __restrict__ lmr_out, int keep_taps) {
-    __shared__ float lpr_ph[4 * kP4];            // real part of fm_out_iq, 4 phases
-    __shared__ float2 lmr_ph[4 * kP4];           // x2-mixed signal, 4 phases
-    __shared__ float2 rds_ph[8 * kP8];           // x3-mixed signal, 8 phases
-    __shared__ float tap_lpr[128], tap_lmr[128];
-    __shared__ float lpr_res[kTA];
+// Four consecutive outputs of a decimate-by-4, 128-tap FIR on one rail.  ph: 4 phase arrays of stride P, window of
+// output i starts at phase index i.  Accumulation order per output = c32_f32_cum_mul_avx: lane p sums taps 4jj+p in
+// increasing jj, then (l0+l2)+(l1+l3).
+template <typename TapFn>
+__device__ __forceinline__ void fir4_quad(const float* __restrict__ ph, int P, int u, TapFn tap, float out[4]) {
+    float acc[4][4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) { acc[v][0] = acc[v][1] = acc[v][2] = acc[v][3] = 0.0f; }
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        float w[36];
+        const float4* src = reinterpret_cast<const float4*>(ph + p * P + 4 * u);
+#pragma unroll
+        for (int k = 0; k < 9; k++) { const float4 t = src[k]; w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w; }
+#pragma unroll
+        for (int jj = 0; jj < 32; jj++) {
+            const float b = tap(4 * jj + p);
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc[v][p] = fmaf(w[v + jj], b, acc[v][p]);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) out[v] = (acc[v][0] + acc[v][2]) + (acc[v][1] + acc[v][3]);
+}
 
-    const int tiles = d.n_audio / kTA;
+// Four consecutive outputs of a decimate-by-8, 128-tap FIR on one rail: 8 phase arrays; lane (n & 3) sums taps n = 8jj+p
+// in increasing n, so phases p and p+4 feed the same accumulator alternately.
+template <typename TapFn>
+__device__ __forceinline__ void fir8_quad(const float* __restrict__ ph, int P, int u, TapFn tap, float out[4]) {
+    float acc[4][4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) { acc[v][0] = acc[v][1] = acc[v][2] = acc[v][3] = 0.0f; }
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        float wa[20], wb[20];
+        const float4* sa = reinterpret_cast<const float4*>(ph + p * P + 4 * u);
+        const float4* sb = reinterpret_cast<const float4*>(ph + (p + 4) * P + 4 * u);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const float4 t = sa[k]; wa[4 * k] = t.x; wa[4 * k + 1] = t.y; wa[4 * k + 2] = t.z; wa[4 * k + 3] = t.w;
+            const float4 r = sb[k]; wb[4 * k] = r.x; wb[4 * k + 1] = r.y; wb[4 * k + 2] = r.z; wb[4 * k + 3] = r.w;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) {
+            const float ba = tap(8 * jj + p), bb = tap(8 * jj + p + 4);
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                acc[v][p] = fmaf(wa[v + jj], ba, acc[v][p]);
+                acc[v][p] = fmaf(wb[v + jj], bb, acc[v][p]);
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) out[v] = (acc[v][0] + acc[v][2]) + (acc[v][1] + acc[v][3]);
+}
+
+template <int TA>
+__global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict__ fm_out_iq, const float* __restrict__ pll_dt,
+                                                const float2* __restrict__ iq_tail_in, const float* __restrict__ dt_tail_in,
+                                                float2* __restrict__ iq_tail_out, float* __restrict__ dt_tail_out,
+                                                const float* __restrict__ b_lpr, const float* __restrict__ b_lmr, RdsTaps rds_taps,
+                                                const float* __restrict__ mixctl, float* __restrict__ state,
+                                                float* __restrict__ audio, float2* __restrict__ rds, float* __restrict__ lmr_est,
+                                                float* __restrict__ lpr_out, float* __restrict__ lmr_out, int keep_taps) {
+    using G = ExtractGeom<TA>;
+    constexpr int XS = G::XS, P4 = G::P4, P8 = G::P8, NQ = G::NQ;
+    __shared__ __attribute__((aligned(16))) float lpr_ph[4 * P4];     // Re fm_out_iq, 4 phases
+    __shared__ __attribute__((aligned(16))) float lmr_re_ph[4 * P4];  // x2-mixed signal, real / imaginary rail
+    __shared__ __attribute__((aligned(16))) float lmr_im_ph[4 * P4];
+    __shared__ __attribute__((aligned(16))) float rds_re_ph[8 * P8];  // x3-mixed signal
+    __shared__ __attribute__((aligned(16))) float rds_im_ph[8 * P8];
+    __shared__ __attribute__((aligned(16))) float res_lpr[TA];
+    __shared__ __attribute__((aligned(16))) float res_lmr[TA];
+    __shared__ __attribute__((aligned(16))) float res_rds[TA];        // [TA/2][2]
+    __shared__ float res_est_re[G::NEST];
+
+    const int tiles = d.n_audio / TA;
     const int c = blockIdx.x / tiles, tile = blockIdx.x % tiles;
-    const int i0 = tile * kTA;
+    const int i0 = tile * TA;
     const int tid = threadIdx.x;
     const int s_lo = 4 * i0 - 124;               // first fm_out sample staged (block relative)
     const int n = d.n_fm_out;
     const float2* x_c = fm_out_iq + (size_t)c * n;
     const float* dt_c = pll_dt + (size_t)c * n;
-
-    if (tid < 128) { tap_lpr[tid] = b_lpr[(size_t)c * 128 + tid]; tap_lmr[tid] = b_lmr[(size_t)c * 128 + tid]; }
     const float off_cur = st(state, S_LMR_PHASE_CUR, d.C, c), off_prev = st(state, S_LMR_PHASE_PREV, d.C, c);
 
-    for (int e = tid; e < kXS; e += 256) {
-        const int s = s_lo + e;
-        float2 x; float dt; float off;
-        if (s < 0) { x = iq_tail_in[(size_t)c * 128 + 128 + s]; dt = dt_tail_in[(size_t)c * 128 + 128 + s]; off = off_prev; }
-        else { x = x_c[s]; dt = dt_c[s]; off = off_cur; }
-        lpr_ph[(e & 3) * kP4 + (e >> 2)] = x.x;
-        lmr_ph[(e & 3) * kP4 + (e >> 2)] = harmonic_mix(x, dt, 2.0f, off, off + 0.25f);
-        if (e >= 4) {
-            const int e8 = e - 4;
-            rds_ph[(e8 & 7) * kP8 + (e8 >> 3)] = harmonic_mix(x, dt, 3.0f, 0.0f, 0.25f);
+    // stage + mix: all loads first, then the arithmetic
+    {
+        constexpr int PER = (XS + TA - 1) / TA;
+        float2 xv[PER]; float dv[PER];
+        if (tile != 0) {
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+                const int e = tid + TA * r;
+                if (e < XS) { xv[r] = x_c[s_lo + e]; dv[r] = dt_c[s_lo + e]; }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+                const int e = tid + TA * r;
+                if (e < XS) {
+                    const int s = s_lo + e;
+                    xv[r] = (s < 0) ? iq_tail_in[(size_t)c * 128 + 128 + s] : x_c[s];
+                    dv[r] = (s < 0) ? dt_tail_in[(size_t)c * 128 + 128 + s] : dt_c[s];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int e = tid + TA * r;
+            if (e < XS) {
+                const float off = (s_lo + e < 0) ? off_prev : off_cur;   // history samples were mixed with last block's offset
+                const float2 m2 = harmonic_mix(xv[r], dv[r], 2.0f, off, off + 0.25f);
+                const int a4 = (e & 3) * P4 + (e >> 2);
+                lpr_ph[a4] = xv[r].x;
+                lmr_re_ph[a4] = m2.x;
+                lmr_im_ph[a4] = m2.y;
+                if (e >= 4) {
+                    const float2 m3 = harmonic_mix(xv[r], dv[r], 3.0f, 0.0f, 0.25f);
+                    const int e8 = e - 4, a8 = (e8 & 7) * P8 + (e8 >> 3);
+                    rds_re_ph[a8] = m3.x;
+                    rds_im_ph[a8] = m3.y;
+                }
+            }
         }
     }
     __syncthreads();
 
-    float lmr_re = 0.0f, lmr_im = 0.0f;
-    if (tid < 128) {
-        // L-R: complex dot over 128 taps, 4 lane accumulators per rail (c32_f32_cum_mul_avx order)
-        const int ii = tid;
-        float ar[4] = {0.f, 0.f, 0.f, 0.f}, ai[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int jj = 0; jj < 32; jj++) {
+    const int job = tid / NQ, u = tid % NQ;
+    const float* taps_lpr = b_lpr + (size_t)c * 128;
+    const float* taps_lmr = b_lmr + (size_t)c * 128;
+    const int est_first = (10 - (i0 % 10)) % 10;   // first output of this tile whose block index is a multiple of 10
+    if (job == 0) {
+        float o[4];
+        fir4_quad(lpr_ph, P4, u, [&](int k) { return taps_lpr[k]; }, o);
+        *reinterpret_cast<float4*>(res_lpr + 4 * u) = make_float4(o[0], o[1], o[2], o[3]);
+    } else if (job == 1) {
+        float o[4];
+        fir4_quad(lmr_im_ph, P4, u, [&](int k) { return taps_lmr[k]; }, o);
+        *reinterpret_cast<float4*>(res_lmr + 4 * u) = make_float4(o[0], o[1], o[2], o[3]);
+    } else if (job == 2) {
+        // RDS: first half of the job's threads take the real rail, second half the imaginary rail
+        const int rail = u / (NQ / 2), uu = u % (NQ / 2);
+        float o[4];
+        fir8_quad(rail ? rds_im_ph : rds_re_ph, P8, uu, [&](int k) { return rds_taps.b[k]; }, o);
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const float2 v = lmr_ph[p * kP4 + ii + jj];
-                const float b = tap_lmr[4 * jj + p];
-                ar[p] = fmaf(v.x, b, ar[p]);
-                ai[p] = fmaf(v.y, b, ai[p]);
-            }
-        }
-        lmr_re = (ar[0] + ar[2]) + (ar[1] + ar[3]);
-        lmr_im = (ai[0] + ai[2]) + (ai[1] + ai[3]);
+        for (int v = 0; v < 4; v++) res_rds[2 * (4 * uu + v) + rail] = o[v];
     } else {
-        // L+R: real rail of the complex dot; RDS: one rail per thread
-        const int t2 = tid - 128;
-        {
+        // real rail of the L-R outputs that feed the phase estimate (one output per thread)
+        const int ii = est_first + 10 * u;
+        if (ii < TA) {
             float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
             for (int jj = 0; jj < 32; jj++) {
 #pragma unroll
-                for (int p = 0; p < 4; p++) a[p] = fmaf(lpr_ph[p * kP4 + t2 + jj], tap_lpr[4 * jj + p], a[p]);
+                for (int p = 0; p < 4; p++) a[p] = fmaf(lmr_re_ph[p * P4 + ii + jj], taps_lmr[4 * jj + p], a[p]);
             }
-            lpr_res[t2] = (a[0] + a[2]) + (a[1] + a[3]);
-        }
-        {
-            const int rr = t2 & 63, rail = t2 >> 6;
-            float a[4] = {0.f, 0.f, 0.f, 0.f};
-            const float* ph = reinterpret_cast<const float*>(rds_ph) + rail;
-#pragma unroll 4
-            for (int jj = 0; jj < 16; jj++) {
-#pragma unroll
-                for (int p = 0; p < 8; p++) a[p & 3] = fmaf(ph[2 * (p * kP8 + rr + jj)], rds_taps.b[8 * jj + p], a[p & 3]);
-            }
-            const float v = (a[0] + a[2]) + (a[1] + a[3]);
-            reinterpret_cast<float*>(rds)[2 * ((size_t)c * d.n_rds + i0 / 2 + rr) + rail] = v;
+            res_est_re[u] = (a[0] + a[2]) + (a[1] + a[3]);
         }
     }
     __syncthreads();
-    if (tid < 128) {
-        const int ii = tid, i = i0 + ii;
-        if ((i % 10) == 0) {
-            // reference :500-510: estimate against the +-pi/2 constellation
-            const float ph = fmd_atan2f(lmr_im, lmr_re);
-            const float half_pi = bits_f32(kHalfPiBits);
-            lmr_est[(size_t)c * d.n_est + i / 10] = (ph > 0.0f) ? (half_pi - ph) : (-half_pi - ph);
-        }
-        const float lpr = lpr_res[ii], lmr = lmr_im;
+
+    {
+        const int i = i0 + tid;
+        const float lpr = res_lpr[tid], lmr = res_lmr[tid];
         const int mode = (int)mixctl[2 * c];
         const float kmix = mixctl[2 * c + 1];
         float l, r;
@@ -491,6 +570,14 @@ __global__ __launch_bounds__(256) void k_extract(Dims d, const float2* __restric
         else { l = lpr; r = lpr; }
         reinterpret_cast<float2*>(audio)[(size_t)c * d.n_audio + i] = make_float2(l + l, r + r);
         if (keep_taps) { lpr_out[(size_t)c * d.n_audio + i] = lpr; lmr_out[(size_t)c * d.n_audio + i] = lmr; }
+        if (tid < TA / 2) rds[(size_t)c * d.n_rds + i0 / 2 + tid] = make_float2(res_rds[2 * tid], res_rds[2 * tid + 1]);
+        // reference :500-510: estimate against the +-pi/2 constellation, every 10th output of the block
+        const int ii = est_first + 10 * tid;
+        if (ii < TA) {
+            const float ph = fmd_atan2f(res_lmr[ii], res_est_re[tid]);
+            const float half_pi = bits_f32(kHalfPiBits);
+            lmr_est[(size_t)c * d.n_est + (i0 + ii) / 10] = (ph > 0.0f) ? (half_pi - ph) : (-half_pi - ph);
+        }
     }
     // history for the next block: last 128 fm_out_iq / pll_dt samples
     if (tile == tiles - 1 && tid < 128) {
@@ -798,12 +885,18 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, int slot, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_stage_extract(const LaunchCtx& ctx, int slot, hipStream_t s) {
+template <int TA>
+static void launch_extract_ta(const LaunchCtx& ctx, int slot, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
-    hipLaunchKernelGGL(k_extract, dim3((unsigned)(d.n_audio / kTA * d.C)), dim3(256), 0, s, d, b.fm_out_iq[slot], b.pll_dt[slot],
+    hipLaunchKernelGGL(k_extract<TA>, dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fm_out_iq[slot], b.pll_dt[slot],
                        b.iq_tail[slot], b.dt_tail[slot], b.iq_tail[slot ^ 1], b.dt_tail[slot ^ 1], b.b_lpr, b.b_lmr, ctx.rds_taps, b.mix,
                        b.state, b.audio[slot], b.rds, b.lmr_est, b.lpr[slot], b.lmr[slot], ctx.keep_taps);
+}
+
+hipError_t launch_stage_extract(const LaunchCtx& ctx, int slot, hipStream_t s) {
+    if (ctx.d.n_audio % 256 == 0) launch_extract_ta<256>(ctx, slot, s);
+    else launch_extract_ta<128>(ctx, slot, s);
     return hipGetLastError();
 }
 
