@@ -217,6 +217,7 @@ def main() -> None:
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
+    dm.spec_stats(reset=True)
     dm.profile(True)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -234,6 +235,7 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         el = float(tmax.item())
     ktimes = dm.profile_read()
+    spec = dm.spec_stats()
 
     samples_per_step = C * block * world
     value = samples_per_step * K / el / 1e6
@@ -281,6 +283,9 @@ def main() -> None:
         "channels_at_realtime": value * 1e6 / fs,
         "msa_per_gpu": value / world,
         "roofline": roofline,
+        # serial loops: 32-sample chunks (x wavefronts) in the timed region, how many ran with the general forms
+        # (loop not in lock, or a speculated chunk replayed) instead of the locked-loop short forms — same results either way
+        "speculation": spec,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         dm.close()

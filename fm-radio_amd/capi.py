@@ -124,6 +124,8 @@ def load_library():
     L.fmd_get_rds_bytes.argtypes = [H, C.c_void_p, C.c_int, C.c_void_p]
     L.fmd_get_stream.argtypes = [H, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.fmd_selftest_atan2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.fmd_selftest_atan2_small.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.fmd_get_spec_stats.argtypes = [H, C.c_void_p, C.c_int]
     L.fmd_profile_enable.argtypes = [H, C.c_int]
     L.fmd_profile_read.argtypes = [H, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]
     L.fmd_last_error.restype = C.c_char_p
@@ -140,6 +142,17 @@ def selftest_atan2(y: np.ndarray, x: np.ndarray) -> np.ndarray:
     if rc != FMD_OK:
         raise FmdError(rc, load_library().fmd_last_error(None).decode())
     return out
+
+
+def selftest_atan2_small(y: np.ndarray, x: np.ndarray):
+    """The locked-loop short form of atan2f on the device: (values, ok) — values are exact wherever ok is True."""
+    y = np.ascontiguousarray(y, np.float32); x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(y); ok = np.empty(y.size, np.uint8)
+    rc = load_library().fmd_selftest_atan2_small(y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                                 ok.ctypes.data_as(C.c_void_p), y.size)
+    if rc != FMD_OK:
+        raise FmdError(rc, load_library().fmd_last_error(None).decode())
+    return out, ok.astype(bool).reshape(y.shape)
 
 
 def default_controls() -> Controls:
@@ -261,6 +274,13 @@ class BatchDemod:
 
     def profile(self, on: bool):
         self._check(self.L.fmd_profile_enable(self.h, 1 if on else 0))
+
+    def spec_stats(self, reset: bool = False) -> dict:
+        """Speculation counters of the serial loops (fmd_get_spec_stats), in 32-sample chunks summed over wavefronts."""
+        a = np.zeros(8, np.uint64)
+        self._check(self.L.fmd_get_spec_stats(self.h, a.ctypes.data_as(C.c_void_p), 1 if reset else 0))
+        return {"pll": {"chunks": int(a[0]), "general": int(a[1]), "replayed": int(a[2])},
+                "rds": {"chunks": int(a[4]), "general": int(a[5]), "replayed": int(a[6])}}
 
     def profile_read(self) -> dict:
         """{kernel name: (total ms, launches)} since the last read (HIP events on the processing stream)."""

@@ -401,6 +401,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     if (!rc) rc = dev_alloc(h, &b.deemph, C * 4);
     if (!rc) rc = dev_alloc(h, &b.mix, C * 2);
     if (!rc) rc = dev_alloc(h, &b.state, (size_t)S_NUM_FIELDS * C);
+    if (!rc) rc = dev_alloc(h, &b.spec_stats, 8);
     if (rc) return bail(rc);
     rc = zero_history(h, h->own_stream);
     if (!rc) rc = upload_controls(h, h->own_stream);
@@ -581,20 +582,40 @@ int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats
     return FMD_OK;
 }
 
-int fmd_selftest_atan2(const float* y, const float* x, float* out, size_t n) {
+static int selftest_atan2_host(const float* y, const float* x, float* out, uint8_t* ok, size_t n) {
     if (!y || !x || !out) return FMD_ERR_ARG;
     if (fmd_device_count() <= 0) return fail(nullptr, FMD_ERR_NO_DEVICE, "no gfx950 device");
     float *dy = nullptr, *dx = nullptr, *dout = nullptr;
+    unsigned char* dok = nullptr;
     const size_t bytes = n * sizeof(float);
     int rc = FMD_OK;
     if (hipMalloc(&dy, bytes) != hipSuccess || hipMalloc(&dx, bytes) != hipSuccess || hipMalloc(&dout, bytes) != hipSuccess) rc = FMD_ERR_DEVICE;
+    if (!rc && ok && hipMalloc(&dok, n) != hipSuccess) rc = FMD_ERR_DEVICE;
     if (!rc && (hipMemcpy(dy, y, bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice) != hipSuccess)) rc = FMD_ERR_DEVICE;
-    if (!rc && selftest_atan2(dy, dx, dout, n, nullptr) != hipSuccess) rc = FMD_ERR_DEVICE;
+    if (!rc && selftest_atan2(dy, dx, dout, dok, n, nullptr) != hipSuccess) rc = FMD_ERR_DEVICE;
     if (!rc && hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = FMD_ERR_DEVICE;
+    if (!rc && ok && hipMemcpy(ok, dok, n, hipMemcpyDeviceToHost) != hipSuccess) rc = FMD_ERR_DEVICE;
     if (dy) (void)hipFree(dy);
     if (dx) (void)hipFree(dx);
     if (dout) (void)hipFree(dout);
+    if (dok) (void)hipFree(dok);
     return rc ? fail(nullptr, rc, "selftest_atan2 failed") : FMD_OK;
+}
+
+int fmd_selftest_atan2(const float* y, const float* x, float* out, size_t n) { return selftest_atan2_host(y, x, out, nullptr, n); }
+
+int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t* ok, size_t n) {
+    if (!ok) return FMD_ERR_ARG;
+    return selftest_atan2_host(y, x, out, ok, n);
+}
+
+int fmd_get_spec_stats(fmd_handle h, uint64_t* out8, int reset) {
+    if (!h || !out8) return FMD_ERR_ARG;
+    int rc = fmd_synchronize(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpy(out8, h->ctx.b.spec_stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(h, hipMemset(h->ctx.b.spec_stats, 0, 8 * sizeof(uint64_t)));
+    return FMD_OK;
 }
 
 int fmd_profile_enable(fmd_handle h, int on) {

@@ -85,6 +85,7 @@ struct Buffers {
     float*  deemph;         // [C][4]  b0,b1,a0,flag
     float*  mix;            // [C][2]  audio mode (as float), stereo mix factor
     float*  state;          // [S_NUM_FIELDS][C]
+    unsigned long long* spec_stats;  // [8] speculation counters: pll {chunks, general, replayed, -}, rds {chunks, general, replayed, -}
 };
 
 struct LaunchCtx {
@@ -107,7 +108,7 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, int slot, hipStream_t s);     
 hipError_t launch_stage_extract(const LaunchCtx& ctx, int slot, hipStream_t s);                           // k_extract
 hipError_t launch_stage_rds(const LaunchCtx& ctx, int slot, hipStream_t s);                               // k_rds_sync
 hipError_t launch_reset_state(const LaunchCtx& ctx, hipStream_t stream);
-hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, size_t n, hipStream_t s);
+hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, unsigned char* d_ok, size_t n, hipStream_t s);
 hipError_t prepare_kernels();          // one-time function attributes (dynamic LDS sizes)
 int front_tail_len(int m);             // input-history samples k_front needs per channel
 

@@ -308,8 +308,144 @@ __global__ __launch_bounds__(kWave) void k_pilot_power(Dims d, const float2* __r
 }
 
 // a7 gain + a8 — reference LockOntoPilot :423-456, PLL_Mixer::Update (pll_mixer.cpp:12-21)
+struct PllState { float lx1, ly1, integ, err, tph; };
+
+// one loop iteration exactly as the reference computes it; returns dt (= the NCO phase in turns)
+__device__ __forceinline__ float pll_step(PllState& s, float p, float q, const LoopCoeffs& k) {
+    const float Ts = 1.0f / 128000.0f;
+    const float KTsI = 0.1f * Ts;
+    // loop filter IIR_Filter<float> K=2: t_i = fma(xn[i], b[i], yn[i]*a[i]); y += t_i
+    const float t0 = fmaf(s.lx1, k.pll_b0, s.ly1 * k.pll_a0);
+    const float t1 = fmaf(s.err, k.pll_b1, 0.0f);
+    const float lpf = (0.0f + t0) + t1;
+    s.lx1 = s.err; s.ly1 = lpf;
+    const float P = lpf * 0.01f;
+    s.integ = clampf(fmaf(s.err, KTsI, s.integ), -1.0f, 1.0f);
+    const float PI_error = s.integ + P;
+    // PLL_Mixer::Update
+    const float control = clampf(PI_error * 1.0f, -1.0f, 1.0f);
+    const float freq = fmaf(control, -100.0f, -19000.0f);
+    const float yy = fmaf(freq, Ts, s.tph);
+    s.tph = yy - round_half_away(yy);
+    float dt_cos = s.tph + 0.25f;
+    dt_cos = dt_cos - round_half_away(dt_cos);
+    const float ps = cheb_sine_scalar(s.tph);
+    const float pc = cheb_sine_scalar(dt_cos);
+    const float res_im = fmaf(ps, p, q * pc);
+    const float res_re = fmaf(p, pc, -(q * ps));
+    s.err = fmd_atan2f(res_im, res_re);
+    return s.tph;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Speculative form of the same iteration for a loop that is in lock.  A lone wavefront per SIMD issues one instruction
+// every ~4 cycles and waits ~6 cycles on a dependent result, so the loop's duration is set by its instruction count and
+// by the length of its err -> err dependency chain (78 operations in pll_step).  pll_step_locked cuts the chain to ~45:
+//   * the integrator / control clamps are skipped (shown not to bind for the whole chunk by pll_chunk_precheck),
+//   * x - round_half_away(x) becomes x - rndne(x) (equal unless x is an exact tie, detected from the chebyshev
+//     argument: wrapped phase == +-0.5  <=>  z - 0.25 == 0),
+//   * the phase detector is atan2f's first range with an unscaled division (fmd_math.h atan2f_small), valid for
+//     x in [2^-14, 2^13.75), 2^-29 <= |y/x| < 7/16 — both windows are 0x0de00000 wide in the float's bit pattern, so one
+//     unsigned max tracks both.
+// Validity is accumulated in VALU registers only (a v_cmp -> SALU round trip stalls an in-order wave ~18 cycles) and
+// tested once per 32-sample chunk; a chunk with any invalid lane is replayed with pll_step.  Constants live in VGPRs:
+// a 32-bit literal in the instruction stream costs a lone wave ~2.7 extra cycles per instruction.
+// ---------------------------------------------------------------------------------------------------------------
+struct PllConsts {
+    float b0, a0, b1, c001, ktsi, m100, m19000, ts, q25, mq25, c5, c4, c3, c2, c1, c0;
+    float a10, a8, a6, a4, a2, a0t, a9, a7, a5, a3, a1;
+    uint32_t absmask, xlo, tlo;
+};
+#define FMD_OPAQUE_F(dst, val) { float t_ = (val); asm volatile("" : "+v"(t_)); dst = t_; }
+#define FMD_OPAQUE_U(dst, val) { uint32_t t_ = (val); asm volatile("" : "+v"(t_)); dst = t_; }
+__device__ __forceinline__ PllConsts make_pll_consts(const LoopCoeffs& k) {
+    PllConsts c;
+    FMD_OPAQUE_F(c.b0, k.pll_b0) FMD_OPAQUE_F(c.a0, k.pll_a0) FMD_OPAQUE_F(c.b1, k.pll_b1) FMD_OPAQUE_F(c.c001, 0.01f)
+    FMD_OPAQUE_F(c.ktsi, 0.1f * (1.0f / 128000.0f)) FMD_OPAQUE_F(c.m100, -100.0f) FMD_OPAQUE_F(c.m19000, -19000.0f)
+    FMD_OPAQUE_F(c.ts, 1.0f / 128000.0f) FMD_OPAQUE_F(c.q25, 0.25f) FMD_OPAQUE_F(c.mq25, -0.25f)
+    FMD_OPAQUE_F(c.c5, 3.20396066f) FMD_OPAQUE_F(c.c4, -14.07150173f) FMD_OPAQUE_F(c.c3, 38.50016403f)
+    FMD_OPAQUE_F(c.c2, -67.07687378f) FMD_OPAQUE_F(c.c1, 64.83583069f) FMD_OPAQUE_F(c.c0, -25.13274193f)
+    FMD_OPAQUE_F(c.a10, bits_f32(0x3c8569d7u)) FMD_OPAQUE_F(c.a8, bits_f32(0x3d4bda59u)) FMD_OPAQUE_F(c.a6, bits_f32(0x3d886b35u))
+    FMD_OPAQUE_F(c.a4, bits_f32(0x3dba2e6eu)) FMD_OPAQUE_F(c.a2, bits_f32(0x3e124925u)) FMD_OPAQUE_F(c.a0t, bits_f32(0x3eaaaaabu))
+    FMD_OPAQUE_F(c.a9, bits_f32(0xbd15a221u)) FMD_OPAQUE_F(c.a7, bits_f32(0xbd6ef16bu)) FMD_OPAQUE_F(c.a5, bits_f32(0xbd9d8795u))
+    FMD_OPAQUE_F(c.a3, bits_f32(0xbde38e38u)) FMD_OPAQUE_F(c.a1, bits_f32(0xbe4ccccdu))
+    FMD_OPAQUE_U(c.absmask, 0x7fffffffu) FMD_OPAQUE_U(c.xlo, 0x38800000u) FMD_OPAQUE_U(c.tlo, 0x31000000u)
+    return c;
+}
+
+struct PllChecks { float tie_min; uint32_t range_max; };
+static constexpr uint32_t kRangeWindow = 0x0de00000u;
+
+// chebyshev_sine (scalar association) with register constants; zq = z - 1/4 is returned for the tie test
+__device__ __forceinline__ float cheb_sine_locked(float x, const PllConsts& c, float& zq) {
+    const float z = x * x;
+    float p = fmaf(c.c5, z, c.c4);
+    p = fmaf(p, z, c.c3);
+    p = fmaf(p, z, c.c2);
+    p = fmaf(p, z, c.c1);
+    p = fmaf(p, z, c.c0);
+    zq = z + c.mq25;
+    return (zq * x) * p;
+}
+
+// atan2f(y, x) for x in [2^-14, 2^13.75) and 2^-29 <= |y/x| < 7/16 (a locked loop's phase error): the published
+// algorithm reduces to t - t (s1 + s2) with t = y / x (its first range, which is odd-symmetric, so no quadrant or sign
+// selects), and the division needs neither operand scaling nor special-value fix-up.  range_max records the windows.
+__device__ __forceinline__ float atan2f_locked(float y, float x, const PllConsts& c, PllChecks& ck) {
+    const float t = div_unscaled(y, x);
+    ck.range_max = max(max(ck.range_max, f32_bits(x) - c.xlo), (f32_bits(t) & c.absmask) - c.tlo);
+    const float z = t * t;
+    const float w = z * z;
+    float s1 = c.a8 + w * c.a10;
+    s1 = c.a6 + w * s1;
+    s1 = c.a4 + w * s1;
+    s1 = c.a2 + w * s1;
+    s1 = c.a0t + w * s1;
+    s1 = z * s1;
+    float s2 = c.a7 + w * c.a9;
+    s2 = c.a5 + w * s2;
+    s2 = c.a3 + w * s2;
+    s2 = c.a1 + w * s2;
+    s2 = w * s2;
+    return t - t * (s1 + s2);
+}
+
+// Holds for the whole chunk if it holds at its start, given that every err the chunk produces is < 0.42 in magnitude
+// (implied by the range check): the loop filter is a convex combination (|lpf| <= max of its inputs), the integrator
+// moves by < 4e-6 per sample, so |integ| <= 0.9001, |integ + 0.01 lpf| <= 0.95 < 1 and |t + Ts freq| <= 0.65 < 1.5.
+__device__ __forceinline__ bool pll_chunk_precheck(const PllState& s, const LoopCoeffs& k) {
+    const bool convex = (k.pll_b0 >= 0.0f) && (k.pll_b1 >= 0.0f) && (k.pll_a0 >= 0.0f) && ((k.pll_b0 + k.pll_b1) + k.pll_a0 <= 1.0001f);
+    return convex && (fabsf(s.integ) <= 0.9f) && (fabsf(s.lx1) <= 4.0f) && (fabsf(s.ly1) <= 4.0f) && (fabsf(s.err) <= 4.0f) && (fabsf(s.tph) <= 0.5f);
+}
+
+__device__ __forceinline__ float pll_step_locked(PllState& s, float p, float q, const PllConsts& c, PllChecks& ck) {
+    const float t0 = fmaf(s.lx1, c.b0, s.ly1 * c.a0);
+    const float t1 = fmaf(s.err, c.b1, 0.0f);
+    const float lpf = (0.0f + t0) + t1;
+    s.lx1 = s.err; s.ly1 = lpf;
+    const float P = lpf * c.c001;
+    s.integ = fmaf(s.err, c.ktsi, s.integ);
+    const float PI_error = s.integ + P;
+    const float freq = fmaf(PI_error, c.m100, c.m19000);
+    const float yy = fmaf(freq, c.ts, s.tph);
+    s.tph = yy - rintf(yy);
+    const float dc = s.tph + c.q25;
+    const float dt_cos = dc - rintf(dc);
+    float zq_s, zq_c;
+    const float ps = cheb_sine_locked(s.tph, c, zq_s);
+    const float pc = cheb_sine_locked(dt_cos, c, zq_c);
+    ck.tie_min = fminf(fminf(ck.tie_min, fabsf(zq_s)), fabsf(zq_c));
+    const float res_im = fmaf(ps, p, q * pc);
+    const float res_re = fmaf(p, pc, -(q * ps));
+    s.err = atan2f_locked(res_im, res_re, c, ck);
+    return s.tph;
+}
+
+static constexpr int kSlowHoldMax = 64;   // longest run of general-form chunks between two speculation attempts
+
 __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
-                                                     float* __restrict__ state, LoopCoeffs k, int power_field) {
+                                                     float* __restrict__ state, LoopCoeffs k, int power_field,
+                                                     unsigned long long* __restrict__ spec_stats) {
     __shared__ __attribute__((aligned(16))) float2 xin[2][kWave * kRowC];
     __shared__ __attribute__((aligned(16))) float dt_out[kWave * kRowF];
     __builtin_amdgcn_s_setprio(3);  // latency-bound recurrence: win issue arbitration against co-resident FIR waves
@@ -324,48 +460,55 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
         const float target_gain = sqrtf((1.0f / sum) * (float)n);
         gain = fmaf(target_gain - gain, 0.2f, gain);
     }
-    float lx1 = st(state, S_PLL_X1, d.C, cs), ly1 = st(state, S_PLL_Y1, d.C, cs);
-    float integ = st(state, S_PLL_INT, d.C, cs), err = st(state, S_PLL_ERR, d.C, cs), tph = st(state, S_PLL_T, d.C, cs);
-    const float Ts = 1.0f / 128000.0f;
-    const float KTsI = 0.1f * Ts;
+    PllState S;
+    S.lx1 = st(state, S_PLL_X1, d.C, cs); S.ly1 = st(state, S_PLL_Y1, d.C, cs);
+    S.integ = st(state, S_PLL_INT, d.C, cs); S.err = st(state, S_PLL_ERR, d.C, cs); S.tph = st(state, S_PLL_T, d.C, cs);
+    const PllConsts kc = make_pll_consts(k);
+    // a failed speculative chunk is replayed with the general forms; consecutive failures (a loop out of lock) back
+    // off exponentially so an unlocked wavefront pays at most a few percent for its attempts
+    int slow_left = 0, hold = 0, n_replayed = 0, n_general = 0;
     ChunkRegsC regs = chunk_load_c(pilot, n, c0, d.C, 0);
     for (int ch = 0; ch < chunks; ch++) {
         float2* buf = xin[ch & 1];
         chunk_store_c(regs, buf);
         __syncthreads();
         regs = chunk_load_c(pilot, n, c0, d.C, (ch + 1 < chunks ? ch + 1 : ch) * kChunk);
-        for (int t = 0; t < kChunk; t++) {
-            const float2 y = buf[lane * kRowC + t];
-            const float p = gain * y.x, q = gain * y.y;
-            // loop filter IIR_Filter<float> K=2: t_i = fma(xn[i], b[i], yn[i]*a[i]); y += t_i
-            const float t0 = fmaf(lx1, k.pll_b0, ly1 * k.pll_a0);
-            const float t1 = fmaf(err, k.pll_b1, 0.0f);
-            const float lpf = (0.0f + t0) + t1;
-            lx1 = err; ly1 = lpf;
-            const float P = lpf * 0.01f;
-            integ = clampf(fmaf(err, KTsI, integ), -1.0f, 1.0f);
-            const float PI_error = integ + P;
-            // PLL_Mixer::Update
-            const float control = clampf(PI_error * 1.0f, -1.0f, 1.0f);
-            const float freq = fmaf(control, -100.0f, -19000.0f);
-            const float yy = fmaf(freq, Ts, tph);
-            tph = yy - round_half_away(yy);
-            float dt_cos = tph + 0.25f;
-            dt_cos = dt_cos - round_half_away(dt_cos);
-            const float ps = cheb_sine_scalar(tph);
-            const float pc = cheb_sine_scalar(dt_cos);
-            const float res_im = fmaf(ps, p, q * pc);
-            const float res_re = fmaf(p, pc, -(q * ps));
-            err = fmd_atan2f(res_im, res_re);
-            dt_out[lane * kRowF + t] = tph;
+        bool done = false;
+        if (slow_left == 0) {
+            PllState s = S;
+            PllChecks ck{1.0f, 0u};
+            float2 y = buf[lane * kRowC];
+#pragma unroll 8
+            for (int t = 0; t < kChunk; t++) {
+                const float2 yn = buf[lane * kRowC + (t + 1 < kChunk ? t + 1 : t)];   // next sample's LDS read one step ahead
+                dt_out[lane * kRowF + t] = pll_step_locked(s, gain * y.x, gain * y.y, kc, ck);
+                y = yn;
+            }
+            const bool ok = pll_chunk_precheck(S, k) && (ck.tie_min != 0.0f) && (ck.range_max < kRangeWindow);
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) { S = s; done = true; hold = 0; }
+            else { slow_left = hold; hold = hold ? (2 * hold < kSlowHoldMax ? 2 * hold : kSlowHoldMax) : 1; n_replayed++; }
+        } else {
+            slow_left--;
+        }
+        if (!done) {
+            n_general++;
+            for (int t = 0; t < kChunk; t++) {
+                const float2 y = buf[lane * kRowC + t];
+                dt_out[lane * kRowF + t] = pll_step(S, gain * y.x, gain * y.y, k);
+            }
         }
         __syncthreads();
         chunk_flush_f(dt_out, pll_dt, n, c0, d.C, ch * kChunk);
     }
     if (live) {
         st(state, S_AGC_PILOT_GAIN, d.C, c) = gain;
-        st(state, S_PLL_X1, d.C, c) = lx1; st(state, S_PLL_Y1, d.C, c) = ly1;
-        st(state, S_PLL_INT, d.C, c) = integ; st(state, S_PLL_ERR, d.C, c) = err; st(state, S_PLL_T, d.C, c) = tph;
+        st(state, S_PLL_X1, d.C, c) = S.lx1; st(state, S_PLL_Y1, d.C, c) = S.ly1;
+        st(state, S_PLL_INT, d.C, c) = S.integ; st(state, S_PLL_ERR, d.C, c) = S.err; st(state, S_PLL_T, d.C, c) = S.tph;
+    }
+    if (lane == 0 && spec_stats) {   // chunks total / run with the general forms / speculated and replayed
+        atomicAdd(&spec_stats[0], (unsigned long long)chunks);
+        atomicAdd(&spec_stats[1], (unsigned long long)n_general);
+        atomicAdd(&spec_stats[2], (unsigned long long)n_replayed);
     }
 }
 
@@ -816,13 +959,23 @@ __global__ __launch_bounds__(256) void k_hilbert(Dims d, const float* __restrict
     if (tile == tiles - 1 && tid < 64) fo_tail_out[(size_t)c * 64 + tid] = row[d.n_fm_out - 64 + tid];
 }
 
-__global__ void k_selftest_atan2(const float* __restrict__ y, const float* __restrict__ x, float* __restrict__ out, size_t n) {
+__global__ void k_selftest_atan2(const float* __restrict__ y, const float* __restrict__ x, float* __restrict__ out,
+                                 unsigned char* __restrict__ ok_out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = fmd_atan2f(y[i], x[i]);
+    if (i >= n) return;
+    if (ok_out) {   // the locked-loop short form and its exactness predicate
+        LoopCoeffs k{};
+        const PllConsts c = make_pll_consts(k);
+        PllChecks ck{1.0f, 0u};
+        out[i] = atan2f_locked(y[i], x[i], c, ck);
+        ok_out[i] = ck.range_max < kRangeWindow ? 1 : 0;
+    } else {
+        out[i] = fmd_atan2f(y[i], x[i]);
+    }
 }
 
-hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_selftest_atan2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_y, d_x, d_out, n);
+hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, unsigned char* d_ok, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_selftest_atan2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_y, d_x, d_out, d_ok, n);
     return hipGetLastError();
 }
 
@@ -881,7 +1034,7 @@ hipError_t launch_stage_power(const LaunchCtx& ctx, int slot, hipStream_t s) {
 hipError_t launch_stage_pll(const LaunchCtx& ctx, int slot, hipStream_t s) {
     const Dims& d = ctx.d;
     hipLaunchKernelGGL(k_pilot_pll, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.pilot[slot], ctx.b.pll_dt[slot], ctx.b.state,
-                       ctx.loops, slot ? (int)S_PILOT_POWER1 : (int)S_PILOT_POWER0);
+                       ctx.loops, slot ? (int)S_PILOT_POWER1 : (int)S_PILOT_POWER0, ctx.b.spec_stats);
     return hipGetLastError();
 }
 

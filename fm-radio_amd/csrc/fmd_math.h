@@ -212,6 +212,31 @@ FMD_HD float fmd_atan2f(float y, float x) {
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Short forms for the latency-bound serial loops (pilot PLL, BPSK synchroniser), see fmd_kernels.hip pll_step_locked.
+// Each computes EXACTLY the value of its general form whenever its stated precondition holds; the loops run a span of
+// samples with the short forms, record the preconditions off the critical path, and replay the span with the general
+// forms (wave-uniformly) if any lane violated one.  Nothing is approximated.
+// ---------------------------------------------------------------------------------------------
+
+// y / x by the IEEE expansion (rcp, two refinements of the reciprocal and quotient, final residual correction) without
+// its operand scaling and special-value fix-up steps: the correctly rounded quotient whenever neither would act, i.e.
+// for normal operands whose quotient and residuals stay normal (the caller checks ranges).
+FMD_HD float div_unscaled(float y, float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __builtin_amdgcn_rcpf(x);
+#else
+    float r = 1.0f / x;
+#endif
+    const float e0 = fmaf(-x, r, 1.0f);
+    r = fmaf(e0, r, r);
+    float q = y * r;
+    const float e1 = fmaf(-x, q, y);
+    q = fmaf(e1, r, q);
+    const float e2 = fmaf(-x, q, y);
+    return fmaf(e2, r, q);
+}
+
 // std::round as the reference build inlines it: trunc(x + copysign(pred(0.5), x))
 FMD_HD float round_half_away(float x) { return truncf(x + copysignf(bits_f32(kPredHalfBits), x)); }
 

@@ -157,6 +157,14 @@ typedef struct {
 /* Self-test hook: evaluates the kernels' atan2f on the device for n host-side (y, x) pairs, so tests can compare
  * the device math bit-for-bit with the host libm the reference links (std::atan2, reference fm_demod.cpp:40). */
 int fmd_selftest_atan2(const float* y, const float* x, float* out, size_t n);
+/* Same for the short form the serial loops use while in lock: out[i] is only meaningful where ok[i] != 0, and there it
+ * must equal atan2f(y[i], x[i]) bit-for-bit (DESIGN.md "Speculative serial loops"). */
+int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t* ok, size_t n);
+
+/* Speculation counters of the serial loops since creation / the last reset, in 32-sample chunks summed over wavefronts:
+ * out8[0..2] = pilot PLL {chunks, chunks run with the general forms, chunks speculated then replayed};
+ * out8[4..6] = BPSK synchroniser, same meaning.  Results never depend on them; they explain k_pilot_pll's duration. */
+int fmd_get_spec_stats(fmd_handle h, uint64_t* out8, int reset);
 
 int fmd_profile_enable(fmd_handle h, int on);
 int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out);

@@ -203,6 +203,49 @@ def test_device_atan2_equals_host_libm(pkg):
     assert not neq.any(), f"{int(neq.sum())} mismatches, first: y={y[neq][0]!r} x={x[neq][0]!r} dev={dev[neq][0]!r} host={host[neq][0]!r}"
 
 
+def test_device_atan2_short_form_is_exact_where_it_claims(pkg):
+    """The locked-loop short form (no range selection, shortened division): wherever its predicate holds, its value is
+    libm's atan2f bit-for-bit; and the predicate does hold on the inputs a locked loop produces."""
+    rng = np.random.default_rng(11)
+    n = 6_000_000
+    bits = rng.integers(0, 2**32, size=(2, n), dtype=np.uint64).astype(np.uint32)
+    # locked-loop shaped: x > 0, small |y/x|; then everything else, where the predicate must protect the value
+    x0 = np.exp(rng.uniform(-9, 9, n)).astype(np.float32)     # inside the short form's [2^-14, 2^13.75) window
+    y0 = (x0 * rng.uniform(-0.45, 0.45, n)).astype(np.float32)
+    base = np.array([0.4375, 2.0 ** -29, 0.25, 1e-3], np.float32)
+    r = np.concatenate([np.nextafter(b, np.float32(np.inf)) * (1 + np.arange(-3000, 3000, dtype=np.float32) * np.float32(6e-8)) for b in base]).astype(np.float32)
+    xv = rng.choice(np.array([1.0, 3.3, 0.77, 100.0, 2.0 ** -10, 2.0 ** -14, 2.0 ** -15, 2.0 ** 13, 2.0 ** 14, 2.0 ** -62, 2.0 ** 61], np.float32), r.size)
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e38, -1e38, 1e-38, 3e-39, 1e-20, 1e20], np.float32)
+    gy, gx = np.meshgrid(sp, sp)
+    y = np.concatenate([y0, bits[0].view(np.float32), rng.uniform(-1.5, 1.5, n).astype(np.float32), (r * xv * rng.choice(np.array([1, -1], np.float32), r.size)).astype(np.float32), gy.reshape(-1)])
+    x = np.concatenate([x0, bits[1].view(np.float32), rng.uniform(-1.5, 1.5, n).astype(np.float32), xv, gx.reshape(-1)])
+    dev, ok = pkg.selftest_atan2_small(y, x)
+    host = O.libm_atan2f(y, x)
+    neq = ok & (dev.view(np.uint32) != host.view(np.uint32))
+    assert not neq.any(), f"{int(neq.sum())} mismatches, first: y={y[neq][0]!r} x={x[neq][0]!r} dev={dev[neq][0]!r} host={host[neq][0]!r}"
+    with np.errstate(all="ignore"):
+        t = np.abs(y[:n].astype(np.float64) / x[:n].astype(np.float64))
+    inside = (t < 0.43) & (t > 1e-8)
+    assert ok[:n][inside].mean() > 0.999          # the short division almost never needs its last refinement
+    assert not ok[n:2 * n][x[n:2 * n] <= 0].any()  # never claimed outside x > 0
+
+
+def test_serial_loops_speculate_when_locked_and_replay_when_not(pkg):
+    """After acquisition the pilot PLL runs its chunks with the short forms; results are identical either way (every other
+    test in this file checks that) — here only that both paths are actually exercised."""
+    nb = 14
+    caps = _caps(2, nb * 16384, fs=256_000.0, seed=23)
+    dm = pkg.BatchDemod(n_channels=2, block_size=16384, fs_baseband=256_000)
+    per_block = []
+    for b in range(nb):
+        dm.process(caps[:, b * 16384:(b + 1) * 16384])
+        per_block.append(dm.spec_stats(reset=True)["pll"])
+    dm.close()
+    assert per_block[0]["chunks"] == 8192 // 32 and per_block[0]["general"] > 0      # acquisition: general forms
+    locked = per_block[-4:]
+    assert sum(p["general"] for p in locked) <= 0.05 * sum(p["chunks"] for p in locked)   # in lock: short forms
+
+
 def test_gpu_runs_are_deterministic(pkg):
     caps = _caps(3, 6 * 65536, seed=17, u8=True)
     a = run_gpu(pkg, caps, 65536, 1_024_000)
