@@ -279,8 +279,11 @@ class BatchDemod:
         """Speculation counters of the serial loops (fmd_get_spec_stats), in 32-sample chunks summed over wavefronts."""
         a = np.zeros(8, np.uint64)
         self._check(self.L.fmd_get_spec_stats(self.h, a.ctypes.data_as(C.c_void_p), 1 if reset else 0))
-        return {"pll": {"chunks": int(a[0]), "general": int(a[1]), "replayed": int(a[2])},
-                "rds": {"chunks": int(a[4]), "general": int(a[5]), "replayed": int(a[6])}}
+        out = {"pll": {"chunks": int(a[0]), "general": int(a[1]), "replayed": int(a[2])},
+               "rds": {"chunks": int(a[4]), "general": int(a[5])}}
+        if a[7]:
+            out["pll_clock_mhz"] = float(a[6]) / float(a[7]) * 100.0
+        return out
 
     def profile_read(self) -> dict:
         """{kernel name: (total ms, launches)} since the last read (HIP events on the processing stream)."""

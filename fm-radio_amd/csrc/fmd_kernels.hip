@@ -223,7 +223,7 @@ struct ChunkRegsC { float4 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12
 #define FMD_FOR16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
 __device__ __forceinline__ ChunkRegsC chunk_load_c(const float2* __restrict__ base, int n, int c0, int C, int t0) {
-    const int lane = threadIdx.x, row = lane >> 4, col = lane & 15;
+    const int lane = threadIdx.x & (kWave - 1), row = lane >> 4, col = lane & 15;
     ChunkRegsC r;
 #define FMD_LD(k) { int ch = c0 + 4 * k + row; ch = ch < C ? ch : C - 1; \
                     r.v##k = *reinterpret_cast<const float4*>(base + (size_t)ch * n + t0 + 2 * col); }
@@ -232,14 +232,14 @@ __device__ __forceinline__ ChunkRegsC chunk_load_c(const float2* __restrict__ ba
     return r;
 }
 __device__ __forceinline__ void chunk_store_c(const ChunkRegsC& r, float2* lds) {
-    const int lane = threadIdx.x, row = lane >> 4, col = lane & 15;
+    const int lane = threadIdx.x & (kWave - 1), row = lane >> 4, col = lane & 15;
 #define FMD_ST(k) *reinterpret_cast<float4*>(lds + (4 * k + row) * kRowC + 2 * col) = r.v##k;
     FMD_FOR16(FMD_ST)
 #undef FMD_ST
 }
 // flush a transposed cf32 chunk [64][kRowC] to out[C][n] at t0
 __device__ __forceinline__ void chunk_flush_c(const float2* lds, float2* __restrict__ out, int n, int c0, int C, int t0) {
-    const int lane = threadIdx.x, row = lane >> 4, col = lane & 15;
+    const int lane = threadIdx.x & (kWave - 1), row = lane >> 4, col = lane & 15;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const int r = 4 * k + row, ch = c0 + r;
@@ -248,7 +248,7 @@ __device__ __forceinline__ void chunk_flush_c(const float2* lds, float2* __restr
 }
 // flush a [64][kRowF] f32 chunk to out[C][n] at t0
 __device__ __forceinline__ void chunk_flush_f(const float* lds, float* __restrict__ out, int n, int c0, int C, int t0) {
-    const int lane = threadIdx.x, row = lane >> 3, col = lane & 7;
+    const int lane = threadIdx.x & (kWave - 1), row = lane >> 3, col = lane & 7;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int r = 8 * k + row, ch = c0 + r;
@@ -443,36 +443,56 @@ __device__ __forceinline__ float pll_step_locked(PllState& s, float p, float q, 
 
 static constexpr int kSlowHoldMax = 64;   // longest run of general-form chunks between two speculation attempts
 
-__global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
-                                                     float* __restrict__ state, LoopCoeffs k, int power_field,
-                                                     unsigned long long* __restrict__ spec_stats) {
+// Workgroup = two wavefronts.  Wave 0 runs the recurrence for 64 channels and touches only LDS; wave 1 (the mover) stages
+// the next chunks HBM -> registers -> LDS and drains finished pll_dt chunks LDS -> HBM.  A lone wave is bound by its own
+// instruction issue, and a vector-memory instruction costs it tens of cycles — hundreds when other stages' kernels keep
+// the CU's memory pipeline busy — so the memory instructions are given to a sibling on another SIMD; the two meet at one
+// barrier per 32-sample chunk.
+__global__ __launch_bounds__(2 * kWave) void k_pilot_pll(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
+                                                         float* __restrict__ state, LoopCoeffs k, int power_field,
+                                                         unsigned long long* __restrict__ spec_stats) {
     __shared__ __attribute__((aligned(16))) float2 xin[2][kWave * kRowC];
-    __shared__ __attribute__((aligned(16))) float dt_out[kWave * kRowF];
-    __builtin_amdgcn_s_setprio(3);  // latency-bound recurrence: win issue arbitration against co-resident FIR waves
-    const int lane = threadIdx.x, c0 = blockIdx.x * kWave, c = c0 + lane;
+    __shared__ __attribute__((aligned(16))) float dt_out[2][kWave * kRowF];
+    const bool mover = threadIdx.x >= kWave;   // wave-uniform
+    const int lane = threadIdx.x & (kWave - 1), c0 = blockIdx.x * kWave, c = c0 + lane;
     const bool live = c < d.C;
     const int cs = live ? c : d.C - 1;
     const int n = d.n_fm_out, chunks = n / kChunk;
-    // AGC_Filter::process (agc.h:12-19) as compiled: target_gain = sqrt((target/sum) * N)
-    float gain = st(state, S_AGC_PILOT_GAIN, d.C, cs);
-    {
+    unsigned long long clk0 = 0, rt0 = 0;
+    float gain = 0.0f;
+    PllState S{};
+    PllConsts kc{};
+    ChunkRegsC regs_a{}, regs_b{};   // mover: chunks ch+1 / ch+2 in flight
+    if (mover) {
+        regs_a = chunk_load_c(pilot, n, c0, d.C, 0);
+        chunk_store_c(regs_a, xin[0]);
+        regs_a = chunk_load_c(pilot, n, c0, d.C, (chunks > 1 ? 1 : 0) * kChunk);
+        regs_b = chunk_load_c(pilot, n, c0, d.C, (chunks > 2 ? 2 : 0) * kChunk);
+    } else {
+        __builtin_amdgcn_s_setprio(3);  // latency-bound recurrence: win issue arbitration against co-resident FIR waves
+        clk0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime();
+        // AGC_Filter::process (agc.h:12-19) as compiled: target_gain = sqrt((target/sum) * N)
+        gain = st(state, S_AGC_PILOT_GAIN, d.C, cs);
         const float sum = st(state, power_field, d.C, cs);
         const float target_gain = sqrtf((1.0f / sum) * (float)n);
         gain = fmaf(target_gain - gain, 0.2f, gain);
+        S.lx1 = st(state, S_PLL_X1, d.C, cs); S.ly1 = st(state, S_PLL_Y1, d.C, cs);
+        S.integ = st(state, S_PLL_INT, d.C, cs); S.err = st(state, S_PLL_ERR, d.C, cs); S.tph = st(state, S_PLL_T, d.C, cs);
+        kc = make_pll_consts(k);
     }
-    PllState S;
-    S.lx1 = st(state, S_PLL_X1, d.C, cs); S.ly1 = st(state, S_PLL_Y1, d.C, cs);
-    S.integ = st(state, S_PLL_INT, d.C, cs); S.err = st(state, S_PLL_ERR, d.C, cs); S.tph = st(state, S_PLL_T, d.C, cs);
-    const PllConsts kc = make_pll_consts(k);
     // a failed speculative chunk is replayed with the general forms; consecutive failures (a loop out of lock) back
     // off exponentially so an unlocked wavefront pays at most a few percent for its attempts
     int slow_left = 0, hold = 0, n_replayed = 0, n_general = 0;
-    ChunkRegsC regs = chunk_load_c(pilot, n, c0, d.C, 0);
-    for (int ch = 0; ch < chunks; ch++) {
-        float2* buf = xin[ch & 1];
-        chunk_store_c(regs, buf);
-        __syncthreads();
-        regs = chunk_load_c(pilot, n, c0, d.C, (ch + 1 < chunks ? ch + 1 : ch) * kChunk);
+
+    // mover, iteration ch: chunk ch+1 -> LDS (its loads were issued two iterations ago), issue chunk ch+3, drain chunk ch-1
+    auto move_chunk = [&](int ch, ChunkRegsC& regs) {
+        if (ch + 1 < chunks) chunk_store_c(regs, xin[(ch + 1) & 1]);
+        if (ch + 3 < chunks) regs = chunk_load_c(pilot, n, c0, d.C, (ch + 3) * kChunk);
+        if (ch > 0) chunk_flush_f(dt_out[(ch - 1) & 1], pll_dt, n, c0, d.C, (ch - 1) * kChunk);
+    };
+    auto compute_chunk = [&](int ch) {
+        const float2* buf = xin[ch & 1];
+        float* dto = dt_out[ch & 1];
         bool done = false;
         if (slow_left == 0) {
             PllState s = S;
@@ -481,7 +501,7 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
 #pragma unroll 8
             for (int t = 0; t < kChunk; t++) {
                 const float2 yn = buf[lane * kRowC + (t + 1 < kChunk ? t + 1 : t)];   // next sample's LDS read one step ahead
-                dt_out[lane * kRowF + t] = pll_step_locked(s, gain * y.x, gain * y.y, kc, ck);
+                dto[lane * kRowF + t] = pll_step_locked(s, gain * y.x, gain * y.y, kc, ck);
                 y = yn;
             }
             const bool ok = pll_chunk_precheck(S, k) && (ck.tie_min != 0.0f) && (ck.range_max < kRangeWindow);
@@ -494,11 +514,23 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
             n_general++;
             for (int t = 0; t < kChunk; t++) {
                 const float2 y = buf[lane * kRowC + t];
-                dt_out[lane * kRowF + t] = pll_step(S, gain * y.x, gain * y.y, k);
+                dto[lane * kRowF + t] = pll_step(S, gain * y.x, gain * y.y, k);
             }
         }
+    };
+    for (int ch = 0; ch < chunks; ch++) {
+        // here: xin[ch & 1] holds chunk ch, dt_out[(ch - 1) & 1] the results of chunk ch - 1, and nobody reads dt_out[ch & 1]
         __syncthreads();
-        chunk_flush_f(dt_out, pll_dt, n, c0, d.C, ch * kChunk);
+        if (mover) {
+            if (ch & 1) move_chunk(ch, regs_b); else move_chunk(ch, regs_a);
+        } else {
+            compute_chunk(ch);
+        }
+    }
+    __syncthreads();
+    if (mover) {
+        chunk_flush_f(dt_out[(chunks - 1) & 1], pll_dt, n, c0, d.C, (chunks - 1) * kChunk);
+        return;
     }
     if (live) {
         st(state, S_AGC_PILOT_GAIN, d.C, c) = gain;
@@ -509,6 +541,9 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
         atomicAdd(&spec_stats[0], (unsigned long long)chunks);
         atomicAdd(&spec_stats[1], (unsigned long long)n_general);
         atomicAdd(&spec_stats[2], (unsigned long long)n_replayed);
+        // shader-clock cycles and 100 MHz real-time ticks this wavefront ran: their ratio is the core clock the power
+        // management granted while the other stages' kernels ran beside it (DESIGN.md "Clocks")
+        if (blockIdx.x == 0) { atomicAdd(&spec_stats[6], __builtin_readcyclecounter() - clk0); atomicAdd(&spec_stats[7], __builtin_amdgcn_s_memrealtime() - rt0); }
     }
 }
 
@@ -1033,7 +1068,7 @@ hipError_t launch_stage_power(const LaunchCtx& ctx, int slot, hipStream_t s) {
 
 hipError_t launch_stage_pll(const LaunchCtx& ctx, int slot, hipStream_t s) {
     const Dims& d = ctx.d;
-    hipLaunchKernelGGL(k_pilot_pll, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.pilot[slot], ctx.b.pll_dt[slot], ctx.b.state,
+    hipLaunchKernelGGL(k_pilot_pll, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, ctx.b.pilot[slot], ctx.b.pll_dt[slot], ctx.b.state,
                        ctx.loops, slot ? (int)S_PILOT_POWER1 : (int)S_PILOT_POWER0, ctx.b.spec_stats);
     return hipGetLastError();
 }

@@ -163,7 +163,9 @@ int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t
 
 /* Speculation counters of the serial loops since creation / the last reset, in 32-sample chunks summed over wavefronts:
  * out8[0..2] = pilot PLL {chunks, chunks run with the general forms, chunks speculated then replayed};
- * out8[4..6] = BPSK synchroniser, same meaning.  Results never depend on them; they explain k_pilot_pll's duration. */
+ * out8[4..5] = BPSK synchroniser {chunks, general}; out8[6], out8[7] = shader-clock cycles and 100 MHz real-time ticks
+ * accumulated by one k_pilot_pll wavefront per launch (ratio x 100 = the core clock in MHz the kernel ran at).
+ * Results never depend on any of them; they explain k_pilot_pll's duration. */
 int fmd_get_spec_stats(fmd_handle h, uint64_t* out8, int reset);
 
 int fmd_profile_enable(fmd_handle h, int on);

@@ -207,6 +207,323 @@ __global__ __launch_bounds__(kWave) void k_pll_variant(Dims d, const float2* __r
     }
 }
 
+// ---- variant 4: two channels per lane, packed fp32 (v_pk_*) ---------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f splat(float x) { v2f r; r.x = x; r.y = x; return r; }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_rint(v2f a) { v2f r; r.x = rintf(a.x); r.y = rintf(a.y); return r; }
+__device__ __forceinline__ v2f pk_rcp(v2f a) { v2f r; r.x = __builtin_amdgcn_rcpf(a.x); r.y = __builtin_amdgcn_rcpf(a.y); return r; }
+struct PllState2 { v2f lx1, ly1, integ, err, tph; };
+struct Checks2 { float tie_min, t_min, t_max, x_min, x_max; };
+__device__ __forceinline__ v2f cheb2(v2f x, const PllConsts& c, v2f& zq) {
+    const v2f z = x * x;
+    v2f p = pk_fma(splat(c.c5), z, splat(c.c4));
+    p = pk_fma(p, z, splat(c.c3));
+    p = pk_fma(p, z, splat(c.c2));
+    p = pk_fma(p, z, splat(c.c1));
+    p = pk_fma(p, z, splat(c.c0));
+    zq = z + splat(c.mq25);
+    return (zq * x) * p;
+}
+__device__ __forceinline__ v2f pll_step2(PllState2& s, v2f p, v2f q, const PllConsts& c, Checks2& ck) {
+    const v2f zero = splat(0.0f);
+    const v2f t0 = pk_fma(s.lx1, splat(c.b0), s.ly1 * splat(c.a0));
+    const v2f t1 = pk_fma(s.err, splat(c.b1), zero);
+    const v2f lpf = (zero + t0) + t1;
+    s.lx1 = s.err; s.ly1 = lpf;
+    const v2f P = lpf * splat(c.c001);
+    s.integ = pk_fma(s.err, splat(c.ktsi), s.integ);
+    const v2f PI_error = s.integ + P;
+    const v2f freq = pk_fma(PI_error, splat(c.m100), splat(c.m19000));
+    const v2f yy = pk_fma(freq, splat(c.ts), s.tph);
+    s.tph = yy - pk_rint(yy);
+    const v2f dc = s.tph + splat(c.q25);
+    const v2f dt_cos = dc - pk_rint(dc);
+    v2f zq_s, zq_c;
+    const v2f ps = cheb2(s.tph, c, zq_s);
+    const v2f pc = cheb2(dt_cos, c, zq_c);
+    ck.tie_min = fminf(fminf(ck.tie_min, fabsf(zq_s.x)), fabsf(zq_c.x));
+    ck.tie_min = fminf(fminf(ck.tie_min, fabsf(zq_s.y)), fabsf(zq_c.y));
+    const v2f res_im = pk_fma(ps, p, q * pc);
+    const v2f res_re = pk_fma(p, pc, -(q * ps));
+    // div_unscaled
+    v2f r = pk_rcp(res_re);
+    const v2f nx = -res_re;
+    const v2f e0 = pk_fma(nx, r, splat(1.0f));
+    r = pk_fma(e0, r, r);
+    v2f t = res_im * r;
+    const v2f e1 = pk_fma(nx, t, res_im);
+    t = pk_fma(e1, r, t);
+    const v2f e2 = pk_fma(nx, t, res_im);
+    t = pk_fma(e2, r, t);
+    ck.t_max = fmaxf(fmaxf(ck.t_max, fabsf(t.x)), fabsf(t.y));
+    ck.t_min = fminf(fminf(ck.t_min, fabsf(t.x)), fabsf(t.y));
+    ck.x_max = fmaxf(fmaxf(ck.x_max, res_re.x), res_re.y);
+    ck.x_min = fminf(fminf(ck.x_min, res_re.x), res_re.y);
+    const v2f z = t * t;
+    const v2f w = z * z;
+    v2f s1 = splat(c.a8) + w * splat(c.a10);
+    s1 = splat(c.a6) + w * s1;
+    s1 = splat(c.a4) + w * s1;
+    s1 = splat(c.a2) + w * s1;
+    s1 = splat(c.a0t) + w * s1;
+    s1 = z * s1;
+    v2f s2 = splat(c.a7) + w * splat(c.a9);
+    s2 = splat(c.a5) + w * s2;
+    s2 = splat(c.a3) + w * s2;
+    s2 = splat(c.a1) + w * s2;
+    s2 = w * s2;
+    s.err = t - t * (s1 + s2);
+    return s.tph;
+}
+
+// 16-sample chunk helpers (8 float4 registers per 64-channel group instead of 16)
+static constexpr int kCh16 = 16, kRow16C = 18, kRow16F = 20;
+struct Chunk16 { float4 v0, v1, v2, v3, v4, v5, v6, v7; };
+#define FMD_FOR8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+__device__ __forceinline__ Chunk16 chunk16_load(const float2* __restrict__ base, int n, int c0, int C, int t0) {
+    const int lane = threadIdx.x, row = lane >> 3, col = lane & 7;
+    Chunk16 r;
+#define FMD_LD8(k) { int ch = c0 + 8 * k + row; ch = ch < C ? ch : C - 1; r.v##k = *reinterpret_cast<const float4*>(base + (size_t)ch * n + t0 + 2 * col); }
+    FMD_FOR8(FMD_LD8)
+#undef FMD_LD8
+    return r;
+}
+__device__ __forceinline__ void chunk16_store(const Chunk16& r, float2* lds) {
+    const int lane = threadIdx.x, row = lane >> 3, col = lane & 7;
+#define FMD_ST8(k) *reinterpret_cast<float4*>(lds + (8 * k + row) * kRow16C + 2 * col) = r.v##k;
+    FMD_FOR8(FMD_ST8)
+#undef FMD_ST8
+}
+__device__ __forceinline__ void chunk16_flush_f(const float* lds, float* __restrict__ out, int n, int c0, int C, int t0) {
+    const int lane = threadIdx.x, row = lane >> 2, col = lane & 3;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int r = 16 * k + row, ch = c0 + r;
+        if (ch < C) *reinterpret_cast<float4*>(out + (size_t)ch * n + t0 + 4 * col) = *reinterpret_cast<const float4*>(lds + r * kRow16F + 4 * col);
+    }
+}
+
+// NP packed pairs per lane: a wavefront owns 128*NP channels; the NP pair streams are independent, so the scheduler
+// fills one stream's dependency stalls (and packed-op hazard slots) with the other's instructions
+template <int NP>
+__global__ __launch_bounds__(kWave) void k_pll_pk(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
+                                                  float* __restrict__ state, LoopCoeffs k, int power_field,
+                                                  unsigned long long* __restrict__ spec_stats) {
+    constexpr int G = 2 * NP;   // 64-channel groups per wavefront
+    __shared__ __attribute__((aligned(16))) float2 xin[G][kWave * kRow16C];
+    __shared__ __attribute__((aligned(16))) float dt_out[G][kWave * kRow16F];
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x, c0 = blockIdx.x * G * kWave;
+    const int n = d.n_fm_out, chunks = n / kCh16;
+    bool live[G];
+    float gain[G];
+    PllState S[G];
+#pragma unroll
+    for (int h = 0; h < G; h++) {
+        const int c = c0 + h * kWave + lane;
+        live[h] = c < d.C;
+        const int cs = live[h] ? c : d.C - 1;
+        gain[h] = st(state, S_AGC_PILOT_GAIN, d.C, cs);
+        const float sum = st(state, power_field, d.C, cs);
+        const float target_gain = sqrtf((1.0f / sum) * (float)n);
+        gain[h] = fmaf(target_gain - gain[h], 0.2f, gain[h]);
+        S[h].lx1 = st(state, S_PLL_X1, d.C, cs); S[h].ly1 = st(state, S_PLL_Y1, d.C, cs);
+        S[h].integ = st(state, S_PLL_INT, d.C, cs); S[h].err = st(state, S_PLL_ERR, d.C, cs); S[h].tph = st(state, S_PLL_T, d.C, cs);
+    }
+    const PllConsts kc = make_pll_consts(k);
+    int slow_left = 0, hold = 0, n_replayed = 0, n_general = 0;
+    Chunk16 regs[G];
+#pragma unroll
+    for (int h = 0; h < G; h++) regs[h] = chunk16_load(pilot, n, c0 + h * kWave, d.C, 0);
+    for (int ch = 0; ch < chunks; ch++) {
+#pragma unroll
+        for (int h = 0; h < G; h++) chunk16_store(regs[h], xin[h]);
+        __syncthreads();
+        const int tn = (ch + 1 < chunks ? ch + 1 : ch) * kCh16;
+#pragma unroll
+        for (int h = 0; h < G; h++) regs[h] = chunk16_load(pilot, n, c0 + h * kWave, d.C, tn);
+        bool done = false;
+        if (slow_left == 0) {
+            PllState2 s[NP];
+            bool pre = true;
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                const PllState &a = S[2 * j], &b = S[2 * j + 1];
+                s[j].lx1.x = a.lx1; s[j].lx1.y = b.lx1; s[j].ly1.x = a.ly1; s[j].ly1.y = b.ly1; s[j].integ.x = a.integ; s[j].integ.y = b.integ;
+                s[j].err.x = a.err; s[j].err.y = b.err; s[j].tph.x = a.tph; s[j].tph.y = b.tph;
+                pre = pre && pll_chunk_precheck(a, k) && pll_chunk_precheck(b, k);
+            }
+            Checks2 ck{1.0f, 1.0f, 0.0f, 1.0f, 1.0f};
+            float2 y[G];
+#pragma unroll
+            for (int h = 0; h < G; h++) y[h] = xin[h][lane * kRow16C];
+#pragma unroll 4
+            for (int t = 0; t < kCh16; t++) {
+                const int tn2 = (t + 1 < kCh16 ? t + 1 : t);
+                float2 yn[G];
+#pragma unroll
+                for (int h = 0; h < G; h++) yn[h] = xin[h][lane * kRow16C + tn2];
+#pragma unroll
+                for (int j = 0; j < NP; j++) {
+                    v2f p, q;
+                    p.x = gain[2 * j] * y[2 * j].x; p.y = gain[2 * j + 1] * y[2 * j + 1].x;
+                    q.x = gain[2 * j] * y[2 * j].y; q.y = gain[2 * j + 1] * y[2 * j + 1].y;
+                    const v2f dt = pll_step2(s[j], p, q, kc, ck);
+                    dt_out[2 * j][lane * kRow16F + t] = dt.x; dt_out[2 * j + 1][lane * kRow16F + t] = dt.y;
+                }
+#pragma unroll
+                for (int h = 0; h < G; h++) y[h] = yn[h];
+            }
+            bool ok = pre && (ck.tie_min != 0.0f) && (ck.t_max < 0.4375f) && (ck.t_min >= bits_f32(0x31000000u)) &&
+                      (ck.x_min >= bits_f32(0x38800000u)) && (ck.x_max < 8192.0f);
+#pragma unroll
+            for (int j = 0; j < NP; j++) ok = ok && (fabsf(s[j].integ.x) <= 1.0f) && (fabsf(s[j].integ.y) <= 1.0f);
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+#pragma unroll
+                for (int j = 0; j < NP; j++) {
+                    PllState &a = S[2 * j], &b = S[2 * j + 1];
+                    a.lx1 = s[j].lx1.x; b.lx1 = s[j].lx1.y; a.ly1 = s[j].ly1.x; b.ly1 = s[j].ly1.y; a.integ = s[j].integ.x; b.integ = s[j].integ.y;
+                    a.err = s[j].err.x; b.err = s[j].err.y; a.tph = s[j].tph.x; b.tph = s[j].tph.y;
+                }
+                done = true; hold = 0;
+            } else { slow_left = hold; hold = hold ? (2 * hold < kSlowHoldMax ? 2 * hold : kSlowHoldMax) : 1; n_replayed++; }
+        } else {
+            slow_left--;
+        }
+        if (!done) {
+            n_general++;
+            for (int t = 0; t < kCh16; t++) {
+#pragma unroll
+                for (int h = 0; h < G; h++) {
+                    const float2 yy = xin[h][lane * kRow16C + t];
+                    dt_out[h][lane * kRow16F + t] = pll_step(S[h], gain[h] * yy.x, gain[h] * yy.y, k);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < G; h++) chunk16_flush_f(dt_out[h], pll_dt, n, c0 + h * kWave, d.C, ch * kCh16);
+    }
+#pragma unroll
+    for (int h = 0; h < G; h++) {
+        if (!live[h]) continue;
+        const int c = c0 + h * kWave + lane;
+        st(state, S_AGC_PILOT_GAIN, d.C, c) = gain[h];
+        st(state, S_PLL_X1, d.C, c) = S[h].lx1; st(state, S_PLL_Y1, d.C, c) = S[h].ly1;
+        st(state, S_PLL_INT, d.C, c) = S[h].integ; st(state, S_PLL_ERR, d.C, c) = S[h].err; st(state, S_PLL_T, d.C, c) = S[h].tph;
+    }
+    if (lane == 0 && spec_stats) {
+        atomicAdd(&spec_stats[0], (unsigned long long)(G * chunks));
+        atomicAdd(&spec_stats[1], (unsigned long long)(G * n_general));
+        atomicAdd(&spec_stats[2], (unsigned long long)(G * n_replayed));
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(kWave) void k_pll_multi(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
+                                                  float* __restrict__ state, LoopCoeffs k, int power_field,
+                                                  unsigned long long* __restrict__ spec_stats) {
+    __shared__ __attribute__((aligned(16))) float2 xin[G][kWave * kRow16C];
+    __shared__ __attribute__((aligned(16))) float dt_out[G][kWave * kRow16F];
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x, c0 = blockIdx.x * G * kWave;
+    const int n = d.n_fm_out, chunks = n / kCh16;
+    bool live[G];
+    float gain[G];
+    PllState S[G];
+#pragma unroll
+    for (int h = 0; h < G; h++) {
+        const int c = c0 + h * kWave + lane;
+        live[h] = c < d.C;
+        const int cs = live[h] ? c : d.C - 1;
+        gain[h] = st(state, S_AGC_PILOT_GAIN, d.C, cs);
+        const float sum = st(state, power_field, d.C, cs);
+        const float target_gain = sqrtf((1.0f / sum) * (float)n);
+        gain[h] = fmaf(target_gain - gain[h], 0.2f, gain[h]);
+        S[h].lx1 = st(state, S_PLL_X1, d.C, cs); S[h].ly1 = st(state, S_PLL_Y1, d.C, cs);
+        S[h].integ = st(state, S_PLL_INT, d.C, cs); S[h].err = st(state, S_PLL_ERR, d.C, cs); S[h].tph = st(state, S_PLL_T, d.C, cs);
+    }
+    const PllConsts kc = make_pll_consts(k);
+    int slow_left = 0, hold = 0, n_replayed = 0, n_general = 0;
+    Chunk16 regs[G];
+#pragma unroll
+    for (int h = 0; h < G; h++) regs[h] = chunk16_load(pilot, n, c0 + h * kWave, d.C, 0);
+    for (int ch = 0; ch < chunks; ch++) {
+#pragma unroll
+        for (int h = 0; h < G; h++) chunk16_store(regs[h], xin[h]);
+        __syncthreads();
+        const int tn = (ch + 1 < chunks ? ch + 1 : ch) * kCh16;
+#pragma unroll
+        for (int h = 0; h < G; h++) regs[h] = chunk16_load(pilot, n, c0 + h * kWave, d.C, tn);
+        bool done = false;
+        if (slow_left == 0) {
+            PllState s[G];
+            bool pre = true;
+#pragma unroll
+            for (int h = 0; h < G; h++) { s[h] = S[h]; pre = pre && pll_chunk_precheck(S[h], k); }
+            PllChecks ck{1.0f, 0u};
+            float2 y[G];
+#pragma unroll
+            for (int h = 0; h < G; h++) y[h] = xin[h][lane * kRow16C];
+#pragma unroll 4
+            for (int t = 0; t < kCh16; t++) {
+                const int tn2 = (t + 1 < kCh16 ? t + 1 : t);
+                float2 yn[G];
+#pragma unroll
+                for (int h = 0; h < G; h++) yn[h] = xin[h][lane * kRow16C + tn2];
+#pragma unroll
+                for (int h = 0; h < G; h++) dt_out[h][lane * kRow16F + t] = pll_step_locked(s[h], gain[h] * y[h].x, gain[h] * y[h].y, kc, ck);
+#pragma unroll
+                for (int h = 0; h < G; h++) y[h] = yn[h];
+            }
+            const bool ok = pre && (ck.tie_min != 0.0f) && (ck.range_max < kRangeWindow);
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+#pragma unroll
+                for (int h = 0; h < G; h++) S[h] = s[h];
+                done = true; hold = 0;
+            } else { slow_left = hold; hold = hold ? (2 * hold < kSlowHoldMax ? 2 * hold : kSlowHoldMax) : 1; n_replayed++; }
+        } else {
+            slow_left--;
+        }
+        if (!done) {
+            n_general++;
+            for (int t = 0; t < kCh16; t++) {
+#pragma unroll
+                for (int h = 0; h < G; h++) {
+                    const float2 yy = xin[h][lane * kRow16C + t];
+                    dt_out[h][lane * kRow16F + t] = pll_step(S[h], gain[h] * yy.x, gain[h] * yy.y, k);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < G; h++) chunk16_flush_f(dt_out[h], pll_dt, n, c0 + h * kWave, d.C, ch * kCh16);
+    }
+#pragma unroll
+    for (int h = 0; h < G; h++) {
+        if (!live[h]) continue;
+        const int c = c0 + h * kWave + lane;
+        st(state, S_AGC_PILOT_GAIN, d.C, c) = gain[h];
+        st(state, S_PLL_X1, d.C, c) = S[h].lx1; st(state, S_PLL_Y1, d.C, c) = S[h].ly1;
+        st(state, S_PLL_INT, d.C, c) = S[h].integ; st(state, S_PLL_ERR, d.C, c) = S[h].err; st(state, S_PLL_T, d.C, c) = S[h].tph;
+    }
+    if (lane == 0 && spec_stats) {
+        atomicAdd(&spec_stats[0], (unsigned long long)(G * chunks));
+        atomicAdd(&spec_stats[1], (unsigned long long)(G * n_general));
+        atomicAdd(&spec_stats[2], (unsigned long long)(G * n_replayed));
+    }
+}
+
+__global__ void k_spin_valu(float* out, int iters) {   // dense independent FMAs, no memory
+    float a = threadIdx.x * 1e-3f, b = 1.0f, c = 2.0f, e = 3.0f;
+    for (int i = 0; i < iters; i++) { a = fmaf(a, 0.999f, 0.1f); b = fmaf(b, 0.999f, 0.1f); c = fmaf(c, 0.999f, 0.1f); e = fmaf(e, 0.999f, 0.1f); }
+    if (a + b + c + e == 12345.0f) out[0] = a;
+}
+__global__ void k_stream_copy(const float4* __restrict__ in, float4* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
 template <typename T> static T* dalloc(size_t n) { T* p; hipMalloc(&p, n * sizeof(T)); hipMemset(p, 0, n * sizeof(T)); return p; }
 
 int main(int argc, char** argv) {
@@ -246,10 +563,10 @@ int main(int argc, char** argv) {
             if (b == blocks - 3) hipMemset(stats, 0, 64);
             hipEventRecord(e0, nullptr);
             const dim3 g((C + 63) / 64), t(64);
-            if (v == 0) hipLaunchKernelGGL(k_pilot_pll, g, t, 0, nullptr, d, pilot, dt[v], state, k, (int)S_PILOT_POWER0, stats);
-            if (v == 1) hipLaunchKernelGGL(k_pll_variant<1>, g, t, 0, nullptr, d, pilot, dt[v], state, k, (int)S_PILOT_POWER0, stats);
-            if (v == 2) hipLaunchKernelGGL(k_pll_variant<2>, g, t, 0, nullptr, d, pilot, dt[v], state, k, (int)S_PILOT_POWER0, stats);
-            if (v == 3) hipLaunchKernelGGL(k_pll_variant<3>, g, t, 0, nullptr, d, pilot, dt[v], state, k, (int)S_PILOT_POWER0, stats);
+            if (v == 0) hipLaunchKernelGGL(k_pilot_pll, g, dim3(128), 0, nullptr, d, pilot, dt[v], state, k, (int)S_PILOT_POWER0, stats);
+            if (v == 1) hipLaunchKernelGGL(k_pll_multi<1>, g, t, 0, nullptr, d, pilot, dt[v], state, k, (int)S_PILOT_POWER0, stats);
+            if (v == 2) hipLaunchKernelGGL(k_pll_multi<2>, dim3((C + 127) / 128), t, 0, nullptr, d, pilot, dt[v], state, k, (int)S_PILOT_POWER0, stats);
+            if (v == 3) hipLaunchKernelGGL(k_pll_multi<3>, dim3((C + 191) / 192), t, 0, nullptr, d, pilot, dt[v], state, k, (int)S_PILOT_POWER0, stats);
             hipEventRecord(e1, nullptr); hipEventSynchronize(e1);
             hipEventElapsedTime(&last_ms, e0, e1);
             if (b == 0 || b >= blocks - 2) printf("variant %d block %2d: %.3f ms\n", v, b, last_ms);
@@ -260,6 +577,33 @@ int main(int argc, char** argv) {
         size_t diff = 0; for (size_t i = 0; i < out.size(); i++) diff += memcmp(&out[i], &ref[i], 4) != 0;
         printf("variant %d: last-3-block chunks %llu general %llu replayed %llu; dt mismatches vs variant 0: %zu\n", v, hs[0], hs[1], hs[2], diff);
         hipFree(state);
+    }
+    // the production kernel beside (a) nothing (b) a dense-VALU kernel (c) an HBM streaming copy
+    {
+        float* state = dalloc<float>((size_t)S_NUM_FIELDS * C);
+        LaunchCtx ctx{}; ctx.d = d; ctx.b.state = state;
+        launch_reset_state(ctx, nullptr);
+        std::vector<float> pw(C);
+        for (int c = 0; c < C; c++) { double s2 = 0; for (int i = 0; i < n; i++) { const float2 y = hp[(size_t)c * n + i]; s2 += (double)y.x * y.x + (double)y.y * y.y; } pw[c] = (float)s2; }
+        hipMemcpy(state + (size_t)S_PILOT_POWER0 * C, pw.data(), C * 4, hipMemcpyHostToDevice);
+        for (int b = 0; b < 10; b++) hipLaunchKernelGGL(k_pilot_pll, dim3((C + 63) / 64), dim3(128), 0, nullptr, d, pilot, dt[0], state, k, (int)S_PILOT_POWER0, stats);
+        hipDeviceSynchronize();
+        hipStream_t s1, s2; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+        const size_t nb = (size_t)64 << 20;   // 64 Mi float4 = 1 GiB
+        float4* ca = dalloc<float4>(nb); float4* cb = dalloc<float4>(nb);
+        const char* names[3] = {"alone", "dense VALU beside", "HBM copy beside"};
+        for (int mode = 0; mode < 3; mode++) {
+            hipMemset(stats, 0, 64); hipDeviceSynchronize();
+            if (mode == 1) for (int i = 0; i < 6; i++) hipLaunchKernelGGL(k_spin_valu, dim3(2048), dim3(256), 0, s2, dt[1], 40000);
+            if (mode == 2) for (int i = 0; i < 6; i++) hipLaunchKernelGGL(k_stream_copy, dim3(4096), dim3(256), 0, s2, ca, cb, nb);
+            hipEventRecord(e0, s1);
+            hipLaunchKernelGGL(k_pilot_pll, dim3((C + 63) / 64), dim3(128), 0, s1, d, pilot, dt[0], state, k, (int)S_PILOT_POWER0, stats);
+            hipEventRecord(e1, s1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            hipDeviceSynchronize();
+            unsigned long long hs[8]; hipMemcpy(hs, stats, 64, hipMemcpyDeviceToHost);
+            printf("k_pilot_pll %-18s: %.3f ms, %llu cycles, clock %.0f MHz, general chunks %llu; phases store %llu compute %llu flush %llu\n", names[mode], ms, hs[6], (double)hs[6] / (double)hs[7] * 100.0, hs[1], hs[3], hs[4], hs[5]);
+        }
     }
     return 0;
 }

@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
 #endif
     b.rds = dalloc<float2>((size_t)C * d.n_rds); b.lmr_est = dalloc<float>((size_t)C * d.n_est);
     b.b_lpr = dalloc<float>((size_t)C * 128); b.b_lmr = dalloc<float>((size_t)C * 128); b.deemph = dalloc<float>((size_t)C * 4); b.mix = dalloc<float>((size_t)C * 2);
-    b.state = dalloc<float>((size_t)S_NUM_FIELDS * C);
+    b.state = dalloc<float>((size_t)S_NUM_FIELDS * C); b.spec_stats = dalloc<unsigned long long>(8);
     {
         std::vector<float> t((size_t)C * 128); for (size_t i = 0; i < t.size(); i++) t[i] = 0.01f * (float)((i % 128) - 60) / 64.f;
         hipMemcpy(b.b_lpr, t.data(), t.size() * 4, hipMemcpyHostToDevice); hipMemcpy(b.b_lmr, t.data(), t.size() * 4, hipMemcpyHostToDevice);
@@ -55,15 +55,16 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     struct { const char* name; int id; } stages[] = {{"k_front", 0}, {"k_pilot_power", 1}, {"k_pilot_pll", 2}, {"k_extract", 3}, {"k_rds_sync", 4}};
-    auto run = [&](int id, int slot) {
+    auto run_on = [&](int id, int slot, hipStream_t st) {
         switch (id) {
-            case 0: launch_stage_front(ctx, slot, in, false, nullptr); break;
-            case 1: launch_stage_power(ctx, slot, nullptr); break;
-            case 2: launch_stage_pll(ctx, slot, nullptr); break;
-            case 3: launch_stage_extract(ctx, slot, nullptr); break;
-            default: launch_stage_rds(ctx, slot, nullptr); break;
+            case 0: launch_stage_front(ctx, slot, in, false, st); break;
+            case 1: launch_stage_power(ctx, slot, st); break;
+            case 2: launch_stage_pll(ctx, slot, st); break;
+            case 3: launch_stage_extract(ctx, slot, st); break;
+            default: launch_stage_rds(ctx, slot, st); break;
         }
     };
+    auto run = [&](int id, int slot) { run_on(id, slot, nullptr); };
     // one full pass so every stage sees realistic data
     for (int w = 0; w < 2; w++) for (auto& s : stages) run(s.id, w & 1);
     hipDeviceSynchronize();
@@ -73,6 +74,24 @@ int main(int argc, char** argv) {
         hipEventRecord(e1, nullptr); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("%-14s C=%d m=%d: %.3f ms\n", s.name, C, m, ms / iters);
+        if (s.id == 2) { unsigned long long hs[8]; hipMemcpy(hs, b.spec_stats, 64, hipMemcpyDeviceToHost); printf("   alone: cycle counter %llu, realtime ticks %llu -> %.1f MHz if 100 MHz ticks\n", hs[6], hs[7], (double)hs[6] / (double)hs[7] * 100.0); }
+    }
+    // how much does each stage slow the PLL when it runs concurrently (second stream, back-to-back launches)?
+    if (argc > 4) {
+        hipStream_t s1, s2; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+        hipDeviceSynchronize();
+        for (auto& co : stages) {
+            if (co.id == 2) continue;
+            hipEventRecord(e0, s1);
+            run_on(2, 0, s1);
+            hipEventRecord(e1, s1);
+            for (int it = 0; it < 12; it++) run_on(co.id, 1, s2);
+            hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            hipDeviceSynchronize();
+            unsigned long long hs[8]; hipMemcpy(hs, b.spec_stats, 64, hipMemcpyDeviceToHost);
+            printf("k_pilot_pll with %-14s running beside it: %.3f ms  (cycle counter %llu, realtime ticks %llu -> %.1f MHz if 100 MHz ticks)\n", co.name, ms, hs[6], hs[7], (double)hs[6] / (double)hs[7] * 100.0);
+        }
     }
     return 0;
 }
