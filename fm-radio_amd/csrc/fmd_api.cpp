@@ -42,10 +42,10 @@ struct fmd_handle_s {
     hipStream_t own_stream = nullptr;        // host-pointer entry points, uploads, resets
     hipStream_t last_stream = nullptr;
     hipStream_t sF = nullptr, sA = nullptr, sB = nullptr, sX = nullptr;
-    hipEvent_t ev_in = nullptr, ev_F[2] = {}, ev_A[2] = {}, ev_B[2] = {}, ev_X[2] = {};
-    bool slot_used[2] = {false, false};
+    hipEvent_t ev_in = nullptr, ev_F[kSlots] = {}, ev_A[kSlots] = {}, ev_B[kSlots] = {}, ev_X[kSlots] = {};
+    bool slot_used[kSlots] = {};
     bool pipelined = true;
-    long n_blocks = 0;                       // blocks submitted since create/reset; slot = n_blocks & 1
+    long n_blocks = 0;                       // blocks submitted since create/reset; slot = n_blocks % kSlots
     int out_slot = 0;                        // slot holding the newest block's outputs
     int device = 0;
     int bytes_cap = 0;
@@ -162,14 +162,14 @@ int zero_history(fmd_handle h, hipStream_t s) {
         HIP_TRY(h, hipMemsetAsync(b.dt_tail[p], 0, sizeof(float) * (size_t)d.C * 128, s));
         HIP_TRY(h, hipMemsetAsync(b.fo_tail[p], 0, sizeof(float) * (size_t)d.C * 64, s));
     }
-    for (int p = 0; p < 2; p++) {
+    for (int p = 0; p < kSlots; p++) {
         HIP_TRY(h, hipMemsetAsync(b.rds_count[p], 0, sizeof(int) * (size_t)d.C, s));
         HIP_TRY(h, hipMemsetAsync(b.rds_bytes_count[p], 0, sizeof(int) * (size_t)d.C, s));
     }
     HIP_TRY(h, launch_reset_state(h->ctx, s));
     h->n_blocks = 0;
     h->out_slot = 0;
-    h->slot_used[0] = h->slot_used[1] = false;
+    for (bool& u : h->slot_used) u = false;
     return FMD_OK;
 }
 
@@ -193,7 +193,8 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         if (!rc) rc = upload_controls(h, h->own_stream);
         if (rc) return rc;
     }
-    const int slot = (int)(h->n_blocks & 1);
+    const int slot = (int)(h->n_blocks % kSlots);
+    const SlotRef ref{slot, (int)(h->n_blocks & 1)};
     const bool u8 = sizeof(InT) == 2;
     const bool pipe = h->pipelined;
     hipStream_t sF = pipe ? h->sF : s, sA = pipe ? h->sA : s, sB = pipe ? h->sB : s, sX = pipe ? h->sX : s;
@@ -203,9 +204,9 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         for (int i = 0; i < ST_COUNT; i++) { pm->used[i] = false; HIP_TRY(h, hipEventCreate(&pm->t0[i])); HIP_TRY(h, hipEventCreate(&pm->t1[i])); }
         h->marks.push_back(pm);
     }
-    auto run = [&](Stage st, hipStream_t on, hipError_t (*fn)(const LaunchCtx&, int, hipStream_t)) -> hipError_t {
+    auto run = [&](Stage st, hipStream_t on, hipError_t (*fn)(const LaunchCtx&, SlotRef, hipStream_t)) -> hipError_t {
         if (pm) { (void)hipEventRecord(pm->t0[st], on); pm->used[st] = true; }
-        hipError_t e = fn(h->ctx, slot, on);
+        hipError_t e = fn(h->ctx, ref, on);
         if (pm) (void)hipEventRecord(pm->t1[st], on);
         return e;
     };
@@ -214,11 +215,11 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         // input is ready once everything queued so far on the caller's stream has run
         HIP_TRY(h, hipEventRecord(h->ev_in, s));
         HIP_TRY(h, hipStreamWaitEvent(sF, h->ev_in, 0));
-        // WAR: this slot's fm_out_iq / pll_dt were last read by the extract stage two blocks ago
+        // WAR: this slot's fm_out_iq / pilot / pll_dt were last read by the stages of the block kSlots blocks ago
         if (h->slot_used[slot]) HIP_TRY(h, hipStreamWaitEvent(sF, h->ev_X[slot], 0));
     }
     if (pm) { (void)hipEventRecord(pm->t0[ST_FRONT], sF); pm->used[ST_FRONT] = true; }
-    e = launch_stage_front(h->ctx, slot, d_iq, u8, sF);
+    e = launch_stage_front(h->ctx, ref, d_iq, u8, sF);
     if (pm) (void)hipEventRecord(pm->t1[ST_FRONT], sF);
     if (e != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_front launch: %s", hipGetErrorString(e));
     if (h->ctx.any_deemph && (e = run(ST_DEEMPH, sF, launch_stage_deemph)) != hipSuccess)
@@ -350,7 +351,8 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
         if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e)));
     }
     {
-        hipEvent_t* evs[] = {&h->ev_in, &h->ev_F[0], &h->ev_F[1], &h->ev_A[0], &h->ev_A[1], &h->ev_B[0], &h->ev_B[1], &h->ev_X[0], &h->ev_X[1]};
+        std::vector<hipEvent_t*> evs = {&h->ev_in};
+        for (int i = 0; i < kSlots; i++) { evs.push_back(&h->ev_F[i]); evs.push_back(&h->ev_A[i]); evs.push_back(&h->ev_B[i]); evs.push_back(&h->ev_X[i]); }
         for (hipEvent_t* ev : evs) {
             hipError_t e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
             if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "event: %s", hipGetErrorString(e)));
@@ -380,7 +382,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
         if (!rc) rc = dev_alloc(h, &b.dt_tail[p], C * 128);
         if (!rc) rc = dev_alloc(h, &b.fo_tail[p], C * 64);
     }
-    for (int p = 0; p < 2 && !rc; p++) {
+    for (int p = 0; p < kSlots && !rc; p++) {
         rc = dev_alloc(h, &b.fm_out_iq[p], C * d.n_fm_out);
         if (!rc) rc = dev_alloc(h, &b.fm_out[p], C * d.n_fm_out);
         if (!rc) rc = dev_alloc(h, &b.pilot[p], C * d.n_fm_out);
@@ -418,7 +420,8 @@ int fmd_destroy(fmd_handle h) {
     free_marks(h);
     for (hipStream_t st : {h->sF, h->sA, h->sB, h->sX}) if (st) (void)hipStreamDestroy(st);
     {
-        hipEvent_t evs[] = {h->ev_in, h->ev_F[0], h->ev_F[1], h->ev_A[0], h->ev_A[1], h->ev_B[0], h->ev_B[1], h->ev_X[0], h->ev_X[1]};
+        std::vector<hipEvent_t> evs = {h->ev_in};
+        for (int i = 0; i < kSlots; i++) { evs.push_back(h->ev_F[i]); evs.push_back(h->ev_A[i]); evs.push_back(h->ev_B[i]); evs.push_back(h->ev_X[i]); }
         for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     }
     for (void* p : h->allocs) (void)hipFree(p);

@@ -31,7 +31,7 @@ struct LoopCoeffs {
 enum StateField : int {
     // pilot peak IIR
     SA_X1R, SA_X1I, SA_X2R, SA_X2I, SA_Y1R, SA_Y1I, SA_Y2R, SA_Y2I,
-    S_PILOT_POWER0, S_PILOT_POWER1, // sum |pilot|^2 of the block in pipeline slot 0 / 1 (power pass -> PLL pass)
+    S_PILOT_POWER0, S_PILOT_POWER1, S_PILOT_POWER2, // sum |pilot|^2 of the block in pipeline slot 0 / 1 / 2 (power pass -> PLL pass)
     S_AGC_PILOT_GAIN,
     S_PLL_X1, S_PLL_Y1, S_PLL_INT, S_PLL_ERR, S_PLL_T,
     S_LMR_PHASE_CUR, S_LMR_PHASE_PREV,
@@ -55,30 +55,33 @@ struct Dims {
     int tail_base;  // baseband (m>1) or fm_in (m==1) samples of history kept per channel
 };
 
-// Buffers indexed [2] are ping-pong by pipeline slot (= block index & 1): the stages of consecutive blocks run
-// concurrently on different streams, so a producer of block b+1 must not overwrite what a consumer of block b reads.
+// Stream buffers are indexed by pipeline slot (= block index % kSlots): the stages of consecutive blocks run concurrently
+// on different streams, so a producer of block b+1 must not overwrite what a consumer of block b (or b-1) still reads.
+// Three slots let the front end of block b+1 start while extract/RDS of block b-1 are still running.
+static constexpr int kSlots = 3;
+struct SlotRef { int buf; int par; };   // buf = block % kSlots (stream buffers), par = block & 1 (history tails)
 struct Buffers {
-    // history tails: stage of block b reads [slot], writes [slot^1]
+    // history tails: stage of block b reads [par], writes [par^1] (producer and consumer are the same stage, same stream)
     float2* base_tail[2];   // [C][tail_base]
     float2* iq_tail[2];     // [C][128]   last fm_out_iq samples of the previous block
     float*  dt_tail[2];     // [C][128]   last pll_dt samples of the previous block
     float*  fo_tail[2];     // [C][64]    last fm_out samples (Hilbert FIR history, de-emphasis path)
     // intermediate streams
-    float2* fm_out_iq[2];   // [C][n_fm_out]
-    float*  fm_out[2];      // [C][n_fm_out]  (de-emphasis path only)
-    float2* pilot[2];       // [C][n_fm_out]  pilot peak IIR output before AGC (k_pilot_power -> k_pilot_pll)
-    float*  pll_dt[2];      // [C][n_fm_out]
+    float2* fm_out_iq[kSlots];   // [C][n_fm_out]
+    float*  fm_out[kSlots];      // [C][n_fm_out]  (de-emphasis path only)
+    float2* pilot[kSlots];       // [C][n_fm_out]  pilot peak IIR output before AGC (k_pilot_power -> k_pilot_pll)
+    float*  pll_dt[kSlots];      // [C][n_fm_out]
     float2* rds;            // [C][n_rds]      (extract -> rds_sync, same stream)
     float*  lmr_est;        // [C][n_est]
     // outputs
-    float*  audio[2];       // [C][n_audio][2]
-    float*  rds_sym[2];     // [C][n_rds]
-    float2* rds_raw_sym[2]; // [C][n_rds]      (KEEP_TAPS)
-    int*    rds_count[2];   // [C]
-    float*  lpr[2];         // [C][n_audio]    (KEEP_TAPS)
-    float*  lmr[2];         // [C][n_audio]    (KEEP_TAPS)
-    uint8_t* rds_bytes[2];  // [C][bytes_cap]
-    int*    rds_bytes_count[2]; // [C]
+    float*  audio[kSlots];       // [C][n_audio][2]
+    float*  rds_sym[kSlots];     // [C][n_rds]
+    float2* rds_raw_sym[kSlots]; // [C][n_rds]      (KEEP_TAPS)
+    int*    rds_count[kSlots];   // [C]
+    float*  lpr[kSlots];         // [C][n_audio]    (KEEP_TAPS)
+    float*  lmr[kSlots];         // [C][n_audio]    (KEEP_TAPS)
+    uint8_t* rds_bytes[kSlots];  // [C][bytes_cap]
+    int*    rds_bytes_count[kSlots]; // [C]
     // per-channel controls
     float*  b_lpr;          // [C][128]
     float*  b_lmr;          // [C][128]
@@ -99,14 +102,14 @@ struct LaunchCtx {
     int bytes_cap;
 };
 
-// One launcher per pipeline stage of one block; `slot` = block index & 1.  The host (fmd_api.cpp) places the stages on
+// One launcher per pipeline stage of one block.  The host (fmd_api.cpp) places the stages on
 // streams and orders them with events.
-hipError_t launch_stage_front(const LaunchCtx& ctx, int slot, const void* d_iq, bool u8, hipStream_t s);   // k_front
-hipError_t launch_stage_deemph(const LaunchCtx& ctx, int slot, hipStream_t s);                            // k_deemphasis + k_hilbert
-hipError_t launch_stage_power(const LaunchCtx& ctx, int slot, hipStream_t s);                             // k_pilot_power
-hipError_t launch_stage_pll(const LaunchCtx& ctx, int slot, hipStream_t s);                               // k_pilot_pll
-hipError_t launch_stage_extract(const LaunchCtx& ctx, int slot, hipStream_t s);                           // k_extract
-hipError_t launch_stage_rds(const LaunchCtx& ctx, int slot, hipStream_t s);                               // k_rds_sync
+hipError_t launch_stage_front(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s);   // k_front
+hipError_t launch_stage_deemph(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                            // k_deemphasis + k_hilbert
+hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                             // k_pilot_power
+hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                               // k_pilot_pll
+hipError_t launch_stage_extract(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                           // k_extract
+hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                               // k_rds_sync
 hipError_t launch_reset_state(const LaunchCtx& ctx, hipStream_t stream);
 hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, unsigned char* d_ok, size_t n, hipStream_t s);
 hipError_t prepare_kernels();          // one-time function attributes (dynamic LDS sizes)

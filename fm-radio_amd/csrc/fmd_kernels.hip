@@ -1027,72 +1027,72 @@ __global__ void k_reset(Dims d, float* __restrict__ state) {
 // host-side stage launchers
 // ---------------------------------------------------------------------------------------------
 template <int M, typename InT>
-static hipError_t launch_front(const LaunchCtx& ctx, int slot, const InT* d_iq, hipStream_t s) {
+static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq, hipStream_t s) {
     using G = FrontGeom<M>;
     const Dims& d = ctx.d;
     const int tiles = d.n_fm_out / G::T;
     const size_t lds = sizeof(float) * G::LDS_FLOATS;
     auto kern = k_front<M, InT>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * d.C)), dim3(256), lds, s, d, d_iq, ctx.b.base_tail[slot], ctx.b.base_tail[slot ^ 1],
-                       ctx.b.fm_out_iq[slot], ctx.b.fm_out[slot], ctx.b.fo_tail[slot ^ 1], ctx.front, ctx.any_deemph);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * d.C)), dim3(256), lds, s, d, d_iq, ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1],
+                       ctx.b.fm_out_iq[r.buf], ctx.b.fm_out[r.buf], ctx.b.fo_tail[r.par ^ 1], ctx.front, ctx.any_deemph);
     return hipGetLastError();
 }
 
-hipError_t launch_stage_front(const LaunchCtx& ctx, int slot, const void* d_iq, bool u8, hipStream_t s) {
+hipError_t launch_stage_front(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s) {
     const int m = ctx.d.m;
     if (u8) {
         const uchar2* p = static_cast<const uchar2*>(d_iq);
-        return m == 1 ? launch_front<1, uchar2>(ctx, slot, p, s) : (m == 4 ? launch_front<4, uchar2>(ctx, slot, p, s) : launch_front<8, uchar2>(ctx, slot, p, s));
+        return m == 1 ? launch_front<1, uchar2>(ctx, r, p, s) : (m == 4 ? launch_front<4, uchar2>(ctx, r, p, s) : launch_front<8, uchar2>(ctx, r, p, s));
     }
     const float2* p = static_cast<const float2*>(d_iq);
-    return m == 1 ? launch_front<1, float2>(ctx, slot, p, s) : (m == 4 ? launch_front<4, float2>(ctx, slot, p, s) : launch_front<8, float2>(ctx, slot, p, s));
+    return m == 1 ? launch_front<1, float2>(ctx, r, p, s) : (m == 4 ? launch_front<4, float2>(ctx, r, p, s) : launch_front<8, float2>(ctx, r, p, s));
 }
 
 static unsigned serial_waves(const Dims& d) { return (unsigned)((d.C + kWave - 1) / kWave); }
 
-hipError_t launch_stage_deemph(const LaunchCtx& ctx, int slot, hipStream_t s) {
+hipError_t launch_stage_deemph(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
-    hipLaunchKernelGGL(k_deemphasis, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.fm_out[slot], b.deemph, b.state);
-    hipLaunchKernelGGL(k_hilbert, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, b.fm_out[slot], b.fo_tail[slot],
-                       b.fo_tail[slot ^ 1], b.fm_out_iq[slot], ctx.front);
+    hipLaunchKernelGGL(k_deemphasis, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.fm_out[r.buf], b.deemph, b.state);
+    hipLaunchKernelGGL(k_hilbert, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, b.fm_out[r.buf], b.fo_tail[r.par],
+                       b.fo_tail[r.par ^ 1], b.fm_out_iq[r.buf], ctx.front);
     return hipGetLastError();
 }
 
-hipError_t launch_stage_power(const LaunchCtx& ctx, int slot, hipStream_t s) {
+hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
-    hipLaunchKernelGGL(k_pilot_power, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[slot], ctx.b.pilot[slot], ctx.b.state,
-                       ctx.loops, slot ? (int)S_PILOT_POWER1 : (int)S_PILOT_POWER0);
+    hipLaunchKernelGGL(k_pilot_power, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[r.buf], ctx.b.pilot[r.buf], ctx.b.state,
+                       ctx.loops, (int)S_PILOT_POWER0 + r.buf);
     return hipGetLastError();
 }
 
-hipError_t launch_stage_pll(const LaunchCtx& ctx, int slot, hipStream_t s) {
+hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
-    hipLaunchKernelGGL(k_pilot_pll, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, ctx.b.pilot[slot], ctx.b.pll_dt[slot], ctx.b.state,
-                       ctx.loops, slot ? (int)S_PILOT_POWER1 : (int)S_PILOT_POWER0, ctx.b.spec_stats);
+    hipLaunchKernelGGL(k_pilot_pll, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
+                       ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
     return hipGetLastError();
 }
 
 template <int TA>
-static void launch_extract_ta(const LaunchCtx& ctx, int slot, hipStream_t s) {
+static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
-    hipLaunchKernelGGL(k_extract<TA>, dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fm_out_iq[slot], b.pll_dt[slot],
-                       b.iq_tail[slot], b.dt_tail[slot], b.iq_tail[slot ^ 1], b.dt_tail[slot ^ 1], b.b_lpr, b.b_lmr, ctx.rds_taps, b.mix,
-                       b.state, b.audio[slot], b.rds, b.lmr_est, b.lpr[slot], b.lmr[slot], ctx.keep_taps);
+    hipLaunchKernelGGL(k_extract<TA>, dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fm_out_iq[r.buf], b.pll_dt[r.buf],
+                       b.iq_tail[r.par], b.dt_tail[r.par], b.iq_tail[r.par ^ 1], b.dt_tail[r.par ^ 1], b.b_lpr, b.b_lmr, ctx.rds_taps, b.mix,
+                       b.state, b.audio[r.buf], b.rds, b.lmr_est, b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps);
 }
 
-hipError_t launch_stage_extract(const LaunchCtx& ctx, int slot, hipStream_t s) {
-    if (ctx.d.n_audio % 256 == 0) launch_extract_ta<256>(ctx, slot, s);
-    else launch_extract_ta<128>(ctx, slot, s);
+hipError_t launch_stage_extract(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
+    if (ctx.d.n_audio % 256 == 0) launch_extract_ta<256>(ctx, r, s);
+    else launch_extract_ta<128>(ctx, r, s);
     return hipGetLastError();
 }
 
-hipError_t launch_stage_rds(const LaunchCtx& ctx, int slot, hipStream_t s) {
+hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
-    hipLaunchKernelGGL(k_rds_sync, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.rds, b.lmr_est, b.state, ctx.loops, b.rds_sym[slot],
-                       b.rds_raw_sym[slot], b.rds_count[slot], b.rds_bytes[slot], b.rds_bytes_count[slot], ctx.bytes_cap, ctx.keep_taps);
+    hipLaunchKernelGGL(k_rds_sync, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.rds, b.lmr_est, b.state, ctx.loops, b.rds_sym[r.buf],
+                       b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps);
     return hipGetLastError();
 }
 

@@ -110,7 +110,7 @@ int fmd_get_coeffs(fmd_handle h, int channel, fmd_coeffs* k);
  * *_dev: `d_iq` is a DEVICE pointer.  The call returns without synchronising.  The block is read after everything
  * already queued on `stream` (hipStream_t, NULL = default stream), and work queued on `stream` AFTER the call is
  * ordered behind the library's last read of `d_iq`, so the buffer may be refilled in stream order.  The stages of
- * the block run on the library's own streams and overlap with the neighbouring blocks' stages (two blocks in
+ * the block run on the library's own streams and overlap with the neighbouring blocks' stages (up to three blocks in
  * flight); outputs become readable after fmd_synchronize / fmd_wait_outputs and stay valid until the second
  * next fmd_process_* call.  *_host: `iq` is a host pointer; copies, runs, synchronises. */
 int fmd_process_cf32_dev(fmd_handle h, const float* d_iq, int n_channels, int n_samples, void* stream);

@@ -57,11 +57,11 @@ int main(int argc, char** argv) {
     struct { const char* name; int id; } stages[] = {{"k_front", 0}, {"k_pilot_power", 1}, {"k_pilot_pll", 2}, {"k_extract", 3}, {"k_rds_sync", 4}};
     auto run_on = [&](int id, int slot, hipStream_t st) {
         switch (id) {
-            case 0: launch_stage_front(ctx, slot, in, false, st); break;
-            case 1: launch_stage_power(ctx, slot, st); break;
-            case 2: launch_stage_pll(ctx, slot, st); break;
-            case 3: launch_stage_extract(ctx, slot, st); break;
-            default: launch_stage_rds(ctx, slot, st); break;
+            case 0: launch_stage_front(ctx, SlotRef{slot, slot}, in, false, st); break;
+            case 1: launch_stage_power(ctx, SlotRef{slot, slot}, st); break;
+            case 2: launch_stage_pll(ctx, SlotRef{slot, slot}, st); break;
+            case 3: launch_stage_extract(ctx, SlotRef{slot, slot}, st); break;
+            default: launch_stage_rds(ctx, SlotRef{slot, slot}, st); break;
         }
     };
     auto run = [&](int id, int slot) { run_on(id, slot, nullptr); };
