@@ -148,6 +148,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preroll", type=int, default=16, help="blocks demodulated before the warmup so the loops are in lock "
+                    "(a receiver's steady state; 16 blocks = 1 s of signal).  Untimed, like the warmup")
     ap.add_argument("--channels", type=int, default=4096, help="channels PER GPU (BASELINE configs[2]: 4096)")
     ap.add_argument("--fs", type=int, default=256000, choices=[256000, 1024000, 2048000])
     ap.add_argument("--block", type=int, default=0, help="baseband samples per channel per step (default: 64 ms)")
@@ -187,8 +189,8 @@ def main() -> None:
     fs = args.fs
     block = args.block or (fs * 64 // 1000)
     C = args.channels
-    K, W = args.steps, args.warmup
-    n_blocks_resident = min(K + W, 8)  # distinct consecutive blocks kept in HBM, cycled
+    K, W, P = args.steps, args.warmup, max(args.preroll, 0)
+    n_blocks_resident = min(K + W + P, 8)  # distinct consecutive blocks kept in HBM, cycled
     x = synth_block_device(torch, C, n_blocks_resident * block, float(fs), 1234 + rank, device, args.u8)
     x = x.view(C, n_blocks_resident, block, 2).permute(1, 0, 2, 3).contiguous()  # [blocks][C][N][2]
     dm = pkg.BatchDemod(C, block, fs, device=local_rank, pipelined=not args.no_pipeline)
@@ -212,7 +214,7 @@ def main() -> None:
             gstream.synchronize()
         dm.synchronize()
 
-    for k in range(W):
+    for k in range(P + W):   # pre-roll (pilot PLL / RDS loops acquire lock) then the W warmup steps; consecutive signal
         step(k)
     drain()
     torch.cuda.synchronize(device)
@@ -222,7 +224,7 @@ def main() -> None:
     dm.profile(not args.no_kernel_times)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    for k in range(W, W + K):
+    for k in range(P + W, P + W + K):
         step(k)
     drain()
     torch.cuda.synchronize(device)
@@ -280,6 +282,7 @@ def main() -> None:
         "config": {"workload": f"BASELINE configs[2]: {C} synthetic FM channels/GPU @ {fs} Sa/s, {block}-sample blocks, "
                                f"{'u8' if args.u8 else 'cf32'} IQ resident in HBM, full stereo + pilot PLL + RDS",
                    "channels_per_gpu": C, "fs_baseband": fs, "block_size": block, "ingest": "u8" if args.u8 else "cf32",
+                   "preroll_blocks": P,
                    "parallelism": f"channel-sharded x{world}" + (", per-step audio all-gather (RCCL)" if do_gather else "")},
         "channels_at_realtime": value * 1e6 / fs,
         "msa_per_gpu": value / world,

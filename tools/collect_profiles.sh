@@ -1,0 +1,14 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun) from the repo root: kernel-trace statistics of the default bench command plus the two
+# HBM-traffic counter passes (separate --pmc runs, no tracing domains combined with them).  Outputs under gpurun_out/prof/.
+set -u
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/prof
+rm -rf $O && mkdir -p $O
+cd $R
+python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 4 --warmup 1 --preroll 16 --no-cpu-baseline --no-pipeline > /dev/null 2> $O/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 4 --warmup 1 --preroll 16 --no-cpu-baseline --no-pipeline > /dev/null 2> $O/pmc_write.err
+find $O -name "*.csv" | head -20

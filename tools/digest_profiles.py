@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof/ (written by tools/collect_profiles.sh on the GPU box) into the tracked summaries under profiles/."""
+import csv, glob, json, sys, collections, pathlib
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+src = ROOT / "gpurun_out" / "prof"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "round1"
+dst = ROOT / "profiles" / rnd
+dst.mkdir(parents=True, exist_ok=True)
+
+bench = json.loads((src / "bench_default.json").read_text().strip().splitlines()[-1])
+(dst / "bench_default.json").write_text(json.dumps(bench, indent=1) + "\n")
+under = json.loads((src / "bench_under_rocprof.json").read_text().strip().splitlines()[-1])
+
+stats = glob.glob(str(src / "stats" / "*" / "*kernel_stats.csv"))[0]
+rows = [r for r in csv.DictReader(open(stats))]
+with open(dst / "bench_default_kernel_stats.csv", "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline   (durations in ns)\n")
+    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+    w.writeheader()
+    for r in rows:
+        w.writerow(r)
+    # the --stats averages include the pre-roll and warmup launches (loop acquisition); the timed region is the last `steps` launches
+    trace = glob.glob(str(src / "stats" / "*" / "*kernel_trace.csv"))[0]
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        per[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    K = under["steps"]
+    timed = {}
+    for name, v in per.items():
+        if "fmd::" in name:
+            v.sort()
+            timed[name.split("(")[0].replace("void ", "")] = round(sum(d for _, d in v[-K:]) / K / 1e6, 4)
+    f.write("# average over the LAST %d launches of each kernel (= bench.py's timed region), ms, from the kernel trace: %s\n" % (K, json.dumps(timed)))
+    f.write("# bench.py's own HIP-event averages in the same run (ms): " + json.dumps(under["roofline"]["kernels_ms_per_step"]) + "\n")
+
+def pmc(counter):
+    f = glob.glob(str(src / f"pmc_{counter}" / "*" / "*counter_collection.csv"))[0]
+    agg = collections.defaultdict(list)
+    per_dispatch = collections.defaultdict(float)
+    for r in csv.DictReader(open(f)):
+        per_dispatch[(r["Dispatch_Id"], r["Kernel_Name"])] += float(r["Counter_Value"])
+    for (_, name), v in per_dispatch.items():
+        agg[name].append(v)
+    return {k: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in agg.items()}   # steady-state half of the launches
+
+fetch, write = pmc("fetch"), pmc("write")
+cfg = bench["config"]
+key_tail = f"|C={cfg['channels_per_gpu']}|fs={cfg['fs_baseband']}|block={cfg['block_size']}|{cfg['ingest']}"
+names = {"k_front": "k_front", "k_pilot_power": "k_pilot_power", "k_pilot_pll": "k_pilot_pll", "k_extract": "k_extract", "k_rds_sync": "k_rds_sync"}
+traffic, lines = {}, []
+for short in names:
+    fk = [v for k, v in fetch.items() if short in k]
+    wk = [v for k, v in write.items() if short in k]
+    if not fk:
+        continue
+    fr, wr = fk[0], wk[0]
+    total = (2.0 * fr + wr) * 1024.0     # KiB; gfx950 FETCH_SIZE counts half of a 16 B/lane stream (MI355X_MICROARCH.md, HBM section)
+    traffic[short + key_tail] = total
+    lines.append(f"| {short} | {fr:.0f} | {wr:.0f} | {total / 1e6:.1f} MB |")
+(ROOT / "profiles" / "hbm_traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")
+algo = bench["roofline"]["algorithmic_bytes_per_launch"]
+(dst / "hbm_traffic_pmc.md").write_text(
+    "# HBM traffic per launch, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)\n\n"
+    "Command: `rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 4 --warmup 1 --preroll 16 --no-cpu-baseline --no-pipeline`"
+    " (and WRITE_SIZE), " + cfg["workload"] + ".\nCounter unit KiB; reads doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE = 1/2 of a 16 B/lane coalesced stream)."
+    " Averages over the steady-state launches.\n\n| kernel | FETCH_SIZE (KiB, raw) | WRITE_SIZE (KiB) | corrected HBM bytes / launch |\n|---|---|---|---|\n"
+    + "\n".join(lines) + f"\n\nSum over the chain: {sum(traffic.values()) / 1e6:.0f} MB per block (algorithmic: {algo / 1e6:.1f} MB).\n")
+print(json.dumps(traffic, indent=1))
+print(open(dst / "bench_default_kernel_stats.csv").read()[:3000])
