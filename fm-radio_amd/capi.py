@@ -272,11 +272,12 @@ class BatchDemod:
         self._check(self.L.fmd_get_stream(self.h, name.encode(), out.ctypes.data_as(C.c_void_p), out.size, C.byref(n)))
         return out.reshape(self.n_channels, -1)
 
-    def profile(self, on: bool):
-        self._check(self.L.fmd_profile_enable(self.h, 1 if on else 0))
+    def profile(self, on):
+        """False/0: off; True/1: bracket every kernel of every block; 2: the dominant kernel every block, the rest every 4th."""
+        self._check(self.L.fmd_profile_enable(self.h, int(on)))
 
     def spec_stats(self, reset: bool = False) -> dict:
-        """Speculation counters of the serial loops (fmd_get_spec_stats), in 32-sample chunks summed over wavefronts."""
+        """Speculation counters of the serial loops (fmd_get_spec_stats), in 16-sample chunks summed over wavefronts."""
         a = np.zeros(8, np.uint64)
         self._check(self.L.fmd_get_spec_stats(self.h, a.ctypes.data_as(C.c_void_p), 1 if reset else 0))
         out = {"pll": {"chunks": int(a[0]), "general": int(a[1]), "replayed": int(a[2])},

@@ -51,7 +51,7 @@ struct fmd_handle_s {
     int bytes_cap = 0;
     std::string err;
     std::map<int, std::vector<float>> lpf_cache;  // cut-off Hz -> 128 taps
-    bool profiling = false;
+    int profiling = 0;                       // 0 off, 1 every kernel of every block, 2 k_pilot_pll every block + the rest every 4th
     std::vector<ProfiledBlock*> marks;       // one per profiled block, drained by fmd_profile_read
 };
 
@@ -204,10 +204,14 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         for (int i = 0; i < ST_COUNT; i++) { pm->used[i] = false; HIP_TRY(h, hipEventCreate(&pm->t0[i])); HIP_TRY(h, hipEventCreate(&pm->t1[i])); }
         h->marks.push_back(pm);
     }
+    // event bracketing perturbs the pipeline it measures (extra queue packets between dependent kernels): mode 2 keeps it
+    // on the dominant kernel and samples the others
+    auto prof_stage = [&](int st) { return h->profiling == 1 || st == ST_PLL || (h->n_blocks & 3) == 0; };
     auto run = [&](Stage st, hipStream_t on, hipError_t (*fn)(const LaunchCtx&, SlotRef, hipStream_t)) -> hipError_t {
-        if (pm) { (void)hipEventRecord(pm->t0[st], on); pm->used[st] = true; }
+        const bool timed = pm && prof_stage(st);
+        if (timed) { (void)hipEventRecord(pm->t0[st], on); pm->used[st] = true; }
         hipError_t e = fn(h->ctx, ref, on);
-        if (pm) (void)hipEventRecord(pm->t1[st], on);
+        if (timed) (void)hipEventRecord(pm->t1[st], on);
         return e;
     };
     hipError_t e = hipSuccess;
@@ -218,9 +222,10 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         // WAR: this slot's fm_out_iq / pilot / pll_dt were last read by the stages of the block kSlots blocks ago
         if (h->slot_used[slot]) HIP_TRY(h, hipStreamWaitEvent(sF, h->ev_X[slot], 0));
     }
-    if (pm) { (void)hipEventRecord(pm->t0[ST_FRONT], sF); pm->used[ST_FRONT] = true; }
+    const bool front_timed = pm && prof_stage(ST_FRONT);
+    if (front_timed) { (void)hipEventRecord(pm->t0[ST_FRONT], sF); pm->used[ST_FRONT] = true; }
     e = launch_stage_front(h->ctx, ref, d_iq, u8, sF);
-    if (pm) (void)hipEventRecord(pm->t1[ST_FRONT], sF);
+    if (front_timed) (void)hipEventRecord(pm->t1[ST_FRONT], sF);
     if (e != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_front launch: %s", hipGetErrorString(e));
     if (h->ctx.any_deemph && (e = run(ST_DEEMPH, sF, launch_stage_deemph)) != hipSuccess)
         return fail(h, FMD_ERR_DEVICE, "de-emphasis launch: %s", hipGetErrorString(e));
@@ -623,7 +628,7 @@ int fmd_get_spec_stats(fmd_handle h, uint64_t* out8, int reset) {
 
 int fmd_profile_enable(fmd_handle h, int on) {
     if (!h) return FMD_ERR_ARG;
-    h->profiling = on != 0;
+    h->profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
     return FMD_OK;
 }
 

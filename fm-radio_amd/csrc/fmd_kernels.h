@@ -31,7 +31,7 @@ struct LoopCoeffs {
 enum StateField : int {
     // pilot peak IIR
     SA_X1R, SA_X1I, SA_X2R, SA_X2I, SA_Y1R, SA_Y1I, SA_Y2R, SA_Y2I,
-    S_PILOT_POWER0, S_PILOT_POWER1, S_PILOT_POWER2, // sum |pilot|^2 of the block in pipeline slot 0 / 1 / 2 (power pass -> PLL pass)
+    S_PILOT_POWER0, S_PILOT_POWER1, S_PILOT_POWER2, S_PILOT_POWER3, // sum |pilot|^2 of the block in pipeline slot 0..3 (power pass -> PLL pass)
     S_AGC_PILOT_GAIN,
     S_PLL_X1, S_PLL_Y1, S_PLL_INT, S_PLL_ERR, S_PLL_T,
     S_LMR_PHASE_CUR, S_LMR_PHASE_PREV,
@@ -57,8 +57,10 @@ struct Dims {
 
 // Stream buffers are indexed by pipeline slot (= block index % kSlots): the stages of consecutive blocks run concurrently
 // on different streams, so a producer of block b+1 must not overwrite what a consumer of block b (or b-1) still reads.
-// Three slots let the front end of block b+1 start while extract/RDS of block b-1 are still running.
-static constexpr int kSlots = 3;
+// Four slots: the chain 'extract+RDS of block b -> front end of the block that reuses its slot -> power pass -> PLL' must be
+// shorter than the PLL passes that separate the two blocks, with every stage slowed by the others running beside it.
+static constexpr int kSlots = 4;
+static_assert(kSlots <= 4, "one S_PILOT_POWER state field per slot");
 struct SlotRef { int buf; int par; };   // buf = block % kSlots (stream buffers), par = block & 1 (history tails)
 struct Buffers {
     // history tails: stage of block b reads [par], writes [par^1] (producer and consumer are the same stage, same stream)

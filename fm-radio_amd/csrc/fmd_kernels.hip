@@ -373,7 +373,11 @@ __device__ __forceinline__ PllConsts make_pll_consts(const LoopCoeffs& k) {
     return c;
 }
 
+#ifdef FMD_PLL_WHY
+struct PllChecks { float tie_min; uint32_t range_max; uint32_t xr = 0, tr = 0, xbits = 0, tbits = 0; };
+#else
 struct PllChecks { float tie_min; uint32_t range_max; };
+#endif
 static constexpr uint32_t kRangeWindow = 0x0de00000u;
 
 // chebyshev_sine (scalar association) with register constants; zq = z - 1/4 is returned for the tie test
@@ -394,6 +398,10 @@ __device__ __forceinline__ float cheb_sine_locked(float x, const PllConsts& c, f
 __device__ __forceinline__ float atan2f_locked(float y, float x, const PllConsts& c, PllChecks& ck) {
     const float t = div_unscaled(y, x);
     ck.range_max = max(max(ck.range_max, f32_bits(x) - c.xlo), (f32_bits(t) & c.absmask) - c.tlo);
+#ifdef FMD_PLL_WHY
+    if (f32_bits(x) - c.xlo > ck.xr) { ck.xr = f32_bits(x) - c.xlo; ck.xbits = f32_bits(x); }
+    if ((f32_bits(t) & c.absmask) - c.tlo > ck.tr) { ck.tr = (f32_bits(t) & c.absmask) - c.tlo; ck.tbits = f32_bits(t); }
+#endif
     const float z = t * t;
     const float w = z * z;
     float s1 = c.a8 + w * c.a10;
@@ -443,95 +451,148 @@ __device__ __forceinline__ float pll_step_locked(PllState& s, float p, float q, 
 
 static constexpr int kSlowHoldMax = 64;   // longest run of general-form chunks between two speculation attempts
 
+// ---------------------------------------------------------------------------------------------------------------
+// 16-sample chunk staging for the two-wave serial kernels (8 float4 registers per 64-channel chunk).
+// ---------------------------------------------------------------------------------------------------------------
+static constexpr int kCh16 = 16;
+static constexpr int kRow16 = kCh16 + 2;   // float2 row stride (144 B) of a transposed 16-sample cf32 chunk
+struct Chunk16 { float4 v0, v1, v2, v3, v4, v5, v6, v7; };
+#define FMD_FOR8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+__device__ __forceinline__ Chunk16 chunk16_load(const float2* __restrict__ base, int n, int c0, int C, int t0) {
+    const int lane = threadIdx.x & (kWave - 1), row = lane >> 3, col = lane & 7;
+    Chunk16 r;
+#define FMD_LD8(k) { int ch = c0 + 8 * k + row; ch = ch < C ? ch : C - 1; \
+                     r.v##k = *reinterpret_cast<const float4*>(base + (size_t)ch * n + t0 + 2 * col); }
+    FMD_FOR8(FMD_LD8)
+#undef FMD_LD8
+    return r;
+}
+__device__ __forceinline__ void chunk16_store(const Chunk16& r, float2* lds) {
+    const int lane = threadIdx.x & (kWave - 1), row = lane >> 3, col = lane & 7;
+#define FMD_ST8(k) *reinterpret_cast<float4*>(lds + (8 * k + row) * kRow16 + 2 * col) = r.v##k;
+    FMD_FOR8(FMD_ST8)
+#undef FMD_ST8
+}
+// drain 16 f32 results per channel, stored compactly at the start of each row of a chunk buffer, to out[C][n] at t0
+__device__ __forceinline__ void chunk16_flush_f(const float2* lds, float* __restrict__ out, int n, int c0, int C, int t0) {
+    const int lane = threadIdx.x & (kWave - 1), row = lane >> 2, col = lane & 3;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int r = 16 * k + row, ch = c0 + r;
+        const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(lds + r * kRow16) + 4 * col);
+        if (ch < C) *reinterpret_cast<float4*>(out + (size_t)ch * n + t0 + 4 * col) = v;
+    }
+}
+
 // Workgroup = two wavefronts.  Wave 0 runs the recurrence for 64 channels and touches only LDS; wave 1 (the mover) stages
 // the next chunks HBM -> registers -> LDS and drains finished pll_dt chunks LDS -> HBM.  A lone wave is bound by its own
 // instruction issue, and a vector-memory instruction costs it tens of cycles — hundreds when other stages' kernels keep
 // the CU's memory pipeline busy — so the memory instructions are given to a sibling on another SIMD; the two meet at one
-// barrier per 32-sample chunk.
+// barrier per 16-sample chunk.
+// The workgroup is kept SMALL on purpose (18 KB of LDS, results written in place over consumed input; well under 150
+// VGPRs per wave): while the FIR stages' kernels fill every CU, a serial-stage workgroup that needs 52 KB and 2 x 256
+// registers waits >100 us for a hole (measured, tools/gap_probe.hip), one that fits the hole a retiring FIR workgroup
+// leaves starts at once.
 __global__ __launch_bounds__(2 * kWave) void k_pilot_pll(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
                                                          float* __restrict__ state, LoopCoeffs k, int power_field,
                                                          unsigned long long* __restrict__ spec_stats) {
-    __shared__ __attribute__((aligned(16))) float2 xin[2][kWave * kRowC];
-    __shared__ __attribute__((aligned(16))) float dt_out[2][kWave * kRowF];
+    __shared__ __attribute__((aligned(16))) float2 ring[2][kWave * kRow16];
     const bool mover = threadIdx.x >= kWave;   // wave-uniform
-    const int lane = threadIdx.x & (kWave - 1), c0 = blockIdx.x * kWave, c = c0 + lane;
+    const int lane = threadIdx.x & (kWave - 1), c0 = blockIdx.x * kWave;
+    const int n = d.n_fm_out, chunks = n / kCh16;
+
+    if (mover) {
+        // iteration ch (between barriers ch and ch+1): drain the results of chunk ch-1 from its slot, refill that slot with
+        // chunk ch+1 (loaded three iterations ago), issue the loads of chunk ch+4
+        auto load_or_last = [&](int ch) { return chunk16_load(pilot, n, c0, d.C, (ch < chunks ? ch : chunks - 1) * kCh16); };
+        Chunk16 r0 = load_or_last(0);
+        chunk16_store(r0, ring[0]);
+        Chunk16 ra = load_or_last(1), rb = load_or_last(2), rc = load_or_last(3);
+        auto move_chunk = [&](int ch, Chunk16& regs) {
+            float2* slot = ring[(ch + 1) & 1];
+            if (ch > 0) chunk16_flush_f(slot, pll_dt, n, c0, d.C, (ch - 1) * kCh16);
+            if (ch + 1 < chunks) chunk16_store(regs, slot);
+            if (ch + 4 < chunks) regs = load_or_last(ch + 4);
+        };
+        for (int ch = 0; ch < chunks; ch += 3) {
+            __syncthreads();
+            move_chunk(ch, ra);
+            if (ch + 1 < chunks) { __syncthreads(); move_chunk(ch + 1, rb); }
+            if (ch + 2 < chunks) { __syncthreads(); move_chunk(ch + 2, rc); }
+        }
+        __syncthreads();
+        chunk16_flush_f(ring[(chunks - 1) & 1], pll_dt, n, c0, d.C, (chunks - 1) * kCh16);
+        return;
+    }
+
+    __builtin_amdgcn_s_setprio(3);  // latency-bound recurrence: win issue arbitration against co-resident FIR waves
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+    const int c = c0 + lane;
     const bool live = c < d.C;
     const int cs = live ? c : d.C - 1;
-    const int n = d.n_fm_out, chunks = n / kChunk;
-    unsigned long long clk0 = 0, rt0 = 0;
-    float gain = 0.0f;
-    PllState S{};
-    PllConsts kc{};
-    ChunkRegsC regs_a{}, regs_b{};   // mover: chunks ch+1 / ch+2 in flight
-    if (mover) {
-        regs_a = chunk_load_c(pilot, n, c0, d.C, 0);
-        chunk_store_c(regs_a, xin[0]);
-        regs_a = chunk_load_c(pilot, n, c0, d.C, (chunks > 1 ? 1 : 0) * kChunk);
-        regs_b = chunk_load_c(pilot, n, c0, d.C, (chunks > 2 ? 2 : 0) * kChunk);
-    } else {
-        __builtin_amdgcn_s_setprio(3);  // latency-bound recurrence: win issue arbitration against co-resident FIR waves
-        clk0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime();
-        // AGC_Filter::process (agc.h:12-19) as compiled: target_gain = sqrt((target/sum) * N)
-        gain = st(state, S_AGC_PILOT_GAIN, d.C, cs);
+    // AGC_Filter::process (agc.h:12-19) as compiled: target_gain = sqrt((target/sum) * N)
+    float gain = st(state, S_AGC_PILOT_GAIN, d.C, cs);
+    {
         const float sum = st(state, power_field, d.C, cs);
         const float target_gain = sqrtf((1.0f / sum) * (float)n);
         gain = fmaf(target_gain - gain, 0.2f, gain);
-        S.lx1 = st(state, S_PLL_X1, d.C, cs); S.ly1 = st(state, S_PLL_Y1, d.C, cs);
-        S.integ = st(state, S_PLL_INT, d.C, cs); S.err = st(state, S_PLL_ERR, d.C, cs); S.tph = st(state, S_PLL_T, d.C, cs);
-        kc = make_pll_consts(k);
     }
+    PllState S;
+    S.lx1 = st(state, S_PLL_X1, d.C, cs); S.ly1 = st(state, S_PLL_Y1, d.C, cs);
+    S.integ = st(state, S_PLL_INT, d.C, cs); S.err = st(state, S_PLL_ERR, d.C, cs); S.tph = st(state, S_PLL_T, d.C, cs);
+    const PllConsts kc = make_pll_consts(k);
     // a failed speculative chunk is replayed with the general forms; consecutive failures (a loop out of lock) back
     // off exponentially so an unlocked wavefront pays at most a few percent for its attempts
     int slow_left = 0, hold = 0, n_replayed = 0, n_general = 0;
-
-    // mover, iteration ch: chunk ch+1 -> LDS (its loads were issued two iterations ago), issue chunk ch+3, drain chunk ch-1
-    auto move_chunk = [&](int ch, ChunkRegsC& regs) {
-        if (ch + 1 < chunks) chunk_store_c(regs, xin[(ch + 1) & 1]);
-        if (ch + 3 < chunks) regs = chunk_load_c(pilot, n, c0, d.C, (ch + 3) * kChunk);
-        if (ch > 0) chunk_flush_f(dt_out[(ch - 1) & 1], pll_dt, n, c0, d.C, (ch - 1) * kChunk);
-    };
-    auto compute_chunk = [&](int ch) {
-        const float2* buf = xin[ch & 1];
-        float* dto = dt_out[ch & 1];
+    for (int ch = 0; ch < chunks; ch++) {
+        // here: ring[ch & 1] holds chunk ch; the other slot holds the results of chunk ch - 1, which the mover now drains
+        __syncthreads();
+        float2* row = ring[ch & 1] + lane * kRow16;
+        float* dto = reinterpret_cast<float*>(row);   // result t goes to float t of the row: x[t/2] has been consumed by then
         bool done = false;
         if (slow_left == 0) {
             PllState s = S;
             PllChecks ck{1.0f, 0u};
-            float2 y = buf[lane * kRowC];
-#pragma unroll 8
-            for (int t = 0; t < kChunk; t++) {
-                const float2 yn = buf[lane * kRowC + (t + 1 < kChunk ? t + 1 : t)];   // next sample's LDS read one step ahead
-                dto[lane * kRowF + t] = pll_step_locked(s, gain * y.x, gain * y.y, kc, ck);
-                y = yn;
-            }
+            float2 xs[kCh16];                         // the chunk is read before any result is written over it
+#pragma unroll
+            for (int t = 0; t < kCh16; t++) xs[t] = row[t];
+            float dts[kCh16];
+#pragma unroll
+            for (int t = 0; t < kCh16; t++) dts[t] = pll_step_locked(s, gain * xs[t].x, gain * xs[t].y, kc, ck);
             const bool ok = pll_chunk_precheck(S, k) && (ck.tie_min != 0.0f) && (ck.range_max < kRangeWindow);
-            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) { S = s; done = true; hold = 0; }
-            else { slow_left = hold; hold = hold ? (2 * hold < kSlowHoldMax ? 2 * hold : kSlowHoldMax) : 1; n_replayed++; }
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+                S = s; done = true; hold = 0;
+#pragma unroll
+                for (int t = 0; t < kCh16; t += 4) *reinterpret_cast<float4*>(dto + t) = make_float4(dts[t], dts[t + 1], dts[t + 2], dts[t + 3]);
+            } else {
+                slow_left = hold; hold = hold ? (2 * hold < kSlowHoldMax ? 2 * hold : kSlowHoldMax) : 1; n_replayed++;
+#ifdef FMD_PLL_WHY
+                if (spec_stats) {
+                    if (__builtin_amdgcn_ballot_w64(!pll_chunk_precheck(S, k)) && lane == 0) atomicAdd(&spec_stats[3], 1ull);
+                    if (__builtin_amdgcn_ballot_w64(ck.tie_min == 0.0f) && lane == 0) atomicAdd(&spec_stats[4], 1ull);
+                    if (__builtin_amdgcn_ballot_w64(!(ck.range_max < kRangeWindow)) && lane == 0) atomicAdd(&spec_stats[5], 1ull);
+                    if (!(ck.range_max < kRangeWindow) && spec_stats[6] == 0) { spec_stats[6] = ((unsigned long long)ck.xbits << 32) | ck.tbits; spec_stats[7] = ((unsigned long long)lane << 32) | (unsigned)ch; }
+                }
+#endif
+            }
         } else {
             slow_left--;
         }
         if (!done) {
             n_general++;
-            for (int t = 0; t < kChunk; t++) {
-                const float2 y = buf[lane * kRowC + t];
-                dto[lane * kRowF + t] = pll_step(S, gain * y.x, gain * y.y, k);
+            float2 y = row[0];
+            for (int t = 0; t < kCh16; t++) {
+                const float2 yn = row[t + 1 < kCh16 ? t + 1 : t];
+                dto[t] = pll_step(S, gain * y.x, gain * y.y, k);
+                y = yn;
             }
         }
-    };
-    for (int ch = 0; ch < chunks; ch++) {
-        // here: xin[ch & 1] holds chunk ch, dt_out[(ch - 1) & 1] the results of chunk ch - 1, and nobody reads dt_out[ch & 1]
-        __syncthreads();
-        if (mover) {
-            if (ch & 1) move_chunk(ch, regs_b); else move_chunk(ch, regs_a);
-        } else {
-            compute_chunk(ch);
-        }
+        // The results must have landed in LDS before the mover reads them after the next barrier.  The compiler's own
+        // wait in front of the loop-header s_barrier went missing on this back edge (seen in the ISA and as stale last
+        // samples at 4096 channels), so it is spelled out.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    if (mover) {
-        chunk_flush_f(dt_out[(chunks - 1) & 1], pll_dt, n, c0, d.C, (chunks - 1) * kChunk);
-        return;
-    }
     if (live) {
         st(state, S_AGC_PILOT_GAIN, d.C, c) = gain;
         st(state, S_PLL_X1, d.C, c) = S.lx1; st(state, S_PLL_Y1, d.C, c) = S.ly1;
@@ -543,7 +604,9 @@ __global__ __launch_bounds__(2 * kWave) void k_pilot_pll(Dims d, const float2* _
         atomicAdd(&spec_stats[2], (unsigned long long)n_replayed);
         // shader-clock cycles and 100 MHz real-time ticks this wavefront ran: their ratio is the core clock the power
         // management granted while the other stages' kernels ran beside it (DESIGN.md "Clocks")
+#ifndef FMD_PLL_WHY
         if (blockIdx.x == 0) { atomicAdd(&spec_stats[6], __builtin_readcyclecounter() - clk0); atomicAdd(&spec_stats[7], __builtin_amdgcn_s_memrealtime() - rt0); }
+#endif
     }
 }
 

@@ -147,8 +147,9 @@ const char* fmd_last_error(fmd_handle h);
 int fmd_get_rds_bytes(fmd_handle h, uint8_t* bytes, int cap_bytes_per_channel, int* counts);
 
 /* Per-kernel timing with HIP events recorded on the processing stream (for bench.py's roofline figures).
- * While enabled, every fmd_process_* call brackets each kernel of the sequence with events; fmd_profile_read
- * synchronises, accumulates and clears them. */
+ * on = 1: every fmd_process_* call brackets each kernel of the sequence with events; on = 2: k_pilot_pll (the dominant
+ * kernel) of every block, the other kernels of every 4th block — the brackets are extra queue packets between dependent
+ * kernels and cost the pipelined step a few percent; fmd_profile_read synchronises, accumulates and clears them. */
 typedef struct {
     char   name[32];     /* kernel name as it appears in rocprofv3 kernel traces (prefix match) */
     double total_ms;     /* sum of launch durations since the last read */
@@ -161,7 +162,7 @@ int fmd_selftest_atan2(const float* y, const float* x, float* out, size_t n);
  * must equal atan2f(y[i], x[i]) bit-for-bit (DESIGN.md "Speculative serial loops"). */
 int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t* ok, size_t n);
 
-/* Speculation counters of the serial loops since creation / the last reset, in 32-sample chunks summed over wavefronts:
+/* Speculation counters of the serial loops since creation / the last reset, in 16-sample chunks summed over wavefronts:
  * out8[0..2] = pilot PLL {chunks, chunks run with the general forms, chunks speculated then replayed};
  * out8[4..5] = BPSK synchroniser {chunks, general}; out8[6], out8[7] = shader-clock cycles and 100 MHz real-time ticks
  * accumulated by one k_pilot_pll wavefront per launch (ratio x 100 = the core clock in MHz the kernel ran at).

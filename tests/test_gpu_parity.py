@@ -241,7 +241,7 @@ def test_serial_loops_speculate_when_locked_and_replay_when_not(pkg):
         dm.process(caps[:, b * 16384:(b + 1) * 16384])
         per_block.append(dm.spec_stats(reset=True)["pll"])
     dm.close()
-    assert per_block[0]["chunks"] == 8192 // 32 and per_block[0]["general"] > 0      # acquisition: general forms
+    assert per_block[0]["chunks"] == 8192 // 16 and per_block[0]["general"] > 0      # acquisition: general forms
     locked = per_block[-4:]
     assert sum(p["general"] for p in locked) <= 0.05 * sum(p["chunks"] for p in locked)   # in lock: short forms
 
