@@ -156,9 +156,7 @@ def main() -> None:
     ap.add_argument("--u8", action="store_true", help="u8 IQ ingest (2 B/sample) instead of cf32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step audio all-gather at N>1")
-    ap.add_argument("--all-kernel-times", action="store_true", help="bracket every kernel of every step (default: the dominant "
-                    "kernel every step, the others every 4th — the brackets themselves cost the pipelined step a few percent)")
-    ap.add_argument("--no-kernel-times", action="store_true", help="do not bracket each kernel with HIP events in the timed region (no roofline object)")
+    ap.add_argument("--no-kernel-times", action="store_true", help="do not attach HIP timing events to the kernels of the timed region (no roofline object; ~2 %% faster)")
     ap.add_argument("--no-pipeline", action="store_true", help="run the stages of a block back to back on one stream")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--share-gpu", action="store_true", help="plumbing test: every rank uses cuda:0")
@@ -223,7 +221,7 @@ def main() -> None:
     if world > 1:
         dist.barrier()
     dm.spec_stats(reset=True)
-    dm.profile(0 if args.no_kernel_times else (1 if args.all_kernel_times else 2))
+    dm.profile(0 if args.no_kernel_times else 1)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for k in range(P + W, P + W + K):

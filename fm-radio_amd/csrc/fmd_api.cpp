@@ -194,7 +194,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         if (rc) return rc;
     }
     const int slot = (int)(h->n_blocks % kSlots);
-    const SlotRef ref{slot, (int)(h->n_blocks & 1)};
+    const SlotRef ref{slot, (int)(h->n_blocks & 1), nullptr, nullptr};
     const bool u8 = sizeof(InT) == 2;
     const bool pipe = h->pipelined;
     hipStream_t sF = pipe ? h->sF : s, sA = pipe ? h->sA : s, sB = pipe ? h->sB : s, sX = pipe ? h->sX : s;
@@ -208,10 +208,9 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     // on the dominant kernel and samples the others
     auto prof_stage = [&](int st) { return h->profiling == 1 || st == ST_PLL || (h->n_blocks & 3) == 0; };
     auto run = [&](Stage st, hipStream_t on, hipError_t (*fn)(const LaunchCtx&, SlotRef, hipStream_t)) -> hipError_t {
-        const bool timed = pm && prof_stage(st);
-        if (timed) { (void)hipEventRecord(pm->t0[st], on); pm->used[st] = true; }
-        hipError_t e = fn(h->ctx, ref, on);
-        if (timed) (void)hipEventRecord(pm->t1[st], on);
+        SlotRef r = ref;
+        if (pm && prof_stage(st)) { r.t0 = pm->t0[st]; r.t1 = pm->t1[st]; pm->used[st] = true; }
+        hipError_t e = fn(h->ctx, r, on);
         return e;
     };
     hipError_t e = hipSuccess;
@@ -222,10 +221,11 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         // WAR: this slot's fm_out_iq / pilot / pll_dt were last read by the stages of the block kSlots blocks ago
         if (h->slot_used[slot]) HIP_TRY(h, hipStreamWaitEvent(sF, h->ev_X[slot], 0));
     }
-    const bool front_timed = pm && prof_stage(ST_FRONT);
-    if (front_timed) { (void)hipEventRecord(pm->t0[ST_FRONT], sF); pm->used[ST_FRONT] = true; }
-    e = launch_stage_front(h->ctx, ref, d_iq, u8, sF);
-    if (front_timed) (void)hipEventRecord(pm->t1[ST_FRONT], sF);
+    {
+        SlotRef r = ref;
+        if (pm && prof_stage(ST_FRONT)) { r.t0 = pm->t0[ST_FRONT]; r.t1 = pm->t1[ST_FRONT]; pm->used[ST_FRONT] = true; }
+        e = launch_stage_front(h->ctx, r, d_iq, u8, sF);
+    }
     if (e != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_front launch: %s", hipGetErrorString(e));
     if (h->ctx.any_deemph && (e = run(ST_DEEMPH, sF, launch_stage_deemph)) != hipSuccess)
         return fail(h, FMD_ERR_DEVICE, "de-emphasis launch: %s", hipGetErrorString(e));

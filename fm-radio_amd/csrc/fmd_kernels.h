@@ -61,7 +61,9 @@ struct Dims {
 // shorter than the PLL passes that separate the two blocks, with every stage slowed by the others running beside it.
 static constexpr int kSlots = 4;
 static_assert(kSlots <= 4, "one S_PILOT_POWER state field per slot");
-struct SlotRef { int buf; int par; };   // buf = block % kSlots (stream buffers), par = block & 1 (history tails)
+// buf = block % kSlots (stream buffers), par = block & 1 (history tails); t0/t1: optional events that receive the stage's
+// first kernel's start and last kernel's end timestamps (attached to the dispatch packets themselves: no extra queue packets)
+struct SlotRef { int buf; int par; hipEvent_t t0 = nullptr; hipEvent_t t1 = nullptr; };
 struct Buffers {
     // history tails: stage of block b reads [par], writes [par^1] (producer and consumer are the same stage, same stream)
     float2* base_tail[2];   // [C][tail_base]

@@ -16,7 +16,17 @@
 // (8 / 4 lane accumulators per dot product, horizontal sums in the x86 order), so results are
 // bit-identical to the CPU path.  No MFMA: the FIRs are VALU work staged through LDS.
 #include "fmd_kernels.h"
+#include <hip/hip_ext.h>
 #include "fmd_math.h"
+
+// launch with the stage's timing events attached to the dispatch packet when the caller asked for them
+#define FMD_LAUNCH(r, first, last, kern, grid, block, lds, s, ...)                                                   \
+    do {                                                                                                             \
+        hipEvent_t e0_ = (first) ? (r).t0 : nullptr, e1_ = (last) ? (r).t1 : nullptr;                                \
+        if (e0_ || e1_) hipExtLaunchKernelGGL(kern, grid, block, lds, s, e0_, e1_, 0, __VA_ARGS__);                  \
+        else hipLaunchKernelGGL(kern, grid, block, lds, s, __VA_ARGS__);                                             \
+    } while (0)
+
 
 namespace fmd {
 
@@ -1096,7 +1106,7 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
     const int tiles = d.n_fm_out / G::T;
     const size_t lds = sizeof(float) * G::LDS_FLOATS;
     auto kern = k_front<M, InT>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * d.C)), dim3(256), lds, s, d, d_iq, ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1],
+    FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), lds, s, d, d_iq, ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1],
                        ctx.b.fm_out_iq[r.buf], ctx.b.fm_out[r.buf], ctx.b.fo_tail[r.par ^ 1], ctx.front, ctx.any_deemph);
     return hipGetLastError();
 }
@@ -1116,22 +1126,22 @@ static unsigned serial_waves(const Dims& d) { return (unsigned)((d.C + kWave - 1
 hipError_t launch_stage_deemph(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
-    hipLaunchKernelGGL(k_deemphasis, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.fm_out[r.buf], b.deemph, b.state);
-    hipLaunchKernelGGL(k_hilbert, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, b.fm_out[r.buf], b.fo_tail[r.par],
+    FMD_LAUNCH(r, true, false, k_deemphasis, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.fm_out[r.buf], b.deemph, b.state);
+    FMD_LAUNCH(r, false, true, k_hilbert, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, b.fm_out[r.buf], b.fo_tail[r.par],
                        b.fo_tail[r.par ^ 1], b.fm_out_iq[r.buf], ctx.front);
     return hipGetLastError();
 }
 
 hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
-    hipLaunchKernelGGL(k_pilot_power, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[r.buf], ctx.b.pilot[r.buf], ctx.b.state,
+    FMD_LAUNCH(r, true, true, k_pilot_power, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[r.buf], ctx.b.pilot[r.buf], ctx.b.state,
                        ctx.loops, (int)S_PILOT_POWER0 + r.buf);
     return hipGetLastError();
 }
 
 hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
-    hipLaunchKernelGGL(k_pilot_pll, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
+    FMD_LAUNCH(r, true, true, k_pilot_pll, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
                        ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
     return hipGetLastError();
 }
@@ -1140,7 +1150,7 @@ template <int TA>
 static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
-    hipLaunchKernelGGL(k_extract<TA>, dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fm_out_iq[r.buf], b.pll_dt[r.buf],
+    FMD_LAUNCH(r, true, true, k_extract<TA>, dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fm_out_iq[r.buf], b.pll_dt[r.buf],
                        b.iq_tail[r.par], b.dt_tail[r.par], b.iq_tail[r.par ^ 1], b.dt_tail[r.par ^ 1], b.b_lpr, b.b_lmr, ctx.rds_taps, b.mix,
                        b.state, b.audio[r.buf], b.rds, b.lmr_est, b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps);
 }
@@ -1154,7 +1164,7 @@ hipError_t launch_stage_extract(const LaunchCtx& ctx, SlotRef r, hipStream_t s) 
 hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
-    hipLaunchKernelGGL(k_rds_sync, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.rds, b.lmr_est, b.state, ctx.loops, b.rds_sym[r.buf],
+    FMD_LAUNCH(r, true, true, k_rds_sync, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.rds, b.lmr_est, b.state, ctx.loops, b.rds_sym[r.buf],
                        b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps);
     return hipGetLastError();
 }
