@@ -349,83 +349,80 @@ __device__ __forceinline__ float pll_step(PllState& s, float p, float q, const L
 
 // ---------------------------------------------------------------------------------------------------------------
 // Speculative form of the same iteration for a loop that is in lock.  A lone wavefront per SIMD issues one instruction
-// every ~4 cycles and waits ~6 cycles on a dependent result, so the loop's duration is set by its instruction count and
-// by the length of its err -> err dependency chain (78 operations in pll_step).  pll_step_locked cuts the chain to ~45:
+// every ~4 cycles and waits ~6 cycles on a dependent result, so the loop's duration is max(4 x instructions, 6 x chain
+// length).  pll_step (the reference iteration) is a 78-operation err -> err chain; pll_step_locked cuts the chain to ~45
+// and the instruction count to ~68 per sample:
 //   * the integrator / control clamps are skipped (shown not to bind for the whole chunk by pll_chunk_precheck),
 //   * x - round_half_away(x) becomes x - rndne(x) (equal unless x is an exact tie, detected from the chebyshev
 //     argument: wrapped phase == +-0.5  <=>  z - 0.25 == 0),
-//   * the phase detector is atan2f's first range with an unscaled division (fmd_math.h atan2f_small), valid for
-//     x in [2^-14, 2^13.75), 2^-29 <= |y/x| < 7/16 — both windows are 0x0de00000 wide in the float's bit pattern, so one
-//     unsigned max tracks both.
+//   * the phase detector is atan2f's first range with an unscaled division (fmd_math.h div_unscaled), valid for
+//     x in [2^-28, ~2e8) and 2^-29 <= |y/x| < 7/16, i.e. (y/x)^2 in [2^-58, 49/256) — both windows are 0x1bc40000 wide
+//     in the float's bit pattern, so one unsigned max tracks both,
+//   * TWO LANES PER CHANNEL: the iteration contains two pairs of structurally identical, mutually independent
+//     polynomial evaluations (chebyshev sine of the phase and of phase + 1/4; the odd and even halves s1 / s2 of the
+//     arctangent series).  The even lane of a pair evaluates the first of each, the odd lane the second, with the same
+//     instructions and per-lane constants, and they exchange the results with DPP quad permutes.  Everything else is
+//     computed redundantly (identically) by both lanes.  A wavefront therefore carries 32 channels.
 // Validity is accumulated in VALU registers only (a v_cmp -> SALU round trip stalls an in-order wave ~18 cycles) and
-// tested once per 32-sample chunk; a chunk with any invalid lane is replayed with pll_step.  Constants live in VGPRs:
+// tested once per 16-sample chunk; a chunk with any invalid lane is replayed with pll_step.  Constants live in VGPRs:
 // a 32-bit literal in the instruction stream costs a lone wave ~2.7 extra cycles per instruction.
 // ---------------------------------------------------------------------------------------------------------------
 struct PllConsts {
-    float b0, a0, b1, c001, ktsi, m100, m19000, ts, q25, mq25, c5, c4, c3, c2, c1, c0;
-    float a10, a8, a6, a4, a2, a0t, a9, a7, a5, a3, a1;
-    uint32_t absmask, xlo, tlo;
+    float b0, a0, b1, c001, ktsi, m100, m19000, ts, q25 /* odd lane 1/4, even lane -0 */, mq25, c5, c4, c3, c2, c1, c0;
+    float k0, k1, k2, k3, k4, k5;   // arctangent series, this lane's half: even lane a10,a8,a6,a4,a2,a0 (s1); odd lane 0,a9,a7,a5,a3,a1 (s2)
+    uint32_t xlo, zlo;
+    bool odd;
 };
 #define FMD_OPAQUE_F(dst, val) { float t_ = (val); asm volatile("" : "+v"(t_)); dst = t_; }
 #define FMD_OPAQUE_U(dst, val) { uint32_t t_ = (val); asm volatile("" : "+v"(t_)); dst = t_; }
-__device__ __forceinline__ PllConsts make_pll_consts(const LoopCoeffs& k) {
+__device__ __forceinline__ PllConsts make_pll_consts(const LoopCoeffs& k, bool odd) {
     PllConsts c;
     FMD_OPAQUE_F(c.b0, k.pll_b0) FMD_OPAQUE_F(c.a0, k.pll_a0) FMD_OPAQUE_F(c.b1, k.pll_b1) FMD_OPAQUE_F(c.c001, 0.01f)
     FMD_OPAQUE_F(c.ktsi, 0.1f * (1.0f / 128000.0f)) FMD_OPAQUE_F(c.m100, -100.0f) FMD_OPAQUE_F(c.m19000, -19000.0f)
-    FMD_OPAQUE_F(c.ts, 1.0f / 128000.0f) FMD_OPAQUE_F(c.q25, 0.25f) FMD_OPAQUE_F(c.mq25, -0.25f)
+    FMD_OPAQUE_F(c.ts, 1.0f / 128000.0f) FMD_OPAQUE_F(c.q25, odd ? 0.25f : -0.0f) FMD_OPAQUE_F(c.mq25, -0.25f)
     FMD_OPAQUE_F(c.c5, 3.20396066f) FMD_OPAQUE_F(c.c4, -14.07150173f) FMD_OPAQUE_F(c.c3, 38.50016403f)
     FMD_OPAQUE_F(c.c2, -67.07687378f) FMD_OPAQUE_F(c.c1, 64.83583069f) FMD_OPAQUE_F(c.c0, -25.13274193f)
-    FMD_OPAQUE_F(c.a10, bits_f32(0x3c8569d7u)) FMD_OPAQUE_F(c.a8, bits_f32(0x3d4bda59u)) FMD_OPAQUE_F(c.a6, bits_f32(0x3d886b35u))
-    FMD_OPAQUE_F(c.a4, bits_f32(0x3dba2e6eu)) FMD_OPAQUE_F(c.a2, bits_f32(0x3e124925u)) FMD_OPAQUE_F(c.a0t, bits_f32(0x3eaaaaabu))
-    FMD_OPAQUE_F(c.a9, bits_f32(0xbd15a221u)) FMD_OPAQUE_F(c.a7, bits_f32(0xbd6ef16bu)) FMD_OPAQUE_F(c.a5, bits_f32(0xbd9d8795u))
-    FMD_OPAQUE_F(c.a3, bits_f32(0xbde38e38u)) FMD_OPAQUE_F(c.a1, bits_f32(0xbe4ccccdu))
-    FMD_OPAQUE_U(c.absmask, 0x7fffffffu) FMD_OPAQUE_U(c.xlo, 0x38800000u) FMD_OPAQUE_U(c.tlo, 0x31000000u)
+    FMD_OPAQUE_F(c.k0, odd ? 0.0f : bits_f32(0x3c8569d7u))
+    FMD_OPAQUE_F(c.k1, odd ? bits_f32(0xbd15a221u) : bits_f32(0x3d4bda59u))
+    FMD_OPAQUE_F(c.k2, odd ? bits_f32(0xbd6ef16bu) : bits_f32(0x3d886b35u))
+    FMD_OPAQUE_F(c.k3, odd ? bits_f32(0xbd9d8795u) : bits_f32(0x3dba2e6eu))
+    FMD_OPAQUE_F(c.k4, odd ? bits_f32(0xbde38e38u) : bits_f32(0x3e124925u))
+    FMD_OPAQUE_F(c.k5, odd ? bits_f32(0xbe4ccccdu) : bits_f32(0x3eaaaaabu))
+    FMD_OPAQUE_U(c.xlo, 0x31800000u) FMD_OPAQUE_U(c.zlo, 0x22800000u)
+    c.odd = odd;
     return c;
 }
 
-#ifdef FMD_PLL_WHY
-struct PllChecks { float tie_min; uint32_t range_max; uint32_t xr = 0, tr = 0, xbits = 0, tbits = 0; };
-#else
 struct PllChecks { float tie_min; uint32_t range_max; };
-#endif
-static constexpr uint32_t kRangeWindow = 0x0de00000u;
+static constexpr uint32_t kRangeWindow = 0x1bc40000u;   // bits(49/256) - bits(2^-58)
 
-// chebyshev_sine (scalar association) with register constants; zq = z - 1/4 is returned for the tie test
-__device__ __forceinline__ float cheb_sine_locked(float x, const PllConsts& c, float& zq) {
-    const float z = x * x;
-    float p = fmaf(c.c5, z, c.c4);
-    p = fmaf(p, z, c.c3);
-    p = fmaf(p, z, c.c2);
-    p = fmaf(p, z, c.c1);
-    p = fmaf(p, z, c.c0);
-    zq = z + c.mq25;
-    return (zq * x) * p;
+// DPP quad permutes between the two lanes of a channel pair (lanes 2j, 2j+1)
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
+static constexpr int kDppEven = 0xA0;   // quad_perm [0,0,2,2]: both lanes read the even lane
+static constexpr int kDppOdd = 0xF5;    // quad_perm [1,1,3,3]: both lanes read the odd lane
+static constexpr int kDppSwap = 0xB1;   // quad_perm [1,0,3,2]: each lane reads its partner
 
-// atan2f(y, x) for x in [2^-14, 2^13.75) and 2^-29 <= |y/x| < 7/16 (a locked loop's phase error): the published
-// algorithm reduces to t - t (s1 + s2) with t = y / x (its first range, which is odd-symmetric, so no quadrant or sign
-// selects), and the division needs neither operand scaling nor special-value fix-up.  range_max records the windows.
+// atan2f(y, x) for x in [2^-28, ~2e8) and 2^-29 <= |y/x| < 7/16 (a locked loop's phase error): the published algorithm
+// reduces to t - t (s1 + s2) with t = y / x (its first range, which is odd-symmetric, so no quadrant or sign selects), and
+// the division needs neither operand scaling nor special-value fix-up.  Both lanes of a pair hold the same (y, x); the even
+// lane evaluates s1 = z (a0 + w (a2 + w (a4 + w (a6 + w (a8 + w a10))))), the odd lane s2 = w (a1 + w (a3 + w (a5 + w (a7 + w a9))))
+// (its first level is a9 + w 0 = a9 exactly), then each adds its partner's half (IEEE addition commutes).
 __device__ __forceinline__ float atan2f_locked(float y, float x, const PllConsts& c, PllChecks& ck) {
     const float t = div_unscaled(y, x);
-    ck.range_max = max(max(ck.range_max, f32_bits(x) - c.xlo), (f32_bits(t) & c.absmask) - c.tlo);
-#ifdef FMD_PLL_WHY
-    if (f32_bits(x) - c.xlo > ck.xr) { ck.xr = f32_bits(x) - c.xlo; ck.xbits = f32_bits(x); }
-    if ((f32_bits(t) & c.absmask) - c.tlo > ck.tr) { ck.tr = (f32_bits(t) & c.absmask) - c.tlo; ck.tbits = f32_bits(t); }
-#endif
     const float z = t * t;
     const float w = z * z;
-    float s1 = c.a8 + w * c.a10;
-    s1 = c.a6 + w * s1;
-    s1 = c.a4 + w * s1;
-    s1 = c.a2 + w * s1;
-    s1 = c.a0t + w * s1;
-    s1 = z * s1;
-    float s2 = c.a7 + w * c.a9;
-    s2 = c.a5 + w * s2;
-    s2 = c.a3 + w * s2;
-    s2 = c.a1 + w * s2;
-    s2 = w * s2;
-    return t - t * (s1 + s2);
+    ck.range_max = max(max(ck.range_max, f32_bits(x) - c.xlo), f32_bits(z) - c.zlo);
+    float s = c.k1 + w * c.k0;
+    s = c.k2 + w * s;
+    s = c.k3 + w * s;
+    s = c.k4 + w * s;
+    s = c.k5 + w * s;
+    s = (c.odd ? w : z) * s;
+    const float sum = s + dpp_quad<kDppSwap>(s);
+    return t - t * sum;
 }
 
 // Holds for the whole chunk if it holds at its start, given that every err the chunk produces is < 0.42 in magnitude
@@ -447,12 +444,21 @@ __device__ __forceinline__ float pll_step_locked(PllState& s, float p, float q, 
     const float freq = fmaf(PI_error, c.m100, c.m19000);
     const float yy = fmaf(freq, c.ts, s.tph);
     s.tph = yy - rintf(yy);
+    // chebyshev_sine (scalar association): the odd lane of the pair takes sin(2 pi wrap(t + 1/4)); the even lane runs the
+    // same three instructions with -0 in place of 1/4, which leave t unchanged bit for bit (t + -0 = t, |t| <= 1/2 so
+    // rndne(t) = +-0), i.e. sin(2 pi t) — no select on the dependency chain
     const float dc = s.tph + c.q25;
-    const float dt_cos = dc - rintf(dc);
-    float zq_s, zq_c;
-    const float ps = cheb_sine_locked(s.tph, c, zq_s);
-    const float pc = cheb_sine_locked(dt_cos, c, zq_c);
-    ck.tie_min = fminf(fminf(ck.tie_min, fabsf(zq_s)), fabsf(zq_c));
+    const float xr = dc - rintf(dc);
+    const float z = xr * xr;
+    float poly = fmaf(c.c5, z, c.c4);
+    poly = fmaf(poly, z, c.c3);
+    poly = fmaf(poly, z, c.c2);
+    poly = fmaf(poly, z, c.c1);
+    poly = fmaf(poly, z, c.c0);
+    const float zq = z + c.mq25;
+    const float sn = (zq * xr) * poly;
+    ck.tie_min = fminf(ck.tie_min, fabsf(zq));   // wrapped phase == +-1/2 <=> zq == 0: the rndne shortcut was not exact
+    const float ps = dpp_quad<kDppEven>(sn), pc = dpp_quad<kDppOdd>(sn);
     const float res_im = fmaf(ps, p, q * pc);
     const float res_re = fmaf(p, pc, -(q * ps));
     s.err = atan2f_locked(res_im, res_re, c, ck);
@@ -462,53 +468,55 @@ __device__ __forceinline__ float pll_step_locked(PllState& s, float p, float q, 
 static constexpr int kSlowHoldMax = 64;   // longest run of general-form chunks between two speculation attempts
 
 // ---------------------------------------------------------------------------------------------------------------
-// 16-sample chunk staging for the two-wave serial kernels (8 float4 registers per 64-channel chunk).
+// 16-sample chunk staging for the two-wave pilot PLL kernel: 32 channels per workgroup (two lanes per channel in the
+// recurrence wave), 4 float4 registers per chunk in the mover wave.
 // ---------------------------------------------------------------------------------------------------------------
 static constexpr int kCh16 = 16;
 static constexpr int kRow16 = kCh16 + 2;   // float2 row stride (144 B) of a transposed 16-sample cf32 chunk
-struct Chunk16 { float4 v0, v1, v2, v3, v4, v5, v6, v7; };
-#define FMD_FOR8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+static constexpr int kPllCh = 32;          // channels per k_pilot_pll workgroup
+struct Chunk16 { float4 v0, v1, v2, v3; };
+#define FMD_FOR4(X) X(0) X(1) X(2) X(3)
 __device__ __forceinline__ Chunk16 chunk16_load(const float2* __restrict__ base, int n, int c0, int C, int t0) {
     const int lane = threadIdx.x & (kWave - 1), row = lane >> 3, col = lane & 7;
     Chunk16 r;
-#define FMD_LD8(k) { int ch = c0 + 8 * k + row; ch = ch < C ? ch : C - 1; \
+#define FMD_LD4(k) { int ch = c0 + 8 * k + row; ch = ch < C ? ch : C - 1; \
                      r.v##k = *reinterpret_cast<const float4*>(base + (size_t)ch * n + t0 + 2 * col); }
-    FMD_FOR8(FMD_LD8)
-#undef FMD_LD8
+    FMD_FOR4(FMD_LD4)
+#undef FMD_LD4
     return r;
 }
 __device__ __forceinline__ void chunk16_store(const Chunk16& r, float2* lds) {
     const int lane = threadIdx.x & (kWave - 1), row = lane >> 3, col = lane & 7;
-#define FMD_ST8(k) *reinterpret_cast<float4*>(lds + (8 * k + row) * kRow16 + 2 * col) = r.v##k;
-    FMD_FOR8(FMD_ST8)
-#undef FMD_ST8
+#define FMD_ST4(k) *reinterpret_cast<float4*>(lds + (8 * k + row) * kRow16 + 2 * col) = r.v##k;
+    FMD_FOR4(FMD_ST4)
+#undef FMD_ST4
 }
 // drain 16 f32 results per channel, stored compactly at the start of each row of a chunk buffer, to out[C][n] at t0
 __device__ __forceinline__ void chunk16_flush_f(const float2* lds, float* __restrict__ out, int n, int c0, int C, int t0) {
     const int lane = threadIdx.x & (kWave - 1), row = lane >> 2, col = lane & 3;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < 2; k++) {
         const int r = 16 * k + row, ch = c0 + r;
         const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(lds + r * kRow16) + 4 * col);
         if (ch < C) *reinterpret_cast<float4*>(out + (size_t)ch * n + t0 + 4 * col) = v;
     }
 }
 
-// Workgroup = two wavefronts.  Wave 0 runs the recurrence for 64 channels and touches only LDS; wave 1 (the mover) stages
-// the next chunks HBM -> registers -> LDS and drains finished pll_dt chunks LDS -> HBM.  A lone wave is bound by its own
-// instruction issue, and a vector-memory instruction costs it tens of cycles — hundreds when other stages' kernels keep
-// the CU's memory pipeline busy — so the memory instructions are given to a sibling on another SIMD; the two meet at one
-// barrier per 16-sample chunk.
-// The workgroup is kept SMALL on purpose (18 KB of LDS, results written in place over consumed input; well under 150
+// Workgroup = two wavefronts for 32 channels.  Wave 0 runs the recurrence (two lanes per channel, see pll_step_locked) and
+// touches only LDS; wave 1 (the mover) stages the next chunks HBM -> registers -> LDS and drains finished pll_dt chunks
+// LDS -> HBM.  A lone wave is bound by its own instruction issue, and a vector-memory instruction costs it tens of cycles
+// — hundreds when other stages' kernels keep the CU's memory pipeline busy — so the memory instructions are given to a
+// sibling on another SIMD; the two meet at one barrier per 16-sample chunk.
+// The workgroup is kept SMALL on purpose (9 KB of LDS, results written in place over consumed input; well under 150
 // VGPRs per wave): while the FIR stages' kernels fill every CU, a serial-stage workgroup that needs 52 KB and 2 x 256
 // registers waits >100 us for a hole (measured, tools/gap_probe.hip), one that fits the hole a retiring FIR workgroup
 // leaves starts at once.
 __global__ __launch_bounds__(2 * kWave) void k_pilot_pll(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
                                                          float* __restrict__ state, LoopCoeffs k, int power_field,
                                                          unsigned long long* __restrict__ spec_stats) {
-    __shared__ __attribute__((aligned(16))) float2 ring[2][kWave * kRow16];
+    __shared__ __attribute__((aligned(16))) float2 ring[2][kPllCh * kRow16];
     const bool mover = threadIdx.x >= kWave;   // wave-uniform
-    const int lane = threadIdx.x & (kWave - 1), c0 = blockIdx.x * kWave;
+    const int lane = threadIdx.x & (kWave - 1), c0 = blockIdx.x * kPllCh;
     const int n = d.n_fm_out, chunks = n / kCh16;
 
     if (mover) {
@@ -537,7 +545,8 @@ __global__ __launch_bounds__(2 * kWave) void k_pilot_pll(Dims d, const float2* _
 
     __builtin_amdgcn_s_setprio(3);  // latency-bound recurrence: win issue arbitration against co-resident FIR waves
     const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
-    const int c = c0 + lane;
+    const int c = c0 + (lane >> 1);            // lanes 2j and 2j+1 both carry channel c0 + j
+    const bool odd = (lane & 1) != 0;
     const bool live = c < d.C;
     const int cs = live ? c : d.C - 1;
     // AGC_Filter::process (agc.h:12-19) as compiled: target_gain = sqrt((target/sum) * N)
@@ -550,14 +559,14 @@ __global__ __launch_bounds__(2 * kWave) void k_pilot_pll(Dims d, const float2* _
     PllState S;
     S.lx1 = st(state, S_PLL_X1, d.C, cs); S.ly1 = st(state, S_PLL_Y1, d.C, cs);
     S.integ = st(state, S_PLL_INT, d.C, cs); S.err = st(state, S_PLL_ERR, d.C, cs); S.tph = st(state, S_PLL_T, d.C, cs);
-    const PllConsts kc = make_pll_consts(k);
+    const PllConsts kc = make_pll_consts(k, odd);
     // a failed speculative chunk is replayed with the general forms; consecutive failures (a loop out of lock) back
     // off exponentially so an unlocked wavefront pays at most a few percent for its attempts
     int slow_left = 0, hold = 0, n_replayed = 0, n_general = 0;
     for (int ch = 0; ch < chunks; ch++) {
         // here: ring[ch & 1] holds chunk ch; the other slot holds the results of chunk ch - 1, which the mover now drains
         __syncthreads();
-        float2* row = ring[ch & 1] + lane * kRow16;
+        float2* row = ring[ch & 1] + (lane >> 1) * kRow16;
         float* dto = reinterpret_cast<float*>(row);   // result t goes to float t of the row: x[t/2] has been consumed by then
         bool done = false;
         if (slow_left == 0) {
@@ -572,23 +581,15 @@ __global__ __launch_bounds__(2 * kWave) void k_pilot_pll(Dims d, const float2* _
             const bool ok = pll_chunk_precheck(S, k) && (ck.tie_min != 0.0f) && (ck.range_max < kRangeWindow);
             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
                 S = s; done = true; hold = 0;
+                if (!odd) {
 #pragma unroll
-                for (int t = 0; t < kCh16; t += 4) *reinterpret_cast<float4*>(dto + t) = make_float4(dts[t], dts[t + 1], dts[t + 2], dts[t + 3]);
-            } else {
-                slow_left = hold; hold = hold ? (2 * hold < kSlowHoldMax ? 2 * hold : kSlowHoldMax) : 1; n_replayed++;
-#ifdef FMD_PLL_WHY
-                if (spec_stats) {
-                    if (__builtin_amdgcn_ballot_w64(!pll_chunk_precheck(S, k)) && lane == 0) atomicAdd(&spec_stats[3], 1ull);
-                    if (__builtin_amdgcn_ballot_w64(ck.tie_min == 0.0f) && lane == 0) atomicAdd(&spec_stats[4], 1ull);
-                    if (__builtin_amdgcn_ballot_w64(!(ck.range_max < kRangeWindow)) && lane == 0) atomicAdd(&spec_stats[5], 1ull);
-                    if (!(ck.range_max < kRangeWindow) && spec_stats[6] == 0) { spec_stats[6] = ((unsigned long long)ck.xbits << 32) | ck.tbits; spec_stats[7] = ((unsigned long long)lane << 32) | (unsigned)ch; }
+                    for (int t = 0; t < kCh16; t += 4) *reinterpret_cast<float4*>(dto + t) = make_float4(dts[t], dts[t + 1], dts[t + 2], dts[t + 3]);
                 }
-#endif
-            }
+            } else { slow_left = hold; hold = hold ? (2 * hold < kSlowHoldMax ? 2 * hold : kSlowHoldMax) : 1; n_replayed++; }
         } else {
             slow_left--;
         }
-        if (!done) {
+        if (!done) {   // general iteration, computed identically by both lanes of a pair (same address, same value)
             n_general++;
             float2 y = row[0];
             for (int t = 0; t < kCh16; t++) {
@@ -603,7 +604,7 @@ __global__ __launch_bounds__(2 * kWave) void k_pilot_pll(Dims d, const float2* _
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    if (live) {
+    if (live && !odd) {
         st(state, S_AGC_PILOT_GAIN, d.C, c) = gain;
         st(state, S_PLL_X1, d.C, c) = S.lx1; st(state, S_PLL_Y1, d.C, c) = S.ly1;
         st(state, S_PLL_INT, d.C, c) = S.integ; st(state, S_PLL_ERR, d.C, c) = S.err; st(state, S_PLL_T, d.C, c) = S.tph;
@@ -614,9 +615,7 @@ __global__ __launch_bounds__(2 * kWave) void k_pilot_pll(Dims d, const float2* _
         atomicAdd(&spec_stats[2], (unsigned long long)n_replayed);
         // shader-clock cycles and 100 MHz real-time ticks this wavefront ran: their ratio is the core clock the power
         // management granted while the other stages' kernels ran beside it (DESIGN.md "Clocks")
-#ifndef FMD_PLL_WHY
         if (blockIdx.x == 0) { atomicAdd(&spec_stats[6], __builtin_readcyclecounter() - clk0); atomicAdd(&spec_stats[7], __builtin_amdgcn_s_memrealtime() - rt0); }
-#endif
     }
 }
 
@@ -1069,21 +1068,21 @@ __global__ __launch_bounds__(256) void k_hilbert(Dims d, const float* __restrict
 
 __global__ void k_selftest_atan2(const float* __restrict__ y, const float* __restrict__ x, float* __restrict__ out,
                                  unsigned char* __restrict__ ok_out, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (ok_out) {   // the locked-loop short form and its exactness predicate
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ok_out) {   // the locked-loop short form (two lanes per element, as in k_pilot_pll) and its exactness predicate
+        const size_t i = tid >> 1, ic = i < n ? i : n - 1;
         LoopCoeffs k{};
-        const PllConsts c = make_pll_consts(k);
+        const PllConsts c = make_pll_consts(k, (tid & 1) != 0);
         PllChecks ck{1.0f, 0u};
-        out[i] = atan2f_locked(y[i], x[i], c, ck);
-        ok_out[i] = ck.range_max < kRangeWindow ? 1 : 0;
-    } else {
-        out[i] = fmd_atan2f(y[i], x[i]);
+        const float r = atan2f_locked(y[ic], x[ic], c, ck);
+        if (i < n && !(tid & 1)) { out[i] = r; ok_out[i] = ck.range_max < kRangeWindow ? 1 : 0; }
+    } else if (tid < n) {
+        out[tid] = fmd_atan2f(y[tid], x[tid]);
     }
 }
 
 hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, unsigned char* d_ok, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_selftest_atan2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_y, d_x, d_out, d_ok, n);
+    hipLaunchKernelGGL(k_selftest_atan2, dim3((unsigned)(((d_ok ? 2 * n : n) + 255) / 256)), dim3(256), 0, s, d_y, d_x, d_out, d_ok, n);
     return hipGetLastError();
 }
 
@@ -1141,7 +1140,7 @@ hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
 
 hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
-    FMD_LAUNCH(r, true, true, k_pilot_pll, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
+    FMD_LAUNCH(r, true, true, k_pilot_pll, dim3((unsigned)((d.C + kPllCh - 1) / kPllCh)), dim3(2 * kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
                        ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
     return hipGetLastError();
 }
