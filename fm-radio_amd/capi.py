@@ -55,6 +55,11 @@ class Coeffs(C.Structure):
                 ("fm_gain", C.c_float)]
 
 
+class ChanConfig(C.Structure):
+    _fields_ = [("fs_in", C.c_double), ("fs_out", C.c_double), ("n_stations", C.c_int), ("center_hz", C.POINTER(C.c_double)),
+                ("taps_per_phase", C.c_int), ("max_input_samples", C.c_longlong), ("device", C.c_int)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_int)]
 
@@ -128,6 +133,15 @@ def load_library():
     L.fmd_get_spec_stats.argtypes = [H, C.c_void_p, C.c_int]
     L.fmd_profile_enable.argtypes = [H, C.c_int]
     L.fmd_profile_read.argtypes = [H, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]
+    L.fmd_chan_design.argtypes = [C.c_double, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.fmd_chan_create.argtypes = [C.POINTER(ChanConfig), C.POINTER(C.c_void_p)]
+    L.fmd_chan_destroy.argtypes = [C.c_void_p]
+    L.fmd_chan_reset.argtypes = [C.c_void_p]
+    L.fmd_chan_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+    L.fmd_chan_get_taps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.fmd_chan_process_cf32_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
+    L.fmd_chan_last_error.restype = C.c_char_p
+    L.fmd_chan_last_error.argtypes = [C.c_void_p]
     L.fmd_last_error.restype = C.c_char_p
     L.fmd_last_error.argtypes = [H]
     _lib = L
@@ -304,3 +318,71 @@ class BatchDemod:
         class _Arr:
             __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (p.value, False), "version": 2}
         return torch.as_tensor(_Arr(), device="cuda").view(self.n_channels, self.rates.n_audio, 2)
+
+
+def chan_design(fs_in: float, fs_out: float, taps_per_phase: int = 640):
+    """Host-only prototype design of the wideband channeliser: (taps [T, L] float32, L, M).  Needs no GPU."""
+    lib = load_library()
+    L, M = C.c_int(0), C.c_int(0)
+    rc = lib.fmd_chan_design(fs_in, fs_out, taps_per_phase, None, C.byref(L), C.byref(M))
+    if rc != FMD_OK:
+        raise FmdError(rc, "unsupported channeliser rates")
+    taps = np.empty((taps_per_phase, L.value), np.float32)
+    lib.fmd_chan_design(fs_in, fs_out, taps_per_phase, taps.ctypes.data_as(C.c_void_p), None, None)
+    return taps, L.value, M.value
+
+
+class Channelizer:
+    """Wideband capture -> [C][n_out] cf32 stations at fs_out on the GPU (fmd_chan_*); feeds BatchDemod.process directly."""
+
+    def __init__(self, fs_in: float, center_hz, fs_out: float = 256_000.0, max_input_samples: int = 640_000, taps_per_phase: int = 0, device: int = -1):
+        self.L = load_library()
+        self.centers = np.ascontiguousarray(center_hz, np.float64)
+        cfg = ChanConfig(fs_in, fs_out, int(self.centers.size), self.centers.ctypes.data_as(C.POINTER(C.c_double)), taps_per_phase, max_input_samples, device)
+        self.h = C.c_void_p()
+        rc = self.L.fmd_chan_create(C.byref(cfg), C.byref(self.h))
+        if rc != FMD_OK:
+            raise FmdError(rc, self.L.fmd_chan_last_error(None).decode())
+        l, m, t, c = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.L.fmd_chan_info(self.h, C.byref(l), C.byref(m), C.byref(t), C.byref(c))
+        self.interp, self.decim, self.taps_per_phase, self.n_stations = l.value, m.value, t.value, c.value
+
+    def taps(self) -> np.ndarray:
+        a = np.empty((self.taps_per_phase, self.interp), np.float32)
+        rc = self.L.fmd_chan_get_taps(self.h, a.ctypes.data_as(C.c_void_p), a.size)
+        if rc != FMD_OK:
+            raise FmdError(rc, "fmd_chan_get_taps")
+        return a
+
+    def process(self, wide, out=None, stream=None):
+        """wide: contiguous CUDA float32 tensor [n_in, 2]; returns a CUDA tensor [C, n_out, 2] (asynchronous on the stream)."""
+        import torch
+        if not (wide.is_cuda and wide.is_contiguous() and wide.dtype == torch.float32 and wide.dim() == 2 and wide.shape[1] == 2):
+            raise ValueError("wide must be a contiguous CUDA float32 tensor [n_in, 2]")
+        n_in = int(wide.shape[0])
+        n_out = n_in * self.interp // self.decim
+        if out is None:
+            out = torch.empty((self.n_stations, n_out, 2), dtype=torch.float32, device=wide.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(wide.device).cuda_stream
+        got = C.c_size_t(0)
+        rc = self.L.fmd_chan_process_cf32_dev(self.h, wide.data_ptr(), n_in, out.data_ptr(), int(out.shape[1]), C.byref(got), C.c_void_p(stream))
+        if rc != FMD_OK:
+            raise FmdError(rc, self.L.fmd_chan_last_error(self.h).decode())
+        return out[:, :got.value]
+
+    def reset(self):
+        rc = self.L.fmd_chan_reset(self.h)
+        if rc != FMD_OK:
+            raise FmdError(rc, self.L.fmd_chan_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.fmd_chan_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,239 @@
+// Wideband channeliser (BASELINE configs[4]): one wideband IQ capture (e.g. 10 MSa/s) is split into C
+// FM stations at the demodulator's 256 kSa/s, laid out [C][n_out] cf32 — exactly what fmd_process_cf32_dev consumes.
+//
+// NOT in the reference (it tunes one station in the RTL-SDR hardware, src/device): parity is unpinned; the tests validate
+// by construction against a float64 restatement of the same definition (tests/test_channelizer.py).
+//
+// Definition.  fs_out / fs_in = L / M in lowest terms (256 k / 10 M = 16 / 625).  For station k with centre f_k:
+//     x_k[n] = x[n] * exp(-j 2 pi f_k n / fs_in)                                 (mix to baseband; n absolute, 64-bit)
+//     y_k[o] = sum_{t=0}^{T-1} h[p + L t] * x_k[n0 - t],   n0 = floor(o M / L),  p = (o M) mod L
+// i.e. the polyphase form of "zero-stuff by L, low-pass h, keep every M-th": a polyphase filter bank whose branches are
+// the L phases of one Kaiser-windowed prototype (cut-off fs_out/2, length L*T), shared by all stations.  Per output
+// sample that is T complex-by-real MACs; 40 stations x 256 kSa/s x 640 taps = 13 GFMA/s — noise next to the demodulator.
+//
+// Kernel: workgroup = (station, 128 consecutive outputs).  The input window those outputs need (128 M/L + T samples) is
+// mixed once while it is staged into LDS; every thread then walks its own T taps.  Taps are stored [t][p] so the 64 lanes
+// of a wavefront (consecutive outputs = consecutive phases when M mod L == 1) read contiguous rows.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "fmdemod.h"
+
+namespace {
+
+constexpr int kTile = 128;          // outputs per workgroup
+constexpr int kMaxWindow = 7168;    // staged input samples per workgroup (56 KB of LDS)
+
+struct ChanDims {
+    int L, M, T;            // interpolation, decimation, taps per phase
+    int n_stations;
+    long long n_out;        // outputs per station this call
+    unsigned long long o0;  // absolute index of the first output of this call
+    unsigned long long n_base;  // absolute input index of win[0]
+};
+
+__global__ __launch_bounds__(256) void k_channelize(ChanDims d, const float2* __restrict__ win, const float* __restrict__ taps /* [T][L] */,
+                                                    const unsigned long long* __restrict__ phase_inc /* [C], turns * 2^64 per input sample */,
+                                                    float2* __restrict__ out /* [C][n_out] */) {
+    __shared__ float2 xs[kMaxWindow];
+    const int k = blockIdx.y;
+    const long long tile0 = (long long)blockIdx.x * kTile;
+    const int n_tile = (int)((d.n_out - tile0) < kTile ? (d.n_out - tile0) : kTile);
+    // absolute input range needed by this tile: [n_lo, n_hi]
+    const unsigned long long o_first = d.o0 + (unsigned long long)tile0, o_last = o_first + (unsigned long long)(n_tile - 1);
+    const unsigned long long n_hi = (o_last * (unsigned long long)d.M) / (unsigned long long)d.L;
+    const unsigned long long n_lo = (o_first * (unsigned long long)d.M) / (unsigned long long)d.L - (unsigned long long)(d.T - 1);
+    const int n_win = (int)(n_hi - n_lo + 1);
+    const unsigned long long inc = phase_inc[k];
+    for (int i = threadIdx.x; i < n_win; i += 256) {
+        const unsigned long long n_abs = n_lo + (unsigned long long)i;
+        const float2 x = win[n_abs - d.n_base];
+        // phase in turns = frac(n_abs * f_k / fs_in), exact in 64-bit modular arithmetic, then one rounding to float
+        const unsigned int ph = (unsigned int)((n_abs * inc) >> 32);
+        float s, c;
+        sincospif((float)ph * 4.656612873077393e-10f /* 2^-31: argument in units of pi */, &s, &c);
+        xs[i] = make_float2(fmaf(x.x, c, x.y * s), fmaf(x.y, c, -(x.x * s)));   // x * (cos - j sin)
+    }
+    __syncthreads();
+    for (int oo = threadIdx.x; oo < n_tile; oo += 256) {
+        const unsigned long long o = o_first + (unsigned long long)oo;
+        const unsigned long long om = o * (unsigned long long)d.M;
+        const int n0 = (int)(om / (unsigned long long)d.L - n_lo);
+        const int p = (int)(om % (unsigned long long)d.L);
+        float ar[4] = {0.f, 0.f, 0.f, 0.f}, ai[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* tp = taps + p;
+        for (int t = 0; t < d.T; t += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float h = tp[(size_t)(t + u) * d.L];
+                const float2 x = xs[n0 - t - u];
+                ar[u] = fmaf(h, x.x, ar[u]); ai[u] = fmaf(h, x.y, ai[u]);
+            }
+        }
+        out[(size_t)k * d.n_out + tile0 + oo] = make_float2((ar[0] + ar[2]) + (ar[1] + ar[3]), (ai[0] + ai[2]) + (ai[1] + ai[3]));
+    }
+}
+
+double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    for (int k = 1; k < 64; k++) { term *= (x / (2.0 * k)) * (x / (2.0 * k)); sum += term; if (term < 1e-18 * sum) break; }
+    return sum;
+}
+
+thread_local std::string g_chan_error;
+
+}  // namespace
+
+struct fmd_channelizer_s {
+    int device = 0;
+    int L = 0, M = 0, T = 0, C = 0;
+    double fs_in = 0, fs_out = 0;
+    size_t max_in = 0;
+    unsigned long long n_abs = 0;     // absolute index of the next input sample
+    unsigned long long o_abs = 0;     // absolute index of the next output sample
+    float2* win = nullptr;            // [T-1 + max_in]
+    float* taps = nullptr;            // [T][L]
+    unsigned long long* inc = nullptr;
+    std::vector<float> h_taps;
+    std::string err;
+};
+
+static int chan_fail(fmd_channelizer h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    if (h) h->err = buf; else g_chan_error = buf;
+    return code;
+}
+
+extern "C" {
+
+int fmd_chan_design(double fs_in, double fs_out, int taps_per_phase, float* taps /* [T][L], may be NULL */, int* L_out, int* M_out) {
+    if (!(fs_in > 0) || !(fs_out > 0) || fs_out > fs_in || taps_per_phase <= 0 || taps_per_phase % 4 != 0) return FMD_ERR_ARG;
+    const long long a = llround(fs_out), b = llround(fs_in);
+    if (std::fabs(fs_out - (double)a) > 1e-9 || std::fabs(fs_in - (double)b) > 1e-9) return FMD_ERR_ARG;   // integer rates only
+    const long long g = std::gcd(a, b);
+    const long long L = a / g, M = b / g;
+    if (L > 64 || M > (1 << 20)) return FMD_ERR_ARG;
+    if (L_out) *L_out = (int)L;
+    if (M_out) *M_out = (int)M;
+    if (!taps) return FMD_OK;
+    // Kaiser-windowed sinc at the up-sampled rate L*fs_in, cut-off fs_out/2, DC gain L (makes up for the zero-stuffing)
+    const int T = taps_per_phase, N = (int)L * T;
+    const double fc = 0.5 / (double)M;           // cut-off (fs_out / 2) as a fraction of the up-sampled rate: (fs_out/2) / (L fs_in)
+    const double beta = 5.65326;                 // 60 dB
+    const double mid = 0.5 * (N - 1), i0b = bessel_i0(beta);
+    std::vector<double> h(N);
+    double sum = 0.0;
+    for (int n = 0; n < N; n++) {
+        const double x = (double)n - mid;
+        const double s = (x == 0.0) ? 2.0 * fc : std::sin(2.0 * M_PI * fc * x) / (M_PI * x);
+        const double r = x / mid;
+        h[n] = s * bessel_i0(beta * std::sqrt(std::max(0.0, 1.0 - r * r))) / i0b;
+        sum += h[n];
+    }
+    for (int n = 0; n < N; n++) {
+        const int p = n % (int)L, t = n / (int)L;
+        taps[(size_t)t * L + p] = (float)(h[n] * (double)L / sum);
+    }
+    return FMD_OK;
+}
+
+int fmd_chan_create(const fmd_chan_config* cfg, fmd_channelizer* out) {
+    if (!cfg || !out || cfg->n_stations <= 0 || !cfg->center_hz || cfg->max_input_samples <= 0) return chan_fail(nullptr, FMD_ERR_ARG, "bad channeliser configuration");
+    if (fmd_device_count() <= 0) return chan_fail(nullptr, FMD_ERR_NO_DEVICE, "no gfx950 device");
+    int dev = cfg->device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return chan_fail(nullptr, FMD_ERR_DEVICE, "hipGetDevice failed");
+    const int T = cfg->taps_per_phase > 0 ? cfg->taps_per_phase : 640;
+    int L = 0, M = 0;
+    if (fmd_chan_design(cfg->fs_in, cfg->fs_out, T, nullptr, &L, &M) != FMD_OK) return chan_fail(nullptr, FMD_ERR_ARG, "unsupported rates %g -> %g (need integer rates, L <= 64)", cfg->fs_in, cfg->fs_out);
+    if ((long long)kTile * M / L + T + 2 > kMaxWindow) return chan_fail(nullptr, FMD_ERR_ARG, "decimation %d/%d with %d taps per phase needs a larger staging window", M, L, T);
+    fmd_channelizer h = new fmd_channelizer_s();
+    h->device = dev; h->L = L; h->M = M; h->T = T; h->C = cfg->n_stations; h->fs_in = cfg->fs_in; h->fs_out = cfg->fs_out;
+    h->max_in = (size_t)cfg->max_input_samples;
+    h->h_taps.resize((size_t)T * L);
+    fmd_chan_design(cfg->fs_in, cfg->fs_out, T, h->h_taps.data(), nullptr, nullptr);
+    std::vector<unsigned long long> inc(h->C);
+    for (int k = 0; k < h->C; k++) {
+        double fr = cfg->center_hz[k] / cfg->fs_in;
+        if (!(std::fabs(fr) < 0.5)) { delete h; return chan_fail(nullptr, FMD_ERR_ARG, "station %d centre %g Hz is outside +-fs_in/2", k, cfg->center_hz[k]); }
+        fr -= std::floor(fr);                                       // [0, 1) turns per sample
+        inc[k] = (unsigned long long)std::llround(std::ldexp(fr, 63)) << 1;   // fr * 2^64, even
+    }
+    bool ok = hipSetDevice(dev) == hipSuccess;
+    ok = ok && hipMalloc(&h->win, sizeof(float2) * (h->max_in + (size_t)T)) == hipSuccess;
+    ok = ok && hipMalloc(&h->taps, sizeof(float) * h->h_taps.size()) == hipSuccess;
+    ok = ok && hipMalloc(&h->inc, sizeof(unsigned long long) * h->C) == hipSuccess;
+    ok = ok && hipMemset(h->win, 0, sizeof(float2) * (h->max_in + (size_t)T)) == hipSuccess;
+    ok = ok && hipMemcpy(h->taps, h->h_taps.data(), sizeof(float) * h->h_taps.size(), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(h->inc, inc.data(), sizeof(unsigned long long) * h->C, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { fmd_chan_destroy(h); return chan_fail(nullptr, FMD_ERR_DEVICE, "device allocation failed"); }
+    *out = h;
+    return FMD_OK;
+}
+
+int fmd_chan_destroy(fmd_channelizer h) {
+    if (!h) return FMD_ERR_ARG;
+    (void)hipSetDevice(h->device);
+    if (h->win) (void)hipFree(h->win);
+    if (h->taps) (void)hipFree(h->taps);
+    if (h->inc) (void)hipFree(h->inc);
+    delete h;
+    return FMD_OK;
+}
+
+int fmd_chan_info(fmd_channelizer h, int* L, int* M, int* taps_per_phase, int* n_stations) {
+    if (!h) return FMD_ERR_ARG;
+    if (L) *L = h->L;
+    if (M) *M = h->M;
+    if (taps_per_phase) *taps_per_phase = h->T;
+    if (n_stations) *n_stations = h->C;
+    return FMD_OK;
+}
+
+int fmd_chan_get_taps(fmd_channelizer h, float* taps, size_t cap_floats) {
+    if (!h || !taps || cap_floats < h->h_taps.size()) return FMD_ERR_ARG;
+    std::memcpy(taps, h->h_taps.data(), sizeof(float) * h->h_taps.size());
+    return FMD_OK;
+}
+
+int fmd_chan_reset(fmd_channelizer h) {
+    if (!h) return FMD_ERR_ARG;
+    if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "synchronise failed");
+    if (hipMemset(h->win, 0, sizeof(float2) * (h->max_in + (size_t)h->T)) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "memset failed");
+    h->n_abs = 0; h->o_abs = 0;
+    return FMD_OK;
+}
+
+int fmd_chan_process_cf32_dev(fmd_channelizer h, const float* d_wide, size_t n_in, float* d_out, size_t out_capacity_per_station, size_t* n_out, void* stream) {
+    if (!h || !d_wide || !d_out || !n_out) return FMD_ERR_ARG;
+    if (n_in == 0 || n_in > h->max_in) return chan_fail(h, FMD_ERR_SIZE, "n_in %zu outside (0, %zu]", n_in, h->max_in);
+    if ((n_in * (size_t)h->L) % (size_t)h->M != 0) return chan_fail(h, FMD_ERR_SIZE, "n_in must be a multiple of %d so that a whole number of output samples results", h->M / std::gcd(h->L, h->M));
+    const size_t no = n_in * (size_t)h->L / (size_t)h->M;
+    if (no > out_capacity_per_station) return chan_fail(h, FMD_ERR_SIZE, "output capacity %zu < %zu", out_capacity_per_station, no);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipSetDevice(h->device) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "hipSetDevice failed");
+    const int T = h->T;
+    // window = [T-1 history samples][this block]; win[0] has absolute input index n_abs - (T-1)
+    if (hipMemcpyAsync(h->win + (T - 1), d_wide, sizeof(float2) * n_in, hipMemcpyDeviceToDevice, s) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "staging copy failed");
+    ChanDims d{h->L, h->M, T, h->C, (long long)no, h->o_abs, h->n_abs - (unsigned long long)(T - 1)};
+    // outputs o0 .. o0+no-1 need inputs up to floor((o0+no-1) M / L) <= n_abs + n_in - 1 by construction
+    hipLaunchKernelGGL(k_channelize, dim3((unsigned)((no + kTile - 1) / kTile), (unsigned)h->C), dim3(256), 0, s, d, h->win, h->taps, h->inc,
+                       reinterpret_cast<float2*>(d_out));
+    if (hipGetLastError() != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "k_channelize launch failed");
+    // keep the last T-1 input samples as the next call's history
+    if (hipMemcpyAsync(h->win, h->win + n_in, sizeof(float2) * (size_t)(T - 1), hipMemcpyDeviceToDevice, s) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "history copy failed");
+    h->n_abs += n_in; h->o_abs += no;
+    *n_out = no;
+    return FMD_OK;
+}
+
+const char* fmd_chan_last_error(fmd_channelizer h) { return h ? h->err.c_str() : g_chan_error.c_str(); }
+
+}  // extern "C"

@@ -172,6 +172,38 @@ int fmd_get_spec_stats(fmd_handle h, uint64_t* out8, int reset);
 int fmd_profile_enable(fmd_handle h, int on);
 int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out);
 
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Wideband channeliser (SURVEY.md §8f row 3 / BASELINE configs[4]; NOT part of the reference, which tunes one station in
+ * the RTL-SDR hardware): splits one wideband cf32 capture into n_stations channels at fs_out, laid out [C][n_out] cf32 —
+ * the input layout of fmd_process_cf32_dev.  Per station: mix the centre frequency to 0, then a rational polyphase
+ * decimator L/M = fs_out/fs_in (256 k / 10 M = 16 / 625) built from one Kaiser-windowed prototype (cut-off fs_out / 2,
+ * 60 dB).  Streaming: histories and the mixers' phases carry over from call to call.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct fmd_channelizer_s* fmd_channelizer;
+typedef struct {
+    double        fs_in;             /* wideband sample rate, integer Hz */
+    double        fs_out;            /* per-station rate handed to the demodulator, integer Hz (256000) */
+    int           n_stations;
+    const double* center_hz;         /* [n_stations] station centres relative to the capture's centre, |f| < fs_in / 2 */
+    int           taps_per_phase;    /* 0 = default (640), multiple of 4 */
+    long long     max_input_samples; /* largest n_in of a process call */
+    int           device;            /* HIP device ordinal, -1 = current */
+} fmd_chan_config;
+
+/* host-only filter design (no GPU needed): L/M and, if taps != NULL, the prototype stored [t][p] (t = tap within phase p) */
+int fmd_chan_design(double fs_in, double fs_out, int taps_per_phase, float* taps, int* L, int* M);
+int fmd_chan_create(const fmd_chan_config* cfg, fmd_channelizer* out);
+int fmd_chan_destroy(fmd_channelizer h);
+int fmd_chan_reset(fmd_channelizer h);
+int fmd_chan_info(fmd_channelizer h, int* L, int* M, int* taps_per_phase, int* n_stations);
+int fmd_chan_get_taps(fmd_channelizer h, float* taps, size_t cap_floats);
+/* d_wide: [n_in][2] cf32 on the device; n_in * L must be a multiple of M (625 input samples per 16 outputs at 10 M -> 256 k).
+ * d_out: [n_stations][*n_out][2] cf32 on the device.  Asynchronous on `stream`. */
+int fmd_chan_process_cf32_dev(fmd_channelizer h, const float* d_wide, size_t n_in, float* d_out, size_t out_capacity_per_station,
+                              size_t* n_out, void* stream);
+const char* fmd_chan_last_error(fmd_channelizer h);
+
 #ifdef __cplusplus
 }
 #endif
