@@ -359,8 +359,8 @@ def main() -> None:
         "channels_at_realtime": value * 1e6 / fs,
         "msa_per_gpu": value / world,
         "roofline": roofline,
-        # serial loops: 32-sample chunks (x wavefronts) in the timed region, how many ran with the general forms
-        # (loop not in lock, or a speculated chunk replayed) instead of the locked-loop short forms — same results either way
+        # pilot PLL kernel in the timed region: samples committed per 16-sample speculative span, chunks that fell back to the
+        # plain serial iteration, spans redone with the reference forms — same results either way
         "speculation": spec,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -291,11 +291,11 @@ class BatchDemod:
         self._check(self.L.fmd_profile_enable(self.h, int(on)))
 
     def spec_stats(self, reset: bool = False) -> dict:
-        """Speculation counters of the serial loops (fmd_get_spec_stats), in 16-sample chunks summed over wavefronts."""
+        """Speculation counters of the pilot PLL kernel (fmd_get_spec_stats) since creation / the last reset."""
         a = np.zeros(8, np.uint64)
         self._check(self.L.fmd_get_spec_stats(self.h, a.ctypes.data_as(C.c_void_p), 1 if reset else 0))
-        out = {"pll": {"chunks": int(a[0]), "general": int(a[1]), "replayed": int(a[2])},
-               "rds": {"chunks": int(a[4]), "general": int(a[5])}}
+        out = {"pll": {"chunks": int(a[0]), "serial_chunks": int(a[1]), "exact_spans": int(a[2]), "spans": int(a[3]), "samples": int(a[4]),
+                       "samples_per_span": float(a[4]) / float(a[3]) if a[3] else 0.0}}
         if a[7]:
             out["pll_clock_mhz"] = float(a[6]) / float(a[7]) * 100.0
         return out

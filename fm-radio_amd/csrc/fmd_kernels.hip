@@ -348,207 +348,105 @@ __device__ __forceinline__ float pll_step(PllState& s, float p, float q, const L
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Speculative form of the same iteration for a loop that is in lock.  A lone wavefront per SIMD issues one instruction
-// every ~4 cycles and waits ~6 cycles on a dependent result, so the loop's duration is max(4 x instructions, 6 x chain
-// length).  pll_step (the reference iteration) is a 78-operation err -> err chain; pll_step_locked cuts the chain to ~45
-// and the instruction count to ~68 per sample:
-//   * the integrator / control clamps are skipped (shown not to bind for the whole chunk by pll_chunk_precheck),
-//   * x - round_half_away(x) becomes x - rndne(x) (equal unless x is an exact tie, detected from the chebyshev
-//     argument: wrapped phase == +-0.5  <=>  z - 0.25 == 0),
-//   * the phase detector is atan2f's first range with an unscaled division (fmd_math.h div_unscaled), valid for
-//     x in [2^-28, ~2e8) and 2^-29 <= |y/x| < 7/16, i.e. (y/x)^2 in [2^-58, 49/256) — both windows are 0x1bc40000 wide
-//     in the float's bit pattern, so one unsigned max tracks both,
-//   * TWO LANES PER CHANNEL: the iteration contains two pairs of structurally identical, mutually independent
-//     polynomial evaluations (chebyshev sine of the phase and of phase + 1/4; the odd and even halves s1 / s2 of the
-//     arctangent series).  The even lane of a pair evaluates the first of each, the odd lane the second, with the same
-//     instructions and per-lane constants, and they exchange the results with DPP quad permutes.  Everything else is
-//     computed redundantly (identically) by both lanes.  A wavefront therefore carries 32 channels.
-// Validity is accumulated in VALU registers only (a v_cmp -> SALU round trip stalls an in-order wave ~18 cycles) and
-// tested once per 16-sample chunk; a chunk with any invalid lane is replayed with pll_step.  Constants live in VGPRs:
-// a 32-bit literal in the instruction stream costs a lone wave ~2.7 extra cycles per instruction.
+// k_pilot_pll — frequency-speculative, time-parallel evaluation of the pilot PLL.
+//
+// The loop is a strictly serial recurrence: err_{t-1} -> loop filter -> frequency word F_t -> NCO phase tph_t -> phase
+// detector -> err_t, 78 dependent operations per sample as the reference writes it, and a lone wavefront spends ~6 cycles on
+// every dependent operation (4 on every instruction) whatever its width.  But F_t is a float near -19000 (ulp 2^-9) driven by
+// a heavily low-passed error: in lock it changes on ~0.5 % of samples.  So sixteen lanes evaluate sixteen consecutive samples
+// of one channel AT ONCE under the assumption "F stays what it is for the first of them", and the assumption is then checked
+// exactly:
+//   (A) every lane: S_0 = U(state, err_prev), F = frequency word of the span's first sample  (exact, no assumption)
+//   (B) every lane: the phase recurrence tph <- wrap(tph + F Ts), 16 steps; lane j keeps step j     (3 dependent ops per step)
+//   (C) lane j: its own sample's phase detector -> err_j          (the expensive part: two chebyshev sines, atan2; in parallel)
+//   (D) every lane: the loop filter over err_0..err_14 (4 dependent ops per step); lane i keeps the filter state S_i and
+//       decides whether S_i still yields F.  A ballot gives the group the index m of its first sample that does not:
+//       samples 0..m-1 are exactly what the serial loop would have produced (sample 0 always is) and are committed; the
+//       state to resume from sits in lane m-1 and is fetched with ds_bpermute.  The next span starts at sample m.
+// Nothing is approximated and nothing is replayed on a mis-speculation: a span just commits fewer samples (15.2 of 16 on
+// average in lock).  The serial work left per sample is (B) + (D), 7 dependent operations instead of 78.
+//
+// (C) uses short forms that equal the reference arithmetic on a locked loop's operands — x - rndne(x) for the phase wraps
+// (equal unless x is an exact tie, visible as z - 1/4 == 0 in the chebyshev argument), atan2f's first range with an unscaled
+// division (x in [2^-28, ~2e8), (y/x)^2 in [2^-58, 49/256): both windows 0x1bc40000 wide in the bit pattern) — and every lane
+// reports whether its operands were inside; if a lane that matters was not, the whole wavefront redoes (B)+(C) for that span
+// with the reference forms.  (D) runs the integrator unclamped and checks at both ends of the span that the clamp could not
+// have acted (it moves < 4e-6 per sample); otherwise the span is verified with the exact predicated loop.
+//
+// A wavefront out of lock (acquisition, a station without pilot) commits ~1 sample per span; after a chunk that needed more
+// than 24 spans the wavefront runs the next chunks with the plain serial iteration (pll_step), backing off exponentially.
+//
+// Layout: one wavefront = 4 channels x 16 lanes, one workgroup = one wavefront (14 KB LDS, ~150 VGPRs: fits any hole a
+// retiring FIR workgroup leaves).  128-sample chunks; LDS rings of two chunks per channel for the pilot samples and the
+// results; the chunk after next is in flight in 4 float4 registers per lane; all global traffic is 16-byte, row-contiguous.
+// Constants live in VGPRs (a 32-bit literal costs a lone wave ~2.7 cycles per instruction).
 // ---------------------------------------------------------------------------------------------------------------
 struct PllConsts {
-    float b0, a0, b1, c001, ktsi, m100, m19000, ts, q25 /* odd lane 1/4, even lane -0 */, mq25, c5, c4, c3, c2, c1, c0;
-    float k0, k1, k2, k3, k4, k5;   // arctangent series, this lane's half: even lane a10,a8,a6,a4,a2,a0 (s1); odd lane 0,a9,a7,a5,a3,a1 (s2)
+    float b0, a0, b1, c001, ktsi, m100, m19000, ts, q25, mq25, c5, c4, c3, c2, c1, c0;
+    float a10, a8, a6, a4, a2, a0t, a9, a7, a5, a3, a1;
     uint32_t xlo, zlo;
-    bool odd;
 };
 #define FMD_OPAQUE_F(dst, val) { float t_ = (val); asm volatile("" : "+v"(t_)); dst = t_; }
 #define FMD_OPAQUE_U(dst, val) { uint32_t t_ = (val); asm volatile("" : "+v"(t_)); dst = t_; }
-__device__ __forceinline__ PllConsts make_pll_consts(const LoopCoeffs& k, bool odd) {
+__device__ __forceinline__ PllConsts make_pll_consts(const LoopCoeffs& k) {
     PllConsts c;
     FMD_OPAQUE_F(c.b0, k.pll_b0) FMD_OPAQUE_F(c.a0, k.pll_a0) FMD_OPAQUE_F(c.b1, k.pll_b1) FMD_OPAQUE_F(c.c001, 0.01f)
     FMD_OPAQUE_F(c.ktsi, 0.1f * (1.0f / 128000.0f)) FMD_OPAQUE_F(c.m100, -100.0f) FMD_OPAQUE_F(c.m19000, -19000.0f)
-    FMD_OPAQUE_F(c.ts, 1.0f / 128000.0f) FMD_OPAQUE_F(c.q25, odd ? 0.25f : -0.0f) FMD_OPAQUE_F(c.mq25, -0.25f)
+    FMD_OPAQUE_F(c.ts, 1.0f / 128000.0f) FMD_OPAQUE_F(c.q25, 0.25f) FMD_OPAQUE_F(c.mq25, -0.25f)
     FMD_OPAQUE_F(c.c5, 3.20396066f) FMD_OPAQUE_F(c.c4, -14.07150173f) FMD_OPAQUE_F(c.c3, 38.50016403f)
     FMD_OPAQUE_F(c.c2, -67.07687378f) FMD_OPAQUE_F(c.c1, 64.83583069f) FMD_OPAQUE_F(c.c0, -25.13274193f)
-    FMD_OPAQUE_F(c.k0, odd ? 0.0f : bits_f32(0x3c8569d7u))
-    FMD_OPAQUE_F(c.k1, odd ? bits_f32(0xbd15a221u) : bits_f32(0x3d4bda59u))
-    FMD_OPAQUE_F(c.k2, odd ? bits_f32(0xbd6ef16bu) : bits_f32(0x3d886b35u))
-    FMD_OPAQUE_F(c.k3, odd ? bits_f32(0xbd9d8795u) : bits_f32(0x3dba2e6eu))
-    FMD_OPAQUE_F(c.k4, odd ? bits_f32(0xbde38e38u) : bits_f32(0x3e124925u))
-    FMD_OPAQUE_F(c.k5, odd ? bits_f32(0xbe4ccccdu) : bits_f32(0x3eaaaaabu))
+    FMD_OPAQUE_F(c.a10, bits_f32(0x3c8569d7u)) FMD_OPAQUE_F(c.a8, bits_f32(0x3d4bda59u)) FMD_OPAQUE_F(c.a6, bits_f32(0x3d886b35u))
+    FMD_OPAQUE_F(c.a4, bits_f32(0x3dba2e6eu)) FMD_OPAQUE_F(c.a2, bits_f32(0x3e124925u)) FMD_OPAQUE_F(c.a0t, bits_f32(0x3eaaaaabu))
+    FMD_OPAQUE_F(c.a9, bits_f32(0xbd15a221u)) FMD_OPAQUE_F(c.a7, bits_f32(0xbd6ef16bu)) FMD_OPAQUE_F(c.a5, bits_f32(0xbd9d8795u))
+    FMD_OPAQUE_F(c.a3, bits_f32(0xbde38e38u)) FMD_OPAQUE_F(c.a1, bits_f32(0xbe4ccccdu))
     FMD_OPAQUE_U(c.xlo, 0x31800000u) FMD_OPAQUE_U(c.zlo, 0x22800000u)
-    c.odd = odd;
     return c;
 }
-
-struct PllChecks { float tie_min; uint32_t range_max; };
 static constexpr uint32_t kRangeWindow = 0x1bc40000u;   // bits(49/256) - bits(2^-58)
 
-// DPP quad permutes between the two lanes of a channel pair (lanes 2j, 2j+1)
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+// chebyshev_sine (scalar association) with register constants; zq = z - 1/4 is returned for the tie test
+__device__ __forceinline__ float cheb_sine_locked(float x, const PllConsts& c, float& zq) {
+    const float z = x * x;
+    float p = fmaf(c.c5, z, c.c4);
+    p = fmaf(p, z, c.c3); p = fmaf(p, z, c.c2); p = fmaf(p, z, c.c1); p = fmaf(p, z, c.c0);
+    zq = z + c.mq25;
+    return (zq * x) * p;
 }
-static constexpr int kDppEven = 0xA0;   // quad_perm [0,0,2,2]: both lanes read the even lane
-static constexpr int kDppOdd = 0xF5;    // quad_perm [1,1,3,3]: both lanes read the odd lane
-static constexpr int kDppSwap = 0xB1;   // quad_perm [1,0,3,2]: each lane reads its partner
 
 // atan2f(y, x) for x in [2^-28, ~2e8) and 2^-29 <= |y/x| < 7/16 (a locked loop's phase error): the published algorithm
-// reduces to t - t (s1 + s2) with t = y / x (its first range, which is odd-symmetric, so no quadrant or sign selects), and
-// the division needs neither operand scaling nor special-value fix-up.  Both lanes of a pair hold the same (y, x); the even
-// lane evaluates s1 = z (a0 + w (a2 + w (a4 + w (a6 + w (a8 + w a10))))), the odd lane s2 = w (a1 + w (a3 + w (a5 + w (a7 + w a9))))
-// (its first level is a9 + w 0 = a9 exactly), then each adds its partner's half (IEEE addition commutes).
-__device__ __forceinline__ float atan2f_locked(float y, float x, const PllConsts& c, PllChecks& ck) {
+// reduces to t - t (s1 + s2) with t = y / x (its first range, odd-symmetric: no quadrant or sign selects), and the division
+// needs neither operand scaling nor special-value fix-up.  ok reports whether the operands were inside.
+__device__ __forceinline__ float atan2f_locked(float y, float x, const PllConsts& c, bool& ok) {
     const float t = div_unscaled(y, x);
-    const float z = t * t;
-    const float w = z * z;
-    ck.range_max = max(max(ck.range_max, f32_bits(x) - c.xlo), f32_bits(z) - c.zlo);
-    float s = c.k1 + w * c.k0;
-    s = c.k2 + w * s;
-    s = c.k3 + w * s;
-    s = c.k4 + w * s;
-    s = c.k5 + w * s;
-    s = (c.odd ? w : z) * s;
-    const float sum = s + dpp_quad<kDppSwap>(s);
-    return t - t * sum;
+    const float z = t * t, w = z * z;
+    ok = max(f32_bits(x) - c.xlo, f32_bits(z) - c.zlo) < kRangeWindow;
+    float s1 = c.a8 + w * c.a10; s1 = c.a6 + w * s1; s1 = c.a4 + w * s1; s1 = c.a2 + w * s1; s1 = c.a0t + w * s1; s1 = z * s1;
+    float s2 = c.a7 + w * c.a9; s2 = c.a5 + w * s2; s2 = c.a3 + w * s2; s2 = c.a1 + w * s2; s2 = w * s2;
+    return t - t * (s1 + s2);
 }
 
-// Holds for the whole chunk if it holds at its start, given that every err the chunk produces is < 0.42 in magnitude
-// (implied by the range check): the loop filter is a convex combination (|lpf| <= max of its inputs), the integrator
-// moves by < 4e-6 per sample, so |integ| <= 0.9001, |integ + 0.01 lpf| <= 0.95 < 1 and |t + Ts freq| <= 0.65 < 1.5.
-__device__ __forceinline__ bool pll_chunk_precheck(const PllState& s, const LoopCoeffs& k) {
-    const bool convex = (k.pll_b0 >= 0.0f) && (k.pll_b1 >= 0.0f) && (k.pll_a0 >= 0.0f) && ((k.pll_b0 + k.pll_b1) + k.pll_a0 <= 1.0001f);
-    return convex && (fabsf(s.integ) <= 0.9f) && (fabsf(s.lx1) <= 4.0f) && (fabsf(s.ly1) <= 4.0f) && (fabsf(s.err) <= 4.0f) && (fabsf(s.tph) <= 0.5f);
-}
+static constexpr int kPllK = 16;              // lanes (= consecutive samples) per channel
+static constexpr int kPllG = kWave / kPllK;   // channels per wavefront
+static constexpr int kPllChunk = 128;         // samples per chunk
+static constexpr int kPllRing = 2 * kPllChunk;
+static constexpr int kPllSlowSpans = 24;      // a chunk that needed more spans than this is "out of lock"
+static constexpr int kSlowHoldMax = 16;       // longest run of serial chunks between two speculation attempts
 
-__device__ __forceinline__ float pll_step_locked(PllState& s, float p, float q, const PllConsts& c, PllChecks& ck) {
-    const float t0 = fmaf(s.lx1, c.b0, s.ly1 * c.a0);
-    const float t1 = fmaf(s.err, c.b1, 0.0f);
-    const float lpf = (0.0f + t0) + t1;
-    s.lx1 = s.err; s.ly1 = lpf;
-    const float P = lpf * c.c001;
-    s.integ = fmaf(s.err, c.ktsi, s.integ);
-    const float PI_error = s.integ + P;
-    const float freq = fmaf(PI_error, c.m100, c.m19000);
-    const float yy = fmaf(freq, c.ts, s.tph);
-    s.tph = yy - rintf(yy);
-    // chebyshev_sine (scalar association): the odd lane of the pair takes sin(2 pi wrap(t + 1/4)); the even lane runs the
-    // same three instructions with -0 in place of 1/4, which leave t unchanged bit for bit (t + -0 = t, |t| <= 1/2 so
-    // rndne(t) = +-0), i.e. sin(2 pi t) — no select on the dependency chain
-    const float dc = s.tph + c.q25;
-    const float xr = dc - rintf(dc);
-    const float z = xr * xr;
-    float poly = fmaf(c.c5, z, c.c4);
-    poly = fmaf(poly, z, c.c3);
-    poly = fmaf(poly, z, c.c2);
-    poly = fmaf(poly, z, c.c1);
-    poly = fmaf(poly, z, c.c0);
-    const float zq = z + c.mq25;
-    const float sn = (zq * xr) * poly;
-    ck.tie_min = fminf(ck.tie_min, fabsf(zq));   // wrapped phase == +-1/2 <=> zq == 0: the rndne shortcut was not exact
-    const float ps = dpp_quad<kDppEven>(sn), pc = dpp_quad<kDppOdd>(sn);
-    const float res_im = fmaf(ps, p, q * pc);
-    const float res_re = fmaf(p, pc, -(q * ps));
-    s.err = atan2f_locked(res_im, res_re, c, ck);
-    return s.tph;
-}
-
-static constexpr int kSlowHoldMax = 64;   // longest run of general-form chunks between two speculation attempts
-
-// ---------------------------------------------------------------------------------------------------------------
-// 16-sample chunk staging for the two-wave pilot PLL kernel: 32 channels per workgroup (two lanes per channel in the
-// recurrence wave), 4 float4 registers per chunk in the mover wave.
-// ---------------------------------------------------------------------------------------------------------------
-static constexpr int kCh16 = 16;
-static constexpr int kRow16 = kCh16 + 2;   // float2 row stride (144 B) of a transposed 16-sample cf32 chunk
-static constexpr int kPllCh = 32;          // channels per k_pilot_pll workgroup
-struct Chunk16 { float4 v0, v1, v2, v3; };
-#define FMD_FOR4(X) X(0) X(1) X(2) X(3)
-__device__ __forceinline__ Chunk16 chunk16_load(const float2* __restrict__ base, int n, int c0, int C, int t0) {
-    const int lane = threadIdx.x & (kWave - 1), row = lane >> 3, col = lane & 7;
-    Chunk16 r;
-#define FMD_LD4(k) { int ch = c0 + 8 * k + row; ch = ch < C ? ch : C - 1; \
-                     r.v##k = *reinterpret_cast<const float4*>(base + (size_t)ch * n + t0 + 2 * col); }
-    FMD_FOR4(FMD_LD4)
-#undef FMD_LD4
-    return r;
-}
-__device__ __forceinline__ void chunk16_store(const Chunk16& r, float2* lds) {
-    const int lane = threadIdx.x & (kWave - 1), row = lane >> 3, col = lane & 7;
-#define FMD_ST4(k) *reinterpret_cast<float4*>(lds + (8 * k + row) * kRow16 + 2 * col) = r.v##k;
-    FMD_FOR4(FMD_ST4)
-#undef FMD_ST4
-}
-// drain 16 f32 results per channel, stored compactly at the start of each row of a chunk buffer, to out[C][n] at t0
-__device__ __forceinline__ void chunk16_flush_f(const float2* lds, float* __restrict__ out, int n, int c0, int C, int t0) {
-    const int lane = threadIdx.x & (kWave - 1), row = lane >> 2, col = lane & 3;
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int r = 16 * k + row, ch = c0 + r;
-        const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(lds + r * kRow16) + 4 * col);
-        if (ch < C) *reinterpret_cast<float4*>(out + (size_t)ch * n + t0 + 4 * col) = v;
-    }
-}
-
-// Workgroup = two wavefronts for 32 channels.  Wave 0 runs the recurrence (two lanes per channel, see pll_step_locked) and
-// touches only LDS; wave 1 (the mover) stages the next chunks HBM -> registers -> LDS and drains finished pll_dt chunks
-// LDS -> HBM.  A lone wave is bound by its own instruction issue, and a vector-memory instruction costs it tens of cycles
-// — hundreds when other stages' kernels keep the CU's memory pipeline busy — so the memory instructions are given to a
-// sibling on another SIMD; the two meet at one barrier per 16-sample chunk.
-// The workgroup is kept SMALL on purpose (9 KB of LDS, results written in place over consumed input; well under 150
-// VGPRs per wave): while the FIR stages' kernels fill every CU, a serial-stage workgroup that needs 52 KB and 2 x 256
-// registers waits >100 us for a hole (measured, tools/gap_probe.hip), one that fits the hole a retiring FIR workgroup
-// leaves starts at once.
-__global__ __launch_bounds__(2 * kWave) void k_pilot_pll(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
-                                                         float* __restrict__ state, LoopCoeffs k, int power_field,
-                                                         unsigned long long* __restrict__ spec_stats) {
-    __shared__ __attribute__((aligned(16))) float2 ring[2][kPllCh * kRow16];
-    const bool mover = threadIdx.x >= kWave;   // wave-uniform
-    const int lane = threadIdx.x & (kWave - 1), c0 = blockIdx.x * kPllCh;
-    const int n = d.n_fm_out, chunks = n / kCh16;
-
-    if (mover) {
-        // iteration ch (between barriers ch and ch+1): drain the results of chunk ch-1 from its slot, refill that slot with
-        // chunk ch+1 (loaded three iterations ago), issue the loads of chunk ch+4
-        auto load_or_last = [&](int ch) { return chunk16_load(pilot, n, c0, d.C, (ch < chunks ? ch : chunks - 1) * kCh16); };
-        Chunk16 r0 = load_or_last(0);
-        chunk16_store(r0, ring[0]);
-        Chunk16 ra = load_or_last(1), rb = load_or_last(2), rc = load_or_last(3);
-        auto move_chunk = [&](int ch, Chunk16& regs) {
-            float2* slot = ring[(ch + 1) & 1];
-            if (ch > 0) chunk16_flush_f(slot, pll_dt, n, c0, d.C, (ch - 1) * kCh16);
-            if (ch + 1 < chunks) chunk16_store(regs, slot);
-            if (ch + 4 < chunks) regs = load_or_last(ch + 4);
-        };
-        for (int ch = 0; ch < chunks; ch += 3) {
-            __syncthreads();
-            move_chunk(ch, ra);
-            if (ch + 1 < chunks) { __syncthreads(); move_chunk(ch + 1, rb); }
-            if (ch + 2 < chunks) { __syncthreads(); move_chunk(ch + 2, rc); }
-        }
-        __syncthreads();
-        chunk16_flush_f(ring[(chunks - 1) & 1], pll_dt, n, c0, d.C, (chunks - 1) * kCh16);
-        return;
-    }
-
+__global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
+                                                     float* __restrict__ state, LoopCoeffs k, int power_field,
+                                                     unsigned long long* __restrict__ spec_stats) {
+    constexpr int K = kPllK, G = kPllG, CH = kPllChunk, RING = kPllRing;
+    __shared__ __attribute__((aligned(16))) float2 xin[G][RING];   // pilot samples, ring by (sample index & 255)
+    __shared__ __attribute__((aligned(16))) float dts[G][RING];    // results, same ring
+    __shared__ __attribute__((aligned(16))) float ex[G][K + 4];    // [0] = err_prev, [1 + i] = err_i of the current span
+    __shared__ __attribute__((aligned(16))) float e1x[G][K + 4];   // fma(err_i, b1, 0)
     __builtin_amdgcn_s_setprio(3);  // latency-bound recurrence: win issue arbitration against co-resident FIR waves
     const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
-    const int c = c0 + (lane >> 1);            // lanes 2j and 2j+1 both carry channel c0 + j
-    const bool odd = (lane & 1) != 0;
+    const int lane = threadIdx.x, g = lane / K, j = lane % K;
+    const int c0 = blockIdx.x * G, c = c0 + g;
     const bool live = c < d.C;
     const int cs = live ? c : d.C - 1;
+    const int n = d.n_fm_out, chunks = n / CH;
     // AGC_Filter::process (agc.h:12-19) as compiled: target_gain = sqrt((target/sum) * N)
     float gain = st(state, S_AGC_PILOT_GAIN, d.C, cs);
     {
@@ -556,66 +454,178 @@ __global__ __launch_bounds__(2 * kWave) void k_pilot_pll(Dims d, const float2* _
         const float target_gain = sqrtf((1.0f / sum) * (float)n);
         gain = fmaf(target_gain - gain, 0.2f, gain);
     }
-    PllState S;
-    S.lx1 = st(state, S_PLL_X1, d.C, cs); S.ly1 = st(state, S_PLL_Y1, d.C, cs);
-    S.integ = st(state, S_PLL_INT, d.C, cs); S.err = st(state, S_PLL_ERR, d.C, cs); S.tph = st(state, S_PLL_T, d.C, cs);
-    const PllConsts kc = make_pll_consts(k, odd);
-    // a failed speculative chunk is replayed with the general forms; consecutive failures (a loop out of lock) back
-    // off exponentially so an unlocked wavefront pays at most a few percent for its attempts
-    int slow_left = 0, hold = 0, n_replayed = 0, n_general = 0;
-    for (int ch = 0; ch < chunks; ch++) {
-        // here: ring[ch & 1] holds chunk ch; the other slot holds the results of chunk ch - 1, which the mover now drains
-        __syncthreads();
-        float2* row = ring[ch & 1] + (lane >> 1) * kRow16;
-        float* dto = reinterpret_cast<float*>(row);   // result t goes to float t of the row: x[t/2] has been consumed by then
-        bool done = false;
-        if (slow_left == 0) {
-            PllState s = S;
-            PllChecks ck{1.0f, 0u};
-            float2 xs[kCh16];                         // the chunk is read before any result is written over it
-#pragma unroll
-            for (int t = 0; t < kCh16; t++) xs[t] = row[t];
-            float dts[kCh16];
-#pragma unroll
-            for (int t = 0; t < kCh16; t++) dts[t] = pll_step_locked(s, gain * xs[t].x, gain * xs[t].y, kc, ck);
-            const bool ok = pll_chunk_precheck(S, k) && (ck.tie_min != 0.0f) && (ck.range_max < kRangeWindow);
-            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
-                S = s; done = true; hold = 0;
-                if (!odd) {
-#pragma unroll
-                    for (int t = 0; t < kCh16; t += 4) *reinterpret_cast<float4*>(dto + t) = make_float4(dts[t], dts[t + 1], dts[t + 2], dts[t + 3]);
-                }
-            } else { slow_left = hold; hold = hold ? (2 * hold < kSlowHoldMax ? 2 * hold : kSlowHoldMax) : 1; n_replayed++; }
-        } else {
-            slow_left--;
+    // loop state, identical in the 16 lanes of a channel
+    float lx1 = st(state, S_PLL_X1, d.C, cs), ly1 = st(state, S_PLL_Y1, d.C, cs), integ = st(state, S_PLL_INT, d.C, cs);
+    float err_prev = st(state, S_PLL_ERR, d.C, cs), tph_prev = st(state, S_PLL_T, d.C, cs);
+    const PllConsts kc = make_pll_consts(k);
+    ex[g][0] = err_prev;
+
+    // global <-> LDS: lane (g, j) moves row g; chunk q of the pilot = 4 float4 (2 samples each) per lane
+    const int srow = c0 + g < d.C ? c0 + g : d.C - 1;
+    const float2* prow = pilot + (size_t)srow * n;
+    float4 pre0, pre1, pre2, pre3;
+    auto fetch = [&](int q) {
+        const int b0 = (q < chunks ? q : chunks - 1) * CH + 2 * j;
+        pre0 = *reinterpret_cast<const float4*>(prow + b0);
+        pre1 = *reinterpret_cast<const float4*>(prow + b0 + 32);
+        pre2 = *reinterpret_cast<const float4*>(prow + b0 + 64);
+        pre3 = *reinterpret_cast<const float4*>(prow + b0 + 96);
+    };
+    auto stash = [&](int q) {
+        float2* r = &xin[g][(q & 1) * CH + 2 * j];
+        *reinterpret_cast<float4*>(r) = pre0; *reinterpret_cast<float4*>(r + 32) = pre1;
+        *reinterpret_cast<float4*>(r + 64) = pre2; *reinterpret_cast<float4*>(r + 96) = pre3;
+    };
+    auto flush = [&](int q) {   // results of chunk q, all final
+        const float* r = &dts[g][(q & 1) * CH + 4 * j];
+        const float4 v0 = *reinterpret_cast<const float4*>(r), v1 = *reinterpret_cast<const float4*>(r + 64);
+        if (live) {
+            float* o = pll_dt + (size_t)c * n + (size_t)q * CH + 4 * j;
+            *reinterpret_cast<float4*>(o) = v0; *reinterpret_cast<float4*>(o + 64) = v1;
         }
-        if (!done) {   // general iteration, computed identically by both lanes of a pair (same address, same value)
-            n_general++;
-            float2 y = row[0];
-            for (int t = 0; t < kCh16; t++) {
-                const float2 yn = row[t + 1 < kCh16 ? t + 1 : t];
-                dto[t] = pll_step(S, gain * y.x, gain * y.y, k);
-                y = yn;
+    };
+    fetch(0); stash(0);
+    fetch(1); stash(1);
+    fetch(2);
+
+    int pos = 0;                 // next sample of this channel (absolute within the block); identical in its 16 lanes
+    int seq_left = 0, hold = 0;  // wave-uniform: serial chunks still to run / back-off
+    unsigned long long n_spans = 0, n_committed = 0, n_exact = 0, n_seq = 0;
+    for (int q = 0; q < chunks; q++) {
+        const int cend = (q + 1) * CH;
+        int spans = 0;
+        const bool speculative = seq_left == 0;
+        if (!speculative) {
+            // ---- out of lock: the plain serial iteration, computed identically by the 16 lanes of a channel ----
+            seq_left--; n_seq++;
+            PllState S{lx1, ly1, integ, err_prev, tph_prev};
+            while (__builtin_amdgcn_ballot_w64(pos < cend) != 0ull) {
+                if (pos < cend) {
+                    const float2 x = xin[g][pos & (RING - 1)];
+                    dts[g][pos & (RING - 1)] = pll_step(S, gain * x.x, gain * x.y, k);
+                    pos++;
+                }
+            }
+            lx1 = S.lx1; ly1 = S.ly1; integ = S.integ; err_prev = S.err; tph_prev = S.tph;
+            ex[g][0] = err_prev;
+        } else {
+            while (__builtin_amdgcn_ballot_w64(pos < cend) != 0ull) {
+                const bool active = pos < cend;
+                const int rem = n - pos;                             // samples left in the block for this channel
+                spans++;
+                // (A) S_0 = U(state, err_prev) and the exact frequency word of the span's first sample
+                float y1, ig;
+                {
+                    const float t0 = fmaf(lx1, kc.b0, ly1 * kc.a0);
+                    const float t1 = fmaf(err_prev, kc.b1, 0.0f);
+                    y1 = (0.0f + t0) + t1;
+                    ig = clampf(fmaf(err_prev, kc.ktsi, integ), -1.0f, 1.0f);
+                }
+                const float F = fmaf(clampf(ig + y1 * kc.c001, -1.0f, 1.0f), kc.m100, kc.m19000);
+                // (B) phase recurrence with constant F; lane j keeps the phase after j+1 steps
+                float tph = tph_prev, mine = 0.0f;
+#pragma unroll
+                for (int i = 0; i < K; i++) {
+                    const float yy = fmaf(F, kc.ts, tph);
+                    tph = yy - rintf(yy);
+                    mine = (i == j) ? tph : mine;
+                }
+                // (C) this lane's sample: phase detector with the locked short forms
+                const int t = active ? pos + j : j;
+                const float2 x = xin[g][t & (RING - 1)];
+                const float p = gain * x.x, q2 = gain * x.y;
+                const float dc = mine + kc.q25;
+                const float dt_cos = dc - rintf(dc);
+                float zq_s, zq_c;
+                const float ps = cheb_sine_locked(mine, kc, zq_s), pc = cheb_sine_locked(dt_cos, kc, zq_c);
+                bool in_range;
+                float e = atan2f_locked(fmaf(ps, p, q2 * pc), fmaf(p, pc, -(q2 * ps)), kc, in_range);
+                const bool lane_ok = in_range && (fminf(fabsf(zq_s), fabsf(zq_c)) != 0.0f);
+                if (__builtin_amdgcn_ballot_w64(active && !lane_ok && j < rem) != 0ull) {
+                    // a short form was outside its domain somewhere (loop out of lock, or an exact tie): reference forms for all
+                    n_exact++;
+                    float tp = tph_prev, mm = 0.0f;
+                    for (int i = 0; i < K; i++) { const float yy = fmaf(F, kc.ts, tp); tp = yy - round_half_away(yy); mm = (i == j) ? tp : mm; }
+                    float dcg = mm + 0.25f; dcg = dcg - round_half_away(dcg);
+                    const float psg = cheb_sine_scalar(mm), pcg = cheb_sine_scalar(dcg);
+                    e = fmd_atan2f(fmaf(psg, p, q2 * pcg), fmaf(p, pcg, -(q2 * psg)));
+                    mine = mm;
+                }
+                ex[g][j + 1] = e;
+                e1x[g][j] = fmaf(e, kc.b1, 0.0f);
+                if (active) dts[g][t & (RING - 1)] = mine;           // speculative; samples past the commit point are rewritten
+                float ev[K], t1v[K];
+#pragma unroll
+                for (int i = 0; i < K; i++) { ev[i] = ex[g][i + 1]; t1v[i] = e1x[g][i]; }
+                // (D) loop filter over the span, identically in every lane of the channel; lane i keeps S_i = (y1_i, ig_i)
+                float fy1 = y1, fig = ig, fx1 = err_prev, my_y1 = y1, my_ig = ig;
+#pragma unroll
+                for (int i = 1; i < K; i++) {
+                    const float t0 = fmaf(fx1, kc.b0, fy1 * kc.a0);
+                    fy1 = (0.0f + t0) + t1v[i - 1]; fx1 = ev[i - 1];
+                    fig = fmaf(ev[i - 1], kc.ktsi, fig);
+                    my_y1 = (i == j) ? fy1 : my_y1; my_ig = (i == j) ? fig : my_ig;
+                }
+                // the integrator moves < 4e-6 per sample: its clamp acted nowhere in the span iff both ends are well inside
+                const bool integ_clamped = !((fabsf(ig) <= 0.99f) && (fabsf(fig) <= 0.99f));
+                const float Fj = fmaf(clampf(my_ig + my_y1 * kc.c001, -1.0f, 1.0f), kc.m100, kc.m19000);
+                const bool ok_j = (f32_bits(Fj) == f32_bits(F)) && (j < rem);
+                const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok_j || j == 0);
+                int m = __builtin_ctz(~((unsigned int)(okm >> (g * K)) & 0xffffu) | 0x10000u);   // first invalid sample (16 = none)
+                float nx, ny, ni, ne, nt;
+                if (__builtin_amdgcn_ballot_w64(active && integ_clamped) != 0ull) {
+                    // a saturated integrator (never in lock): verify with the exact clamps, predicated
+                    float x1 = err_prev, yy1 = y1, ig2 = ig;
+                    bool valid = true;
+                    m = 1;
+                    for (int i = 1; i < K; i++) {
+                        const float ei = ex[g][i];
+                        const float t0 = fmaf(x1, k.pll_b0, yy1 * k.pll_a0), t1 = fmaf(ei, k.pll_b1, 0.0f);
+                        const float ny1 = (0.0f + t0) + t1;
+                        const float ni1 = clampf(fmaf(ei, 0.1f * (1.0f / 128000.0f), ig2), -1.0f, 1.0f);
+                        const float Fi = fmaf(clampf((ni1 + ny1 * 0.01f) * 1.0f, -1.0f, 1.0f), -100.0f, -19000.0f);
+                        valid = valid && (f32_bits(Fi) == f32_bits(F)) && (i < rem);
+                        if (valid) { x1 = ei; yy1 = ny1; ig2 = ni1; m = i + 1; }
+                    }
+                    nx = x1; ny = yy1; ni = ig2; ne = ex[g][m]; nt = dts[g][(pos + m - 1) & (RING - 1)];
+                } else {
+                    // resume state S_{m-1}, err_{m-1}, tph_{m-1}: held by lane m-1 of the channel
+                    const int src = (g * K + m - 1) * 4;
+                    ny = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_y1)));
+                    ni = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_ig)));
+                    ne = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(e)));
+                    nt = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(mine)));
+                    nx = ex[g][m - 1];                               // err_{m-2} (ex[g][0] = err_prev)
+                }
+                if (active) {
+                    lx1 = nx; ly1 = ny; integ = ni; err_prev = ne; tph_prev = nt; pos += m;
+                    if (j == 0) { n_spans++; n_committed += (unsigned long long)m; }
+                }
+                ex[g][0] = err_prev;
             }
         }
-        // The results must have landed in LDS before the mover reads them after the next barrier.  The compiler's own
-        // wait in front of the loop-header s_barrier went missing on this back edge (seen in the ISA and as stale last
-        // samples at 4096 channels), so it is spelled out.
+        // chunk q is final in every channel: drain it, refill its half of the ring with chunk q+2, prefetch chunk q+3
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        flush(q);
+        stash(q + 2);
+        fetch(q + 3);
+        if (speculative) {   // a speculative chunk that went badly sends the wavefront serial for a while, doubling each time in a row
+            if (spans > kPllSlowSpans) { seq_left = hold ? hold : 1; hold = hold ? (2 * hold < kSlowHoldMax ? 2 * hold : kSlowHoldMax) : 1; }
+            else hold = 0;
+        }
     }
-    __syncthreads();
-    if (live && !odd) {
+    if (live && j == 0) {
         st(state, S_AGC_PILOT_GAIN, d.C, c) = gain;
-        st(state, S_PLL_X1, d.C, c) = S.lx1; st(state, S_PLL_Y1, d.C, c) = S.ly1;
-        st(state, S_PLL_INT, d.C, c) = S.integ; st(state, S_PLL_ERR, d.C, c) = S.err; st(state, S_PLL_T, d.C, c) = S.tph;
+        st(state, S_PLL_X1, d.C, c) = lx1; st(state, S_PLL_Y1, d.C, c) = ly1;
+        st(state, S_PLL_INT, d.C, c) = integ; st(state, S_PLL_ERR, d.C, c) = err_prev; st(state, S_PLL_T, d.C, c) = tph_prev;
     }
-    if (lane == 0 && spec_stats) {   // chunks total / run with the general forms / speculated and replayed
-        atomicAdd(&spec_stats[0], (unsigned long long)chunks);
-        atomicAdd(&spec_stats[1], (unsigned long long)n_general);
-        atomicAdd(&spec_stats[2], (unsigned long long)n_replayed);
+    if (spec_stats) {
+        // per wavefront: chunks / chunks run serially / spans redone with the reference forms; per channel: spans, samples
+        if (lane == 0) { atomicAdd(&spec_stats[0], (unsigned long long)chunks); atomicAdd(&spec_stats[1], n_seq); atomicAdd(&spec_stats[2], n_exact); }
+        if (live && j == 0) { atomicAdd(&spec_stats[3], n_spans); atomicAdd(&spec_stats[4], n_committed); }
         // shader-clock cycles and 100 MHz real-time ticks this wavefront ran: their ratio is the core clock the power
         // management granted while the other stages' kernels ran beside it (DESIGN.md "Clocks")
-        if (blockIdx.x == 0) { atomicAdd(&spec_stats[6], __builtin_readcyclecounter() - clk0); atomicAdd(&spec_stats[7], __builtin_amdgcn_s_memrealtime() - rt0); }
+        if (lane == 0 && blockIdx.x == 0) { atomicAdd(&spec_stats[6], __builtin_readcyclecounter() - clk0); atomicAdd(&spec_stats[7], __builtin_amdgcn_s_memrealtime() - rt0); }
     }
 }
 
@@ -1068,21 +1078,21 @@ __global__ __launch_bounds__(256) void k_hilbert(Dims d, const float* __restrict
 
 __global__ void k_selftest_atan2(const float* __restrict__ y, const float* __restrict__ x, float* __restrict__ out,
                                  unsigned char* __restrict__ ok_out, size_t n) {
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ok_out) {   // the locked-loop short form (two lanes per element, as in k_pilot_pll) and its exactness predicate
-        const size_t i = tid >> 1, ic = i < n ? i : n - 1;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (ok_out) {   // the locked-loop short form of k_pilot_pll's phase detector and its domain predicate
         LoopCoeffs k{};
-        const PllConsts c = make_pll_consts(k, (tid & 1) != 0);
-        PllChecks ck{1.0f, 0u};
-        const float r = atan2f_locked(y[ic], x[ic], c, ck);
-        if (i < n && !(tid & 1)) { out[i] = r; ok_out[i] = ck.range_max < kRangeWindow ? 1 : 0; }
-    } else if (tid < n) {
-        out[tid] = fmd_atan2f(y[tid], x[tid]);
+        const PllConsts c = make_pll_consts(k);
+        bool ok;
+        out[i] = atan2f_locked(y[i], x[i], c, ok);
+        ok_out[i] = ok ? 1 : 0;
+    } else {
+        out[i] = fmd_atan2f(y[i], x[i]);
     }
 }
 
 hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, unsigned char* d_ok, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_selftest_atan2, dim3((unsigned)(((d_ok ? 2 * n : n) + 255) / 256)), dim3(256), 0, s, d_y, d_x, d_out, d_ok, n);
+    hipLaunchKernelGGL(k_selftest_atan2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_y, d_x, d_out, d_ok, n);
     return hipGetLastError();
 }
 
@@ -1140,7 +1150,7 @@ hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
 
 hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
-    FMD_LAUNCH(r, true, true, k_pilot_pll, dim3((unsigned)((d.C + kPllCh - 1) / kPllCh)), dim3(2 * kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
+    FMD_LAUNCH(r, true, true, k_pilot_pll, dim3((unsigned)((d.C + kPllG - 1) / kPllG)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
                        ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
     return hipGetLastError();
 }

@@ -158,14 +158,15 @@ typedef struct {
 /* Self-test hook: evaluates the kernels' atan2f on the device for n host-side (y, x) pairs, so tests can compare
  * the device math bit-for-bit with the host libm the reference links (std::atan2, reference fm_demod.cpp:40). */
 int fmd_selftest_atan2(const float* y, const float* x, float* out, size_t n);
-/* Same for the short form the serial loops use while in lock: out[i] is only meaningful where ok[i] != 0, and there it
- * must equal atan2f(y[i], x[i]) bit-for-bit (DESIGN.md "Speculative serial loops"). */
+/* Same for the short form k_pilot_pll's phase detector uses on a locked loop: out[i] is only meaningful where ok[i] != 0, and
+ * there it must equal atan2f(y[i], x[i]) bit-for-bit (DESIGN.md "Pilot PLL"). */
 int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t* ok, size_t n);
 
-/* Speculation counters of the serial loops since creation / the last reset, in 16-sample chunks summed over wavefronts:
- * out8[0..2] = pilot PLL {chunks, chunks run with the general forms, chunks speculated then replayed};
- * out8[4..5] = BPSK synchroniser {chunks, general}; out8[6], out8[7] = shader-clock cycles and 100 MHz real-time ticks
- * accumulated by one k_pilot_pll wavefront per launch (ratio x 100 = the core clock in MHz the kernel ran at).
+/* Counters of k_pilot_pll's frequency speculation since creation / the last reset (DESIGN.md "Pilot PLL"):
+ * out8[0] = 128-sample chunks, summed over wavefronts (4 channels each); out8[1] = of those, chunks run with the plain serial
+ * iteration (wavefront out of lock); out8[2] = spans redone with the reference forms (a short form outside its domain);
+ * out8[3] = spans, out8[4] = samples committed, both summed over channels (ratio = samples per 16-sample span);
+ * out8[6], out8[7] = shader-clock cycles and 100 MHz real-time ticks of one wavefront per launch (ratio x 100 = core MHz).
  * Results never depend on any of them; they explain k_pilot_pll's duration. */
 int fmd_get_spec_stats(fmd_handle h, uint64_t* out8, int reset);
 
