@@ -23,6 +23,8 @@ HEADER = ROOT / "include" / "fmdemod.h"
 FMD_AUDIO_LPR, FMD_AUDIO_LMR, FMD_AUDIO_STEREO = 0, 1, 2
 FMD_FLAG_KEEP_TAPS = 1
 FMD_FLAG_NO_PIPELINE = 2
+FMD_FLAG_PLL_TIME_PARALLEL = 4
+FMD_FLAG_PLL_LOW_WORK = 8
 FMD_OK, FMD_ERR_ARG, FMD_ERR_SIZE, FMD_ERR_DEVICE, FMD_ERR_NO_DEVICE, FMD_ERR_NAME = 0, -1, -2, -3, -4, -5
 
 
@@ -179,10 +181,11 @@ class BatchDemod:
     """C broadcast-FM demodulators advanced in lock-step on one MI355X."""
 
     def __init__(self, n_channels: int, block_size: int = 65536, fs_baseband: int = 1_024_000, device: int = -1, keep_taps: bool = False,
-                 pipelined: bool = True):
+                 pipelined: bool = True, pll_kernel: str = "auto"):
         self.L = load_library()
         self.h = C.c_void_p()
         flags = (FMD_FLAG_KEEP_TAPS if keep_taps else 0) | (0 if pipelined else FMD_FLAG_NO_PIPELINE)
+        flags |= {"auto": 0, "time_parallel": FMD_FLAG_PLL_TIME_PARALLEL, "low_work": FMD_FLAG_PLL_LOW_WORK}[pll_kernel]
         cfg = Config(n_channels, block_size, fs_baseband, device, flags)
         rc = self.L.fmd_create(C.byref(cfg), C.byref(self.h))
         if rc != FMD_OK:

@@ -19,7 +19,7 @@
 
 using namespace fmd;
 
-// Stage placement: k_front on sF, k_pilot_power on sA, k_pilot_pll on sB, k_extract + k_rds_sync on sX.
+// Stage placement: k_front on sF, k_pilot_power on sA, k_pilot_pll on sB, k_extract (+ k_lmr_phase) on sX, k_rds_sync on sR.
 // Blocks alternate between two buffer slots, so in steady state the serial PLL stage of block b runs while the
 // front end of block b+1 and the extract/RDS stages of block b-1 use the rest of the chip.
 enum Stage { ST_FRONT = 0, ST_DEEMPH, ST_POWER, ST_PLL, ST_EXTRACT, ST_RDS, ST_COUNT };
@@ -41,8 +41,8 @@ struct fmd_handle_s {
     size_t d_in_bytes = 0;
     hipStream_t own_stream = nullptr;        // host-pointer entry points, uploads, resets
     hipStream_t last_stream = nullptr;
-    hipStream_t sF = nullptr, sA = nullptr, sB = nullptr, sX = nullptr;
-    hipEvent_t ev_in = nullptr, ev_F[kSlots] = {}, ev_A[kSlots] = {}, ev_B[kSlots] = {}, ev_X[kSlots] = {};
+    hipStream_t sF = nullptr, sA = nullptr, sB = nullptr, sX = nullptr, sR = nullptr;
+    hipEvent_t ev_in = nullptr, ev_F[kSlots] = {}, ev_A[kSlots] = {}, ev_B[kSlots] = {}, ev_E[kSlots] = {}, ev_X[kSlots] = {};
     bool slot_used[kSlots] = {};
     bool pipelined = true;
     long n_blocks = 0;                       // blocks submitted since create/reset; slot = n_blocks % kSlots
@@ -175,7 +175,7 @@ int zero_history(fmd_handle h, hipStream_t s) {
 
 int sync_all(fmd_handle h) {
     HIP_TRY(h, hipSetDevice(h->device));
-    for (hipStream_t st : {h->sF, h->sA, h->sB, h->sX, h->own_stream}) if (st) HIP_TRY(h, hipStreamSynchronize(st));
+    for (hipStream_t st : {h->sF, h->sA, h->sB, h->sX, h->sR, h->own_stream}) if (st) HIP_TRY(h, hipStreamSynchronize(st));
     if (!h->pipelined && h->n_blocks > 0) HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     return FMD_OK;
 }
@@ -197,7 +197,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     const SlotRef ref{slot, (int)(h->n_blocks & 1), nullptr, nullptr};
     const bool u8 = sizeof(InT) == 2;
     const bool pipe = h->pipelined;
-    hipStream_t sF = pipe ? h->sF : s, sA = pipe ? h->sA : s, sB = pipe ? h->sB : s, sX = pipe ? h->sX : s;
+    hipStream_t sF = pipe ? h->sF : s, sA = pipe ? h->sA : s, sB = pipe ? h->sB : s, sX = pipe ? h->sX : s, sR = pipe ? h->sR : s;
     ProfiledBlock* pm = nullptr;
     if (h->profiling) {
         pm = new ProfiledBlock();
@@ -245,8 +245,12 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         HIP_TRY(h, hipStreamWaitEvent(sX, h->ev_B[slot], 0));
     }
     if ((e = run(ST_EXTRACT, sX, launch_stage_extract)) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_extract launch: %s", hipGetErrorString(e));
-    if ((e = run(ST_RDS, sX, launch_stage_rds)) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_rds_sync launch: %s", hipGetErrorString(e));
-    if (pipe) HIP_TRY(h, hipEventRecord(h->ev_X[slot], sX));
+    if (pipe) {
+        HIP_TRY(h, hipEventRecord(h->ev_E[slot], sX));
+        HIP_TRY(h, hipStreamWaitEvent(sR, h->ev_E[slot], 0));
+    }
+    if ((e = run(ST_RDS, sR, launch_stage_rds)) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_rds_sync launch: %s", hipGetErrorString(e));
+    if (pipe) HIP_TRY(h, hipEventRecord(h->ev_X[slot], sR));   // the last consumer of this slot's buffers
     h->slot_used[slot] = true;
     h->out_slot = slot;
     h->n_blocks++;
@@ -348,16 +352,17 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     { hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking); if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e))); }
 
     h->pipelined = (cfg->flags & FMD_FLAG_NO_PIPELINE) == 0;
+
     // (A CU-mask split between the serial and the FIR streams was measured: it shields the PLL wave from FIR waves
     //  sharing its SIMD — 3.06 -> 2.75 ms — but CU-masked streams did not overlap with each other on this runtime, so
     //  the step got slower overall.  Plain streams + s_setprio in the serial kernels it is.)
-    for (hipStream_t* st : {&h->sF, &h->sA, &h->sB, &h->sX}) {
+    for (hipStream_t* st : {&h->sF, &h->sA, &h->sB, &h->sX, &h->sR}) {
         hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
         if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e)));
     }
     {
         std::vector<hipEvent_t*> evs = {&h->ev_in};
-        for (int i = 0; i < kSlots; i++) { evs.push_back(&h->ev_F[i]); evs.push_back(&h->ev_A[i]); evs.push_back(&h->ev_B[i]); evs.push_back(&h->ev_X[i]); }
+        for (int i = 0; i < kSlots; i++) { evs.push_back(&h->ev_F[i]); evs.push_back(&h->ev_A[i]); evs.push_back(&h->ev_B[i]); evs.push_back(&h->ev_E[i]); evs.push_back(&h->ev_X[i]); }
         for (hipEvent_t* ev : evs) {
             hipError_t e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
             if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "event: %s", hipGetErrorString(e)));
@@ -365,6 +370,10 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     }
     Dims& d = h->ctx.d;
     d.C = cfg->n_channels; d.N = cfg->block_size; d.m = m;
+    // Which pilot-PLL kernel: the time-parallel one halves a lone wavefront's latency for 2.6x the VALU work.  Once the chip's
+    // VALU throughput bounds the step (measured: from ~8192 channels at 256 kSa/s; the first decimator of the higher rates
+    // multiplies the FIR work per channel by m) the low-work kernel is faster.
+    h->ctx.pll_time_parallel_max_channels = (cfg->flags & FMD_FLAG_PLL_LOW_WORK) ? 0 : ((cfg->flags & FMD_FLAG_PLL_TIME_PARALLEL) ? 0x7fffffff : 8192 / m);
     d.n_fm_in = d.N / m; d.n_fm_out = d.n_fm_in / 2; d.n_rds = d.n_fm_out / 8; d.n_audio = d.n_fm_out / 4;
     d.n_est = (d.n_audio + 9) / 10;
     d.tail_base = front_tail_len(m);
@@ -400,8 +409,8 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
         if (!rc) rc = dev_alloc(h, &b.lmr[p], h->ctx.keep_taps ? C * d.n_audio : 4);
         if (!rc) rc = dev_alloc(h, &b.rds_bytes[p], C * h->bytes_cap);
         if (!rc) rc = dev_alloc(h, &b.rds_bytes_count[p], C);
+        if (!rc) rc = dev_alloc(h, &b.rds[p], C * d.n_rds);
     }
-    if (!rc) rc = dev_alloc(h, &b.rds, C * d.n_rds);
     if (!rc) rc = dev_alloc(h, &b.lmr_est, C * d.n_est);
     if (!rc) rc = dev_alloc(h, &b.b_lpr, C * 128);
     if (!rc) rc = dev_alloc(h, &b.b_lmr, C * 128);
@@ -423,10 +432,10 @@ int fmd_destroy(fmd_handle h) {
     (void)hipSetDevice(h->device);
     (void)sync_all(h);
     free_marks(h);
-    for (hipStream_t st : {h->sF, h->sA, h->sB, h->sX}) if (st) (void)hipStreamDestroy(st);
+    for (hipStream_t st : {h->sF, h->sA, h->sB, h->sX, h->sR}) if (st) (void)hipStreamDestroy(st);
     {
         std::vector<hipEvent_t> evs = {h->ev_in};
-        for (int i = 0; i < kSlots; i++) { evs.push_back(h->ev_F[i]); evs.push_back(h->ev_A[i]); evs.push_back(h->ev_B[i]); evs.push_back(h->ev_X[i]); }
+        for (int i = 0; i < kSlots; i++) { evs.push_back(h->ev_F[i]); evs.push_back(h->ev_A[i]); evs.push_back(h->ev_B[i]); evs.push_back(h->ev_E[i]); evs.push_back(h->ev_X[i]); }
         for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     }
     for (void* p : h->allocs) (void)hipFree(p);
@@ -572,7 +581,7 @@ int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats
     else if (s == "audio") { p = b.audio[o]; n = 2 * C * d.n_audio; }
     else if (s == "rds_sym") { p = b.rds_sym[o]; n = C * d.n_rds; }
     else if (s == "lmr_est") { p = b.lmr_est; n = C * d.n_est; }
-    else if (s == "rds" ) { p = b.rds; n = 2 * C * d.n_rds; }
+    else if (s == "rds" ) { p = b.rds[o]; n = 2 * C * d.n_rds; }
     else if (s == "lpr" && keep) { p = b.lpr[o]; n = C * d.n_audio; }
     else if (s == "lmr" && keep) { p = b.lmr[o]; n = C * d.n_audio; }
     else if (s == "rds_raw_sym" && keep) { p = b.rds_raw_sym[o]; n = 2 * C * d.n_rds; }

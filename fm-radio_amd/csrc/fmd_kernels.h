@@ -75,7 +75,7 @@ struct Buffers {
     float*  fm_out[kSlots];      // [C][n_fm_out]  (de-emphasis path only)
     float2* pilot[kSlots];       // [C][n_fm_out]  pilot peak IIR output before AGC (k_pilot_power -> k_pilot_pll)
     float*  pll_dt[kSlots];      // [C][n_fm_out]
-    float2* rds;            // [C][n_rds]      (extract -> rds_sync, same stream)
+    float2* rds[kSlots];    // [C][n_rds]      (extract -> rds_sync, which runs on its own stream)
     float*  lmr_est;        // [C][n_est]
     // outputs
     float*  audio[kSlots];       // [C][n_audio][2]
@@ -104,6 +104,7 @@ struct LaunchCtx {
     int keep_taps;
     int any_deemph;
     int bytes_cap;
+    int pll_time_parallel_max_channels;   // batches up to this size use the time-parallel PLL kernel, larger ones the low-work one
 };
 
 // One launcher per pipeline stage of one block.  The host (fmd_api.cpp) places the stages on

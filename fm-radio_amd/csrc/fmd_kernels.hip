@@ -425,11 +425,14 @@ __device__ __forceinline__ float atan2f_locked(float y, float x, const PllConsts
     return t - t * (s1 + s2);
 }
 
-static constexpr int kPllK = 16;              // lanes (= consecutive samples) per channel
+#ifndef FMD_PLL_K
+#define FMD_PLL_K 16
+#endif
+static constexpr int kPllK = FMD_PLL_K;       // lanes (= consecutive samples) per channel
 static constexpr int kPllG = kWave / kPllK;   // channels per wavefront
 static constexpr int kPllChunk = 128;         // samples per chunk
 static constexpr int kPllRing = 2 * kPllChunk;
-static constexpr int kPllSlowSpans = 24;      // a chunk that needed more spans than this is "out of lock"
+static constexpr int kPllSlowSpans = 3 * kPllChunk / kPllK;   // a chunk that needed more spans than this is "out of lock"
 static constexpr int kSlowHoldMax = 16;       // longest run of serial chunks between two speculation attempts
 
 __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
@@ -463,30 +466,17 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
     // global <-> LDS: lane (g, j) moves row g; chunk q of the pilot = 4 float4 (2 samples each) per lane
     const int srow = c0 + g < d.C ? c0 + g : d.C - 1;
     const float2* prow = pilot + (size_t)srow * n;
-    float4 pre0, pre1, pre2, pre3;
-    auto fetch = [&](int q) {
-        const int b0 = (q < chunks ? q : chunks - 1) * CH + 2 * j;
-        pre0 = *reinterpret_cast<const float4*>(prow + b0);
-        pre1 = *reinterpret_cast<const float4*>(prow + b0 + 32);
-        pre2 = *reinterpret_cast<const float4*>(prow + b0 + 64);
-        pre3 = *reinterpret_cast<const float4*>(prow + b0 + 96);
-    };
-    auto stash = [&](int q) {
-        float2* r = &xin[g][(q & 1) * CH + 2 * j];
-        *reinterpret_cast<float4*>(r) = pre0; *reinterpret_cast<float4*>(r + 32) = pre1;
-        *reinterpret_cast<float4*>(r + 64) = pre2; *reinterpret_cast<float4*>(r + 96) = pre3;
-    };
-    auto flush = [&](int q) {   // results of chunk q, all final
-        const float* r = &dts[g][(q & 1) * CH + 4 * j];
-        const float4 v0 = *reinterpret_cast<const float4*>(r), v1 = *reinterpret_cast<const float4*>(r + 64);
-        if (live) {
-            float* o = pll_dt + (size_t)c * n + (size_t)q * CH + 4 * j;
-            *reinterpret_cast<float4*>(o) = v0; *reinterpret_cast<float4*>(o + 64) = v1;
-        }
-    };
-    fetch(0); stash(0);
-    fetch(1); stash(1);
-    fetch(2);
+    constexpr int NLD = CH / (2 * K), NST = CH / (4 * K);   // float4 loads / stores per lane and chunk
+    // named registers, not an array: an indexed local array ends up in scratch memory here
+    float4 pre0{}, pre1{}, pre2{}, pre3{}, pre4{}, pre5{}, pre6{}, pre7{};
+#define FMD_PLL_EACH(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define FMD_PLL_LD(r) if constexpr (r < NLD) pre##r = *reinterpret_cast<const float4*>(prow + b0_ + 2 * K * r);
+#define FMD_PLL_ST(r) if constexpr (r < NLD) *reinterpret_cast<float4*>(row_ + 2 * K * r) = pre##r;
+#define FMD_PLL_FETCH(q_) { const int b0_ = ((q_) < chunks ? (q_) : chunks - 1) * CH + 2 * j; FMD_PLL_EACH(FMD_PLL_LD) }
+#define FMD_PLL_STASH(q_) { float2* row_ = &xin[g][((q_) & 1) * CH + 2 * j]; FMD_PLL_EACH(FMD_PLL_ST) }
+    FMD_PLL_FETCH(0) FMD_PLL_STASH(0)
+    FMD_PLL_FETCH(1) FMD_PLL_STASH(1)
+    FMD_PLL_FETCH(2)
 
     int pos = 0;                 // next sample of this channel (absolute within the block); identical in its 16 lanes
     int seq_left = 0, hold = 0;  // wave-uniform: serial chunks still to run / back-off
@@ -571,7 +561,7 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
                 const float Fj = fmaf(clampf(my_ig + my_y1 * kc.c001, -1.0f, 1.0f), kc.m100, kc.m19000);
                 const bool ok_j = (f32_bits(Fj) == f32_bits(F)) && (j < rem);
                 const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok_j || j == 0);
-                int m = __builtin_ctz(~((unsigned int)(okm >> (g * K)) & 0xffffu) | 0x10000u);   // first invalid sample (16 = none)
+                int m = __builtin_ctz(~((unsigned int)(okm >> (g * K)) & ((1u << K) - 1u)) | (1u << K));   // first invalid sample (K = none)
                 float nx, ny, ni, ne, nt;
                 if (__builtin_amdgcn_ballot_w64(active && integ_clamped) != 0ull) {
                     // a saturated integrator (never in lock): verify with the exact clamps, predicated
@@ -606,9 +596,14 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
         }
         // chunk q is final in every channel: drain it, refill its half of the ring with chunk q+2, prefetch chunk q+3
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        flush(q);
-        stash(q + 2);
-        fetch(q + 3);
+        {   // results of chunk q
+            const float* row = &dts[g][(q & 1) * CH + 4 * j];
+            float* o = pll_dt + (size_t)cs * n + (size_t)q * CH + 4 * j;
+#define FMD_PLL_DRAIN(r) if constexpr (r < NST) { const float4 v_ = *reinterpret_cast<const float4*>(row + 4 * K * r); if (live) *reinterpret_cast<float4*>(o + 4 * K * r) = v_; }
+            FMD_PLL_EACH(FMD_PLL_DRAIN)
+        }
+        FMD_PLL_STASH(q + 2)
+        FMD_PLL_FETCH(q + 3)
         if (speculative) {   // a speculative chunk that went badly sends the wavefront serial for a while, doubling each time in a row
             if (spans > kPllSlowSpans) { seq_left = hold ? hold : 1; hold = hold ? (2 * hold < kSlowHoldMax ? 2 * hold : kSlowHoldMax) : 1; }
             else hold = 0;
@@ -626,6 +621,282 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
         // shader-clock cycles and 100 MHz real-time ticks this wavefront ran: their ratio is the core clock the power
         // management granted while the other stages' kernels ran beside it (DESIGN.md "Clocks")
         if (lane == 0 && blockIdx.x == 0) { atomicAdd(&spec_stats[6], __builtin_readcyclecounter() - clk0); atomicAdd(&spec_stats[7], __builtin_amdgcn_s_memrealtime() - rt0); }
+    }
+}
+
+// ===============================================================================================================
+// k_pilot_pll_pairs — the LOW-WORK variant of the pilot PLL kernel, used for large batches (> kPllTimeParallelMaxChannels).
+// The time-parallel kernel above spends ~2.6x the VALU instructions of this one to cut the latency of a lone wavefront in
+// half; once the batch is large enough that the chip's VALU throughput, not a lone wavefront's latency, bounds the step
+// (measured: from ~8192 channels per GPU), the cheaper kernel wins.  Same arithmetic, same results.
+// ===============================================================================================================
+// ---------------------------------------------------------------------------------------------------------------
+// Speculative form of the same iteration for a loop that is in lock.  A lone wavefront per SIMD issues one instruction
+// every ~4 cycles and waits ~6 cycles on a dependent result, so the loop's duration is max(4 x instructions, 6 x chain
+// length).  pll_step (the reference iteration) is a 78-operation err -> err chain; pll_step_pair cuts the chain to ~45
+// and the instruction count to ~68 per sample:
+//   * the integrator / control clamps are skipped (shown not to bind for the whole chunk by pll_chunk_precheck),
+//   * x - round_half_away(x) becomes x - rndne(x) (equal unless x is an exact tie, detected from the chebyshev
+//     argument: wrapped phase == +-0.5  <=>  z - 0.25 == 0),
+//   * the phase detector is atan2f's first range with an unscaled division (fmd_math.h div_unscaled), valid for
+//     x in [2^-28, ~2e8) and 2^-29 <= |y/x| < 7/16, i.e. (y/x)^2 in [2^-58, 49/256) — both windows are 0x1bc40000 wide
+//     in the float's bit pattern, so one unsigned max tracks both,
+//   * TWO LANES PER CHANNEL: the iteration contains two pairs of structurally identical, mutually independent
+//     polynomial evaluations (chebyshev sine of the phase and of phase + 1/4; the odd and even halves s1 / s2 of the
+//     arctangent series).  The even lane of a pair evaluates the first of each, the odd lane the second, with the same
+//     instructions and per-lane constants, and they exchange the results with DPP quad permutes.  Everything else is
+//     computed redundantly (identically) by both lanes.  A wavefront therefore carries 32 channels.
+// Validity is accumulated in VALU registers only (a v_cmp -> SALU round trip stalls an in-order wave ~18 cycles) and
+// tested once per 16-sample chunk; a chunk with any invalid lane is replayed with pll_step.  Constants live in VGPRs:
+// a 32-bit literal in the instruction stream costs a lone wave ~2.7 extra cycles per instruction.
+// ---------------------------------------------------------------------------------------------------------------
+struct PairConsts {
+    float b0, a0, b1, c001, ktsi, m100, m19000, ts, q25 /* odd lane 1/4, even lane -0 */, mq25, c5, c4, c3, c2, c1, c0;
+    float k0, k1, k2, k3, k4, k5;   // arctangent series, this lane's half: even lane a10,a8,a6,a4,a2,a0 (s1); odd lane 0,a9,a7,a5,a3,a1 (s2)
+    uint32_t xlo, zlo;
+    bool odd;
+};
+__device__ __forceinline__ PairConsts make_pair_consts(const LoopCoeffs& k, bool odd) {
+    PairConsts c;
+    FMD_OPAQUE_F(c.b0, k.pll_b0) FMD_OPAQUE_F(c.a0, k.pll_a0) FMD_OPAQUE_F(c.b1, k.pll_b1) FMD_OPAQUE_F(c.c001, 0.01f)
+    FMD_OPAQUE_F(c.ktsi, 0.1f * (1.0f / 128000.0f)) FMD_OPAQUE_F(c.m100, -100.0f) FMD_OPAQUE_F(c.m19000, -19000.0f)
+    FMD_OPAQUE_F(c.ts, 1.0f / 128000.0f) FMD_OPAQUE_F(c.q25, odd ? 0.25f : -0.0f) FMD_OPAQUE_F(c.mq25, -0.25f)
+    FMD_OPAQUE_F(c.c5, 3.20396066f) FMD_OPAQUE_F(c.c4, -14.07150173f) FMD_OPAQUE_F(c.c3, 38.50016403f)
+    FMD_OPAQUE_F(c.c2, -67.07687378f) FMD_OPAQUE_F(c.c1, 64.83583069f) FMD_OPAQUE_F(c.c0, -25.13274193f)
+    FMD_OPAQUE_F(c.k0, odd ? 0.0f : bits_f32(0x3c8569d7u))
+    FMD_OPAQUE_F(c.k1, odd ? bits_f32(0xbd15a221u) : bits_f32(0x3d4bda59u))
+    FMD_OPAQUE_F(c.k2, odd ? bits_f32(0xbd6ef16bu) : bits_f32(0x3d886b35u))
+    FMD_OPAQUE_F(c.k3, odd ? bits_f32(0xbd9d8795u) : bits_f32(0x3dba2e6eu))
+    FMD_OPAQUE_F(c.k4, odd ? bits_f32(0xbde38e38u) : bits_f32(0x3e124925u))
+    FMD_OPAQUE_F(c.k5, odd ? bits_f32(0xbe4ccccdu) : bits_f32(0x3eaaaaabu))
+    FMD_OPAQUE_U(c.xlo, 0x31800000u) FMD_OPAQUE_U(c.zlo, 0x22800000u)
+    c.odd = odd;
+    return c;
+}
+
+struct PairChecks { float tie_min; uint32_t range_max; };
+static constexpr uint32_t kPairRangeWindow = 0x1bc40000u;   // bits(49/256) - bits(2^-58)
+
+// DPP quad permutes between the two lanes of a channel pair (lanes 2j, 2j+1)
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+static constexpr int kDppEven = 0xA0;   // quad_perm [0,0,2,2]: both lanes read the even lane
+static constexpr int kDppOdd = 0xF5;    // quad_perm [1,1,3,3]: both lanes read the odd lane
+static constexpr int kDppSwap = 0xB1;   // quad_perm [1,0,3,2]: each lane reads its partner
+
+// atan2f(y, x) for x in [2^-28, ~2e8) and 2^-29 <= |y/x| < 7/16 (a locked loop's phase error): the published algorithm
+// reduces to t - t (s1 + s2) with t = y / x (its first range, which is odd-symmetric, so no quadrant or sign selects), and
+// the division needs neither operand scaling nor special-value fix-up.  Both lanes of a pair hold the same (y, x); the even
+// lane evaluates s1 = z (a0 + w (a2 + w (a4 + w (a6 + w (a8 + w a10))))), the odd lane s2 = w (a1 + w (a3 + w (a5 + w (a7 + w a9))))
+// (its first level is a9 + w 0 = a9 exactly), then each adds its partner's half (IEEE addition commutes).
+__device__ __forceinline__ float atan2f_pair(float y, float x, const PairConsts& c, PairChecks& ck) {
+    const float t = div_unscaled(y, x);
+    const float z = t * t;
+    const float w = z * z;
+    ck.range_max = max(max(ck.range_max, f32_bits(x) - c.xlo), f32_bits(z) - c.zlo);
+    float s = c.k1 + w * c.k0;
+    s = c.k2 + w * s;
+    s = c.k3 + w * s;
+    s = c.k4 + w * s;
+    s = c.k5 + w * s;
+    s = (c.odd ? w : z) * s;
+    const float sum = s + dpp_quad<kDppSwap>(s);
+    return t - t * sum;
+}
+
+// Holds for the whole chunk if it holds at its start, given that every err the chunk produces is < 0.42 in magnitude
+// (implied by the range check): the loop filter is a convex combination (|lpf| <= max of its inputs), the integrator
+// moves by < 4e-6 per sample, so |integ| <= 0.9001, |integ + 0.01 lpf| <= 0.95 < 1 and |t + Ts freq| <= 0.65 < 1.5.
+__device__ __forceinline__ bool pll_chunk_precheck(const PllState& s, const LoopCoeffs& k) {
+    const bool convex = (k.pll_b0 >= 0.0f) && (k.pll_b1 >= 0.0f) && (k.pll_a0 >= 0.0f) && ((k.pll_b0 + k.pll_b1) + k.pll_a0 <= 1.0001f);
+    return convex && (fabsf(s.integ) <= 0.9f) && (fabsf(s.lx1) <= 4.0f) && (fabsf(s.ly1) <= 4.0f) && (fabsf(s.err) <= 4.0f) && (fabsf(s.tph) <= 0.5f);
+}
+
+__device__ __forceinline__ float pll_step_pair(PllState& s, float p, float q, const PairConsts& c, PairChecks& ck) {
+    const float t0 = fmaf(s.lx1, c.b0, s.ly1 * c.a0);
+    const float t1 = fmaf(s.err, c.b1, 0.0f);
+    const float lpf = (0.0f + t0) + t1;
+    s.lx1 = s.err; s.ly1 = lpf;
+    const float P = lpf * c.c001;
+    s.integ = fmaf(s.err, c.ktsi, s.integ);
+    const float PI_error = s.integ + P;
+    const float freq = fmaf(PI_error, c.m100, c.m19000);
+    const float yy = fmaf(freq, c.ts, s.tph);
+    s.tph = yy - rintf(yy);
+    // chebyshev_sine (scalar association): the odd lane of the pair takes sin(2 pi wrap(t + 1/4)); the even lane runs the
+    // same three instructions with -0 in place of 1/4, which leave t unchanged bit for bit (t + -0 = t, |t| <= 1/2 so
+    // rndne(t) = +-0), i.e. sin(2 pi t) — no select on the dependency chain
+    const float dc = s.tph + c.q25;
+    const float xr = dc - rintf(dc);
+    const float z = xr * xr;
+    float poly = fmaf(c.c5, z, c.c4);
+    poly = fmaf(poly, z, c.c3);
+    poly = fmaf(poly, z, c.c2);
+    poly = fmaf(poly, z, c.c1);
+    poly = fmaf(poly, z, c.c0);
+    const float zq = z + c.mq25;
+    const float sn = (zq * xr) * poly;
+    ck.tie_min = fminf(ck.tie_min, fabsf(zq));   // wrapped phase == +-1/2 <=> zq == 0: the rndne shortcut was not exact
+    const float ps = dpp_quad<kDppEven>(sn), pc = dpp_quad<kDppOdd>(sn);
+    const float res_im = fmaf(ps, p, q * pc);
+    const float res_re = fmaf(p, pc, -(q * ps));
+    s.err = atan2f_pair(res_im, res_re, c, ck);
+    return s.tph;
+}
+
+static constexpr int kPairSlowHoldMax = 64;   // longest run of general-form chunks between two speculation attempts
+
+// ---------------------------------------------------------------------------------------------------------------
+// 16-sample chunk staging for the two-wave pilot PLL kernel: 32 channels per workgroup (two lanes per channel in the
+// recurrence wave), 4 float4 registers per chunk in the mover wave.
+// ---------------------------------------------------------------------------------------------------------------
+static constexpr int kCh16 = 16;
+static constexpr int kRow16 = kCh16 + 2;   // float2 row stride (144 B) of a transposed 16-sample cf32 chunk
+static constexpr int kPllCh = 32;          // channels per k_pilot_pll_pairs workgroup
+struct Chunk16 { float4 v0, v1, v2, v3; };
+#define FMD_FOR4(X) X(0) X(1) X(2) X(3)
+__device__ __forceinline__ Chunk16 chunk16_load(const float2* __restrict__ base, int n, int c0, int C, int t0) {
+    const int lane = threadIdx.x & (kWave - 1), row = lane >> 3, col = lane & 7;
+    Chunk16 r;
+#define FMD_LD4(k) { int ch = c0 + 8 * k + row; ch = ch < C ? ch : C - 1; \
+                     r.v##k = *reinterpret_cast<const float4*>(base + (size_t)ch * n + t0 + 2 * col); }
+    FMD_FOR4(FMD_LD4)
+#undef FMD_LD4
+    return r;
+}
+__device__ __forceinline__ void chunk16_store(const Chunk16& r, float2* lds) {
+    const int lane = threadIdx.x & (kWave - 1), row = lane >> 3, col = lane & 7;
+#define FMD_ST4(k) *reinterpret_cast<float4*>(lds + (8 * k + row) * kRow16 + 2 * col) = r.v##k;
+    FMD_FOR4(FMD_ST4)
+#undef FMD_ST4
+}
+// drain 16 f32 results per channel, stored compactly at the start of each row of a chunk buffer, to out[C][n] at t0
+__device__ __forceinline__ void chunk16_flush_f(const float2* lds, float* __restrict__ out, int n, int c0, int C, int t0) {
+    const int lane = threadIdx.x & (kWave - 1), row = lane >> 2, col = lane & 3;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int r = 16 * k + row, ch = c0 + r;
+        const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(lds + r * kRow16) + 4 * col);
+        if (ch < C) *reinterpret_cast<float4*>(out + (size_t)ch * n + t0 + 4 * col) = v;
+    }
+}
+
+// Workgroup = two wavefronts for 32 channels.  Wave 0 runs the recurrence (two lanes per channel, see pll_step_pair) and
+// touches only LDS; wave 1 (the mover) stages the next chunks HBM -> registers -> LDS and drains finished pll_dt chunks
+// LDS -> HBM.  A lone wave is bound by its own instruction issue, and a vector-memory instruction costs it tens of cycles
+// — hundreds when other stages' kernels keep the CU's memory pipeline busy — so the memory instructions are given to a
+// sibling on another SIMD; the two meet at one barrier per 16-sample chunk.
+// The workgroup is kept SMALL on purpose (9 KB of LDS, results written in place over consumed input; well under 150
+// VGPRs per wave): while the FIR stages' kernels fill every CU, a serial-stage workgroup that needs 52 KB and 2 x 256
+// registers waits >100 us for a hole (measured, tools/gap_probe.hip), one that fits the hole a retiring FIR workgroup
+// leaves starts at once.
+__global__ __launch_bounds__(2 * kWave) void k_pilot_pll_pairs(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
+                                                         float* __restrict__ state, LoopCoeffs k, int power_field,
+                                                         unsigned long long* __restrict__ spec_stats) {
+    __shared__ __attribute__((aligned(16))) float2 ring[2][kPllCh * kRow16];
+    const bool mover = threadIdx.x >= kWave;   // wave-uniform
+    const int lane = threadIdx.x & (kWave - 1), c0 = blockIdx.x * kPllCh;
+    const int n = d.n_fm_out, chunks = n / kCh16;
+
+    if (mover) {
+        // iteration ch (between barriers ch and ch+1): drain the results of chunk ch-1 from its slot, refill that slot with
+        // chunk ch+1 (loaded three iterations ago), issue the loads of chunk ch+4
+        auto load_or_last = [&](int ch) { return chunk16_load(pilot, n, c0, d.C, (ch < chunks ? ch : chunks - 1) * kCh16); };
+        Chunk16 r0 = load_or_last(0);
+        chunk16_store(r0, ring[0]);
+        Chunk16 ra = load_or_last(1), rb = load_or_last(2), rc = load_or_last(3);
+        auto move_chunk = [&](int ch, Chunk16& regs) {
+            float2* slot = ring[(ch + 1) & 1];
+            if (ch > 0) chunk16_flush_f(slot, pll_dt, n, c0, d.C, (ch - 1) * kCh16);
+            if (ch + 1 < chunks) chunk16_store(regs, slot);
+            if (ch + 4 < chunks) regs = load_or_last(ch + 4);
+        };
+        for (int ch = 0; ch < chunks; ch += 3) {
+            __syncthreads();
+            move_chunk(ch, ra);
+            if (ch + 1 < chunks) { __syncthreads(); move_chunk(ch + 1, rb); }
+            if (ch + 2 < chunks) { __syncthreads(); move_chunk(ch + 2, rc); }
+        }
+        __syncthreads();
+        chunk16_flush_f(ring[(chunks - 1) & 1], pll_dt, n, c0, d.C, (chunks - 1) * kCh16);
+        return;
+    }
+
+    __builtin_amdgcn_s_setprio(3);  // latency-bound recurrence: win issue arbitration against co-resident FIR waves
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+    const int c = c0 + (lane >> 1);            // lanes 2j and 2j+1 both carry channel c0 + j
+    const bool odd = (lane & 1) != 0;
+    const bool live = c < d.C;
+    const int cs = live ? c : d.C - 1;
+    // AGC_Filter::process (agc.h:12-19) as compiled: target_gain = sqrt((target/sum) * N)
+    float gain = st(state, S_AGC_PILOT_GAIN, d.C, cs);
+    {
+        const float sum = st(state, power_field, d.C, cs);
+        const float target_gain = sqrtf((1.0f / sum) * (float)n);
+        gain = fmaf(target_gain - gain, 0.2f, gain);
+    }
+    PllState S;
+    S.lx1 = st(state, S_PLL_X1, d.C, cs); S.ly1 = st(state, S_PLL_Y1, d.C, cs);
+    S.integ = st(state, S_PLL_INT, d.C, cs); S.err = st(state, S_PLL_ERR, d.C, cs); S.tph = st(state, S_PLL_T, d.C, cs);
+    const PairConsts kc = make_pair_consts(k, odd);
+    // a failed speculative chunk is replayed with the general forms; consecutive failures (a loop out of lock) back
+    // off exponentially so an unlocked wavefront pays at most a few percent for its attempts
+    int slow_left = 0, hold = 0, n_replayed = 0, n_general = 0;
+    for (int ch = 0; ch < chunks; ch++) {
+        // here: ring[ch & 1] holds chunk ch; the other slot holds the results of chunk ch - 1, which the mover now drains
+        __syncthreads();
+        float2* row = ring[ch & 1] + (lane >> 1) * kRow16;
+        float* dto = reinterpret_cast<float*>(row);   // result t goes to float t of the row: x[t/2] has been consumed by then
+        bool done = false;
+        if (slow_left == 0) {
+            PllState s = S;
+            PairChecks ck{1.0f, 0u};
+            float2 xs[kCh16];                         // the chunk is read before any result is written over it
+#pragma unroll
+            for (int t = 0; t < kCh16; t++) xs[t] = row[t];
+            float dts[kCh16];
+#pragma unroll
+            for (int t = 0; t < kCh16; t++) dts[t] = pll_step_pair(s, gain * xs[t].x, gain * xs[t].y, kc, ck);
+            const bool ok = pll_chunk_precheck(S, k) && (ck.tie_min != 0.0f) && (ck.range_max < kPairRangeWindow);
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+                S = s; done = true; hold = 0;
+                if (!odd) {
+#pragma unroll
+                    for (int t = 0; t < kCh16; t += 4) *reinterpret_cast<float4*>(dto + t) = make_float4(dts[t], dts[t + 1], dts[t + 2], dts[t + 3]);
+                }
+            } else { slow_left = hold; hold = hold ? (2 * hold < kPairSlowHoldMax ? 2 * hold : kPairSlowHoldMax) : 1; n_replayed++; }
+        } else {
+            slow_left--;
+        }
+        if (!done) {   // general iteration, computed identically by both lanes of a pair (same address, same value)
+            n_general++;
+            float2 y = row[0];
+            for (int t = 0; t < kCh16; t++) {
+                const float2 yn = row[t + 1 < kCh16 ? t + 1 : t];
+                dto[t] = pll_step(S, gain * y.x, gain * y.y, k);
+                y = yn;
+            }
+        }
+        // The results must have landed in LDS before the mover reads them after the next barrier.  The compiler's own
+        // wait in front of the loop-header s_barrier went missing on this back edge (seen in the ISA and as stale last
+        // samples at 4096 channels), so it is spelled out.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (live && !odd) {
+        st(state, S_AGC_PILOT_GAIN, d.C, c) = gain;
+        st(state, S_PLL_X1, d.C, c) = S.lx1; st(state, S_PLL_Y1, d.C, c) = S.ly1;
+        st(state, S_PLL_INT, d.C, c) = S.integ; st(state, S_PLL_ERR, d.C, c) = S.err; st(state, S_PLL_T, d.C, c) = S.tph;
+    }
+    if (lane == 0 && spec_stats) {   // same slots as k_pilot_pll: chunks (16 samples here) / run with the general iteration / replayed
+        atomicAdd(&spec_stats[0], (unsigned long long)chunks);
+        atomicAdd(&spec_stats[1], (unsigned long long)n_general);
+        atomicAdd(&spec_stats[2], (unsigned long long)n_replayed);
+        // shader-clock cycles and 100 MHz real-time ticks this wavefront ran: their ratio is the core clock the power
+        // management granted while the other stages' kernels ran beside it (DESIGN.md "Clocks")
+        if (blockIdx.x == 0) { atomicAdd(&spec_stats[6], __builtin_readcyclecounter() - clk0); atomicAdd(&spec_stats[7], __builtin_amdgcn_s_memrealtime() - rt0); }
     }
 }
 
@@ -846,13 +1117,29 @@ __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict
     }
 }
 
+// a11 — reference ExtractComponents :511-516: integrate the mean L-R phase error of the block (sequential sum in sample order).
+// Its own small kernel, right behind k_extract on the same stream: the next block's k_extract needs the updated offset, the
+// (long, serial) k_rds_sync of this block does not, so that one runs on a stream of its own.
+__global__ void k_lmr_phase(Dims d, const float* __restrict__ lmr_est, float* __restrict__ state) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.C) return;
+    float sum = 0.0f;
+    const float* e = lmr_est + (size_t)c * d.n_est;
+    for (int i = 0; i < d.n_est; i++) sum = sum + e[i];
+    const float avg = sum / (float)d.n_est;
+    const float cur = st(state, S_LMR_PHASE_CUR, d.C, c);
+    const float acc = fmaf(avg, 0.1f, cur);
+    const float nxt = fmodf(acc, bits_f32(kTwoPiBits));
+    st(state, S_LMR_PHASE_PREV, d.C, c) = cur; st(state, S_LMR_PHASE_CUR, d.C, c) = nxt;
+}
+
 // =============================================================================================
 // k_rds_sync — reference ExtractComponents :511-516 (phase integrate), SynchroniseRDS :538-547,
 // AGC_Filter (agc.h:12-30), BPSK_Synchroniser::Process (bpsk_synchroniser.cpp:94-186) with TED_Clock
 // (ted_clock.cpp:18-44), Zero_Crossing_Detector, Trigger_Cooldown, and the differential Manchester
 // decoder (rds_decoder/differential_manchester_decoder.h:32-60).  Lane per channel.
 // =============================================================================================
-__global__ __launch_bounds__(kWave) void k_rds_sync(Dims d, float2* __restrict__ rds, const float* __restrict__ lmr_est,
+__global__ __launch_bounds__(kWave) void k_rds_sync(Dims d, float2* __restrict__ rds,
                                                     float* __restrict__ state, LoopCoeffs k, float* __restrict__ rds_sym,
                                                     float2* __restrict__ rds_raw_sym, int* __restrict__ rds_count,
                                                     uint8_t* __restrict__ rds_bytes, int* __restrict__ rds_bytes_count,
@@ -863,18 +1150,6 @@ __global__ __launch_bounds__(kWave) void k_rds_sync(Dims d, float2* __restrict__
     const bool live = c < d.C;
     const int cs = live ? c : d.C - 1;
     const int n = d.n_rds, chunks = n / kChunk;
-
-    // a11: integrate the mean L-R phase error (sequential sum in sample order)
-    {
-        float sum = 0.0f;
-        const float* e = lmr_est + (size_t)cs * d.n_est;
-        for (int i = 0; i < d.n_est; i++) sum = sum + e[i];
-        const float avg = sum / (float)d.n_est;
-        const float cur = st(state, S_LMR_PHASE_CUR, d.C, cs);
-        const float acc = fmaf(avg, 0.1f, cur);
-        const float nxt = fmodf(acc, bits_f32(kTwoPiBits));
-        if (live) { st(state, S_LMR_PHASE_PREV, d.C, c) = cur; st(state, S_LMR_PHASE_CUR, d.C, c) = nxt; }
-    }
 
     // a13: AGC power pass
     float power = 0.0f;
@@ -1150,6 +1425,11 @@ hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
 
 hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
+    if (d.C > ctx.pll_time_parallel_max_channels) {
+        FMD_LAUNCH(r, true, true, k_pilot_pll_pairs, dim3((unsigned)((d.C + kPllCh - 1) / kPllCh)), dim3(2 * kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf],
+                   ctx.b.state, ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
+        return hipGetLastError();
+    }
     FMD_LAUNCH(r, true, true, k_pilot_pll, dim3((unsigned)((d.C + kPllG - 1) / kPllG)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
                        ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
     return hipGetLastError();
@@ -1161,19 +1441,20 @@ static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Buffers& b = ctx.b;
     FMD_LAUNCH(r, true, true, k_extract<TA>, dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fm_out_iq[r.buf], b.pll_dt[r.buf],
                        b.iq_tail[r.par], b.dt_tail[r.par], b.iq_tail[r.par ^ 1], b.dt_tail[r.par ^ 1], b.b_lpr, b.b_lmr, ctx.rds_taps, b.mix,
-                       b.state, b.audio[r.buf], b.rds, b.lmr_est, b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps);
+                       b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est, b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps);
 }
 
 hipError_t launch_stage_extract(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     if (ctx.d.n_audio % 256 == 0) launch_extract_ta<256>(ctx, r, s);
     else launch_extract_ta<128>(ctx, r, s);
+    hipLaunchKernelGGL(k_lmr_phase, dim3((unsigned)((ctx.d.C + 255) / 256)), dim3(256), 0, s, ctx.d, ctx.b.lmr_est, ctx.b.state);
     return hipGetLastError();
 }
 
 hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
-    FMD_LAUNCH(r, true, true, k_rds_sync, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.rds, b.lmr_est, b.state, ctx.loops, b.rds_sym[r.buf],
+    FMD_LAUNCH(r, true, true, k_rds_sync, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
                        b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps);
     return hipGetLastError();
 }

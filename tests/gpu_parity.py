@@ -25,11 +25,12 @@ def oracle_controls(ctl) -> O.Controls:
     return out
 
 
-def run_gpu(pkg, caps: np.ndarray, block_size: int, fs: int, use_torch: bool = False, controls=None, per_channel_controls=None):
+def run_gpu(pkg, caps: np.ndarray, block_size: int, fs: int, use_torch: bool = False, controls=None, per_channel_controls=None,
+            pll_kernel: str = "auto"):
     """caps: [C, n, 2] float32 or uint8.  Returns dict of per-block concatenated streams [C, ...]."""
     n_ch = caps.shape[0]
     nb = caps.shape[1] // block_size
-    dm = pkg.BatchDemod(n_ch, block_size, fs, keep_taps=True)
+    dm = pkg.BatchDemod(n_ch, block_size, fs, keep_taps=True, pll_kernel=pll_kernel)
     if controls is not None:
         dm.set_controls(controls)
     if per_channel_controls:
@@ -71,10 +72,10 @@ def run_gpu(pkg, caps: np.ndarray, block_size: int, fs: int, use_torch: bool = F
 
 
 def compare_with_oracle(pkg, caps: np.ndarray, block_size: int, fs: int, use_torch: bool = False, controls=None,
-                        per_channel_controls=None) -> dict:
+                        per_channel_controls=None, pll_kernel: str = "auto") -> dict:
     n_ch = caps.shape[0]
     u8 = caps.dtype == np.uint8
-    g = run_gpu(pkg, caps, block_size, fs, use_torch, controls, per_channel_controls)
+    g = run_gpu(pkg, caps, block_size, fs, use_torch, controls, per_channel_controls, pll_kernel)
     report = {"bit_exact": {}, "max_abs": {}, "audio_rms_err": 0.0, "rds_sym_equal_counts": True, "rds_bytes_equal": True}
     for c in range(n_ch):
         ctl = (per_channel_controls or {}).get(c, controls)

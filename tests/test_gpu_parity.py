@@ -230,6 +230,14 @@ def test_device_atan2_short_form_is_exact_where_it_claims(pkg):
     assert not ok[n:2 * n][x[n:2 * n] <= 0].any()  # never claimed outside x > 0
 
 
+@pytest.mark.parametrize("pll_kernel", ["time_parallel", "low_work"])
+def test_both_pilot_pll_kernels_are_bit_identical_to_the_oracle(pkg, pll_kernel):
+    """The library picks the pilot-PLL kernel by batch size (time-parallel up to 8192 channels, low-work above); both must
+    produce the oracle's bits, through acquisition and in lock, for channel counts that do not fill a wavefront."""
+    caps = _caps(5, 10 * 16384, fs=256_000.0, seed=77)
+    _assert_exact(compare_with_oracle(pkg, caps, 16384, 256_000, pll_kernel=pll_kernel))
+
+
 def test_pll_speculation_commits_long_spans_in_lock_and_short_ones_before(pkg):
     """The pilot PLL kernel evaluates 16 samples at a time under the assumption that the NCO frequency word stays put and
     commits the prefix for which that held.  Results are identical either way (every other test in this file checks that) —

@@ -36,7 +36,8 @@ int main(int argc, char** argv) {
 #if 1
     for (int p = 0; p < 2; p++) b.pilot[p] = dalloc<float2>((size_t)C * d.n_fm_out);
 #endif
-    b.rds = dalloc<float2>((size_t)C * d.n_rds); b.lmr_est = dalloc<float>((size_t)C * d.n_est);
+    for (int p = 0; p < kSlots; p++) b.rds[p] = dalloc<float2>((size_t)C * d.n_rds);
+    b.lmr_est = dalloc<float>((size_t)C * d.n_est);
     b.b_lpr = dalloc<float>((size_t)C * 128); b.b_lmr = dalloc<float>((size_t)C * 128); b.deemph = dalloc<float>((size_t)C * 4); b.mix = dalloc<float>((size_t)C * 2);
     b.state = dalloc<float>((size_t)S_NUM_FIELDS * C); b.spec_stats = dalloc<unsigned long long>(8);
     {
