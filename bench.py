@@ -332,11 +332,24 @@ def main() -> None:
                 traffic = tj.get(key)
             except Exception:
                 traffic = None
+        # second roof: the chain is fp32-VALU work; profiles/valu_instructions.json holds the PMC count of VALU
+        # wave-instructions one block costs (tools/collect_profiles.sh), the chip issues 1024 SIMDs x clock / 4 of them per second
+        valu = None
+        vf = ROOT / "profiles" / "valu_instructions.json"
+        if vf.exists() and world == 1:
+            try:
+                vt = json.loads(vf.read_text()).get(f"valu_total_per_block|C={C}|fs={fs}|block={block}|{'u8' if args.u8 else 'cf32'}")
+                if vt:
+                    clk = spec.get("pll_clock_mhz", 2400.0) * 1e6
+                    valu = {"wave_instructions_per_step": vt, "issue_capacity_per_s": 1024 * clk / 4.0, "issue_frac_of_step": vt / (1024 * clk / 4.0 * el / K)}
+            except Exception:
+                valu = None
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_launch": algo_bytes,
                     "whole_step_frac": (bps * C * block * K / el / 1e9) / HBM_PEAK_GBS if world == 1 else None,
-                    "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in ktimes.items()}}
+                    "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in ktimes.items()},
+                    "valu": valu}
 
     out = {
         "metric": "IQ MSamples/sec demodulated to stereo+RDS per GPU; channels @ real-time",

@@ -66,5 +66,32 @@ algo = bench["roofline"]["algorithmic_bytes_per_launch"]
     " (and WRITE_SIZE), " + cfg["workload"] + ".\nCounter unit KiB; reads doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE = 1/2 of a 16 B/lane coalesced stream)."
     " Averages over the steady-state launches.\n\n| kernel | FETCH_SIZE (KiB, raw) | WRITE_SIZE (KiB) | corrected HBM bytes / launch |\n|---|---|---|---|\n"
     + "\n".join(lines) + f"\n\nSum over the chain: {sum(traffic.values()) / 1e6:.0f} MB per block (algorithmic: {algo / 1e6:.1f} MB).\n")
+# VALU instruction counts per launch (wave-instructions) -> how close the pipelined step is to the chip's issue capacity
+try:
+    f = glob.glob(str(src / "pmc_insts" / "*" / "*counter_collection.csv"))[0]
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(f)):
+        per[(r["Dispatch_Id"], r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for (_, name), cs in per.items():
+        for k, v in cs.items():
+            agg[name][k].append(v)
+    insts = {}
+    for short in names:
+        hit = [n for n in agg if short in n]
+        if hit:
+            v = agg[hit[0]]
+            insts[short] = {k: sum(x[len(x) // 2:]) / len(x[len(x) // 2:]) for k, x in v.items()}
+    total_valu = sum(v.get("SQ_INSTS_VALU", 0.0) for v in insts.values())
+    clock_mhz = bench.get("speculation", {}).get("pll_clock_mhz", 2400.0)
+    cap = 1024 * clock_mhz * 1e6 / 4.0          # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles each
+    step_s = bench["ms_per_step"] * 1e-3
+    summary = {"wave_instructions_per_block": insts, "valu_total_per_block": total_valu, "simd_issue_capacity_per_s": cap,
+               "valu_issue_fraction_of_step": total_valu / (cap * step_s), "clock_mhz_used": clock_mhz, "ms_per_step": bench["ms_per_step"]}
+    (dst / "valu_instructions_pmc.json").write_text(json.dumps(summary, indent=1) + "\n")
+    (ROOT / "profiles" / "valu_instructions.json").write_text(json.dumps({"valu_total_per_block" + key_tail: total_valu}, indent=1) + "\n")
+    print(json.dumps(summary, indent=1))
+except Exception as e:   # older gpurun_out without the pass
+    print("no instruction-count pass:", e)
 print(json.dumps(traffic, indent=1))
 print(open(dst / "bench_default_kernel_stats.csv").read()[:3000])
