@@ -44,9 +44,11 @@ __device__ __forceinline__ float& st(float* state, int field, int C, int c) { re
 // recomputed from `tail ++ block` so tiles are independent; the baseband tile is staged in LDS
 // split into M decimation phases, which makes every FIR read unit-stride across lanes.
 // =============================================================================================
-template <int M>
+// TT: fm_out samples per workgroup.  A larger tile recomputes less halo (the 191-sample halo of the three cascaded FIRs costs
+// 19 % extra discriminator work at 512, 9 % at 1024); 1024 is used at 256 kSa/s whenever the block length allows it.
+template <int M, int TT = (M == 8) ? 256 : 512>
 struct FrontGeom {
-    static constexpr int T = (M == 8) ? 256 : 512;
+    static constexpr int T = TT;
     static constexpr int NW = 2 * T + 191;                               // fm_in samples (incl. one for prev_theta)
     static constexpr int TAIL = (M == 1) ? 191 : (190 * M + 64);         // history samples of the input stream
     static constexpr int NB = (M == 1) ? NW : (2 * M * T + TAIL);        // input samples staged per tile
@@ -76,12 +78,12 @@ __device__ __forceinline__ float4 load_iq2(const uchar2* p, size_t i) {
     return make_float4((float)v.x - 127.0f, (float)v.y - 127.0f, (float)v.z - 127.0f, (float)v.w - 127.0f);
 }
 
-template <int M, typename InT>
+template <int M, typename InT, int TT = (M == 8) ? 256 : 512>
 __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
                                                float2* __restrict__ tail_out, float2* __restrict__ fm_out_iq,
                                                float* __restrict__ fm_out_plain, float* __restrict__ fo_tail_out, FrontTaps taps,
                                                int deemph_path) {
-    using G = FrontGeom<M>;
+    using G = FrontGeom<M, TT>;
     constexpr int T = G::T, NW = G::NW, NB = G::NB, PS = G::PS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float2* ph = reinterpret_cast<float2*>(smem);                 // [M][PS]
@@ -1383,13 +1385,16 @@ __global__ void k_reset(Dims d, float* __restrict__ state) {
 // ---------------------------------------------------------------------------------------------
 // host-side stage launchers
 // ---------------------------------------------------------------------------------------------
-template <int M, typename InT>
+template <int M, typename InT, int TT = (M == 8) ? 256 : 512>
 static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq, hipStream_t s) {
-    using G = FrontGeom<M>;
+    using G = FrontGeom<M, TT>;
     const Dims& d = ctx.d;
+    if constexpr (M == 1 && TT == 512) {
+        if (d.n_fm_out % 1024 == 0) return launch_front<1, InT, 1024>(ctx, r, d_iq, s);
+    }
     const int tiles = d.n_fm_out / G::T;
     const size_t lds = sizeof(float) * G::LDS_FLOATS;
-    auto kern = k_front<M, InT>;
+    auto kern = k_front<M, InT, TT>;
     FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), lds, s, d, d_iq, ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1],
                        ctx.b.fm_out_iq[r.buf], ctx.b.fm_out[r.buf], ctx.b.fo_tail[r.par ^ 1], ctx.front, ctx.any_deemph);
     return hipGetLastError();
@@ -1459,10 +1464,10 @@ hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int M, typename InT>
+template <int M, typename InT, int TT = (M == 8) ? 256 : 512>
 static hipError_t prepare_front() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_front<M, InT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(sizeof(float) * FrontGeom<M>::LDS_FLOATS));
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_front<M, InT, TT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(sizeof(float) * FrontGeom<M, TT>::LDS_FLOATS));
 }
 
 hipError_t prepare_kernels() {
@@ -1470,6 +1475,8 @@ hipError_t prepare_kernels() {
     if ((e = prepare_front<1, float2>()) != hipSuccess) return e;
     if ((e = prepare_front<4, float2>()) != hipSuccess) return e;
     if ((e = prepare_front<8, float2>()) != hipSuccess) return e;
+    if ((e = prepare_front<1, float2, 1024>()) != hipSuccess) return e;
+    if ((e = prepare_front<1, uchar2, 1024>()) != hipSuccess) return e;
     if ((e = prepare_front<1, uchar2>()) != hipSuccess) return e;
     if ((e = prepare_front<4, uchar2>()) != hipSuccess) return e;
     if ((e = prepare_front<8, uchar2>()) != hipSuccess) return e;

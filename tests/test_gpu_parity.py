@@ -230,6 +230,13 @@ def test_device_atan2_short_form_is_exact_where_it_claims(pkg):
     assert not ok[n:2 * n][x[n:2 * n] <= 0].any()  # never claimed outside x > 0
 
 
+def test_block_length_that_only_fits_the_small_tiles(pkg):
+    """5120-sample blocks at 256 kSa/s: 2560 fm_out samples (not a multiple of the 1024-sample front tile), 640 audio samples
+    (the 128-sample extract tile), 20 PLL chunks — the less common kernel instantiations."""
+    caps = _caps(3, 12 * 5120, fs=256_000.0, seed=311)
+    _assert_exact(compare_with_oracle(pkg, caps, 5120, 256_000))
+
+
 @pytest.mark.parametrize("pll_kernel", ["time_parallel", "low_work"])
 def test_both_pilot_pll_kernels_are_bit_identical_to_the_oracle(pkg, pll_kernel):
     """The library picks the pilot-PLL kernel by batch size (time-parallel up to 8192 channels, low-work above); both must
