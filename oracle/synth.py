@@ -67,6 +67,8 @@ def fm_capture(
     channel: int = 0,
     noise_sigma: float = 0.02,
     jitter: bool = True,
+    pilot_hz: float = 19000.0,
+    pilot_level: float = 0.10,
 ) -> dict:
     """Complex baseband FM capture of one station.
 
@@ -98,10 +100,10 @@ def fm_capture(
     sym_idx = np.floor(t * RDS_SYMBOL_RATE).astype(np.int64)
     rds = sym[sym_idx]
 
-    p = two_pi * 19000.0 * t
+    p = two_pi * pilot_hz * t   # (pilot_hz / pilot_level other than the defaults: stress cases for the PLL tests)
     mpx = (
         0.40 * (left + right) / 1.6
-        + 0.10 * np.sin(p)
+        + pilot_level * np.sin(p)
         + 0.40 * (left - right) / 1.6 * np.sin(2.0 * p)
         + 0.06 * rds * np.sin(3.0 * p)
     )

@@ -230,6 +230,22 @@ def test_device_atan2_short_form_is_exact_where_it_claims(pkg):
     assert not ok[n:2 * n][x[n:2 * n] <= 0].any()  # never claimed outside x > 0
 
 
+@pytest.mark.parametrize("pll_kernel", ["time_parallel", "low_work"])
+def test_pilot_pll_out_of_its_comfort_zone(pkg, pll_kernel):
+    """Stations the pilot PLL cannot hold: a pilot 130 Hz off (the NCO's +-100 Hz range saturates the control and the
+    integrator: the clamp paths), no pilot at all (phase detector fed noise: every range of atan2f, the serial fall-back), a
+    weak pilot under heavy noise — next to a normal station in the same wavefront.  Bit-identical to the oracle regardless."""
+    n = 8 * 16384
+    caps = np.stack([
+        synth.to_cf32(synth.fm_capture(n, fs=256_000.0, seed=501, channel=0)["iq"]),
+        synth.to_cf32(synth.fm_capture(n, fs=256_000.0, seed=502, channel=1, pilot_hz=19130.0)["iq"]),
+        synth.to_cf32(synth.fm_capture(n, fs=256_000.0, seed=503, channel=2, pilot_level=0.0)["iq"]),
+        synth.to_cf32(synth.fm_capture(n, fs=256_000.0, seed=504, channel=3, pilot_level=0.02, noise_sigma=0.3)["iq"]),
+        synth.to_cf32(synth.fm_capture(n, fs=256_000.0, seed=505, channel=4, pilot_hz=18870.0)["iq"]),
+    ])
+    _assert_exact(compare_with_oracle(pkg, caps, 16384, 256_000, pll_kernel=pll_kernel))
+
+
 def test_block_length_that_only_fits_the_small_tiles(pkg):
     """5120-sample blocks at 256 kSa/s: 2560 fm_out samples (not a multiple of the 1024-sample front tile), 640 audio samples
     (the 128-sample extract tile), 20 PLL chunks — the less common kernel instantiations."""
