@@ -25,6 +25,7 @@ FMD_FLAG_KEEP_TAPS = 1
 FMD_FLAG_NO_PIPELINE = 2
 FMD_FLAG_PLL_TIME_PARALLEL = 4
 FMD_FLAG_PLL_LOW_WORK = 8
+FMD_FLAG_PLL_K8 = 16
 FMD_OK, FMD_ERR_ARG, FMD_ERR_SIZE, FMD_ERR_DEVICE, FMD_ERR_NO_DEVICE, FMD_ERR_NAME = 0, -1, -2, -3, -4, -5
 
 
@@ -185,7 +186,8 @@ class BatchDemod:
         self.L = load_library()
         self.h = C.c_void_p()
         flags = (FMD_FLAG_KEEP_TAPS if keep_taps else 0) | (0 if pipelined else FMD_FLAG_NO_PIPELINE)
-        flags |= {"auto": 0, "time_parallel": FMD_FLAG_PLL_TIME_PARALLEL, "low_work": FMD_FLAG_PLL_LOW_WORK}[pll_kernel]
+        flags |= {"auto": 0, "time_parallel": FMD_FLAG_PLL_TIME_PARALLEL, "time_parallel8": FMD_FLAG_PLL_TIME_PARALLEL | FMD_FLAG_PLL_K8,
+                  "low_work": FMD_FLAG_PLL_LOW_WORK}[pll_kernel]
         cfg = Config(n_channels, block_size, fs_baseband, device, flags)
         rc = self.L.fmd_create(C.byref(cfg), C.byref(self.h))
         if rc != FMD_OK:

@@ -105,6 +105,7 @@ struct LaunchCtx {
     int any_deemph;
     int bytes_cap;
     int pll_time_parallel_max_channels;   // batches up to this size use the time-parallel PLL kernel, larger ones the low-work one
+    int pll_k16_max_channels;             // (channels x m) up to this: 16 lanes per channel, above: 8
 };
 
 // One launcher per pipeline stage of one block.  The host (fmd_api.cpp) places the stages on

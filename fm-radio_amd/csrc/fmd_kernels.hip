@@ -427,20 +427,19 @@ __device__ __forceinline__ float atan2f_locked(float y, float x, const PllConsts
     return t - t * (s1 + s2);
 }
 
-#ifndef FMD_PLL_K
-#define FMD_PLL_K 16
-#endif
-static constexpr int kPllK = FMD_PLL_K;       // lanes (= consecutive samples) per channel
-static constexpr int kPllG = kWave / kPllK;   // channels per wavefront
 static constexpr int kPllChunk = 128;         // samples per chunk
 static constexpr int kPllRing = 2 * kPllChunk;
-static constexpr int kPllSlowSpans = 3 * kPllChunk / kPllK;   // a chunk that needed more spans than this is "out of lock"
 static constexpr int kSlowHoldMax = 16;       // longest run of serial chunks between two speculation attempts
 
+// K = lanes (= consecutive samples) per channel.  K = 16 gives the shortest latency (4 channels per wavefront, 1024 wavefronts
+// for 4096 channels); K = 8 spends 30 % fewer VALU instructions (8 channels per wavefront share the serial parts) for ~25 %
+// more latency — better as soon as the chip, not a lone wavefront, is the limit.
+template <int K>
 __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
                                                      float* __restrict__ state, LoopCoeffs k, int power_field,
                                                      unsigned long long* __restrict__ spec_stats) {
-    constexpr int K = kPllK, G = kPllG, CH = kPllChunk, RING = kPllRing;
+    constexpr int G = kWave / K, CH = kPllChunk, RING = kPllRing;
+    constexpr int kPllSlowSpans = 3 * CH / K;     // a chunk that needed more spans than this is "out of lock"
     __shared__ __attribute__((aligned(16))) float2 xin[G][RING];   // pilot samples, ring by (sample index & 255)
     __shared__ __attribute__((aligned(16))) float dts[G][RING];    // results, same ring
     __shared__ __attribute__((aligned(16))) float ex[G][K + 4];    // [0] = err_prev, [1 + i] = err_i of the current span
@@ -1435,8 +1434,13 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
                    ctx.b.state, ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
         return hipGetLastError();
     }
-    FMD_LAUNCH(r, true, true, k_pilot_pll, dim3((unsigned)((d.C + kPllG - 1) / kPllG)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
-                       ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
+    if (d.C * d.m <= ctx.pll_k16_max_channels) {
+        FMD_LAUNCH(r, true, true, k_pilot_pll<16>, dim3((unsigned)((d.C + 3) / 4)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
+                   ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
+    } else {
+        FMD_LAUNCH(r, true, true, k_pilot_pll<8>, dim3((unsigned)((d.C + 7) / 8)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
+                   ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
+    }
     return hipGetLastError();
 }
 

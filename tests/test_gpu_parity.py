@@ -230,7 +230,7 @@ def test_device_atan2_short_form_is_exact_where_it_claims(pkg):
     assert not ok[n:2 * n][x[n:2 * n] <= 0].any()  # never claimed outside x > 0
 
 
-@pytest.mark.parametrize("pll_kernel", ["time_parallel", "low_work"])
+@pytest.mark.parametrize("pll_kernel", ["time_parallel", "time_parallel8", "low_work"])
 def test_pilot_pll_out_of_its_comfort_zone(pkg, pll_kernel):
     """Stations the pilot PLL cannot hold: a pilot 130 Hz off (the NCO's +-100 Hz range saturates the control and the
     integrator: the clamp paths), no pilot at all (phase detector fed noise: every range of atan2f, the serial fall-back), a
@@ -253,7 +253,7 @@ def test_block_length_that_only_fits_the_small_tiles(pkg):
     _assert_exact(compare_with_oracle(pkg, caps, 5120, 256_000))
 
 
-@pytest.mark.parametrize("pll_kernel", ["time_parallel", "low_work"])
+@pytest.mark.parametrize("pll_kernel", ["time_parallel", "time_parallel8", "low_work"])
 def test_both_pilot_pll_kernels_are_bit_identical_to_the_oracle(pkg, pll_kernel):
     """The library picks the pilot-PLL kernel by batch size (time-parallel up to 8192 channels, low-work above); both must
     produce the oracle's bits, through acquisition and in lock, for channel counts that do not fill a wavefront."""
