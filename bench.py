@@ -221,6 +221,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step audio all-gather at N>1")
     ap.add_argument("--no-kernel-times", action="store_true", help="do not attach HIP timing events to the kernels of the timed region (no roofline object; ~2 %% faster)")
+    ap.add_argument("--pll-kernel", default="auto", choices=["auto", "time_parallel", "time_parallel8", "low_work"],
+                    help="force one of the pilot-PLL kernels (default: chosen by batch size; same results either way)")
     ap.add_argument("--no-pipeline", action="store_true", help="run the stages of a block back to back on one stream")
     ap.add_argument("--wideband", action="store_true", help="BASELINE configs[4] instead of configs[2]: one 10 MSa/s capture, 40 stations "
                     "through the on-GPU channeliser, then the batched demodulator (single GPU)")
@@ -265,7 +267,7 @@ def main() -> None:
     n_blocks_resident = min(K + W + P, 8)  # distinct consecutive blocks kept in HBM, cycled
     x = synth_block_device(torch, C, n_blocks_resident * block, float(fs), 1234 + rank, device, args.u8)
     x = x.view(C, n_blocks_resident, block, 2).permute(1, 0, 2, 3).contiguous()  # [blocks][C][N][2]
-    dm = pkg.BatchDemod(C, block, fs, device=local_rank, pipelined=not args.no_pipeline)
+    dm = pkg.BatchDemod(C, block, fs, device=local_rank, pipelined=not args.no_pipeline, pll_kernel=args.pll_kernel)
 
     do_gather = world > 1 and not args.no_gather
     if do_gather:

@@ -1121,12 +1121,23 @@ __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict
 // a11 — reference ExtractComponents :511-516: integrate the mean L-R phase error of the block (sequential sum in sample order).
 // Its own small kernel, right behind k_extract on the same stream: the next block's k_extract needs the updated offset, the
 // (long, serial) k_rds_sync of this block does not, so that one runs on a stream of its own.
-__global__ void k_lmr_phase(Dims d, const float* __restrict__ lmr_est, float* __restrict__ state) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d.C) return;
+__global__ __launch_bounds__(kWave) void k_lmr_phase(Dims d, const float* __restrict__ lmr_est, float* __restrict__ state) {
+    constexpr int TILE = 128;                            // estimates per channel staged at a time
+    __shared__ float est[kWave][TILE + 1];
+    const int c0 = blockIdx.x * kWave, c = c0 + threadIdx.x;
+    const int rows = (d.C - c0) < kWave ? (d.C - c0) : kWave;
     float sum = 0.0f;
-    const float* e = lmr_est + (size_t)c * d.n_est;
-    for (int i = 0; i < d.n_est; i++) sum = sum + e[i];
+    for (int base = 0; base < d.n_est; base += TILE) {
+        const int w = (d.n_est - base) < TILE ? (d.n_est - base) : TILE;
+        __syncthreads();
+        for (int i = threadIdx.x; i < rows * w; i += kWave) {     // row-contiguous reads
+            const int r = i / w, col = i - r * w;
+            est[r][col] = lmr_est[(size_t)(c0 + r) * d.n_est + base + col];
+        }
+        __syncthreads();
+        for (int i = 0; i < w; i++) sum = sum + est[threadIdx.x][i];   // sequential, in sample order
+    }
+    if (c >= d.C) return;
     const float avg = sum / (float)d.n_est;
     const float cur = st(state, S_LMR_PHASE_CUR, d.C, c);
     const float acc = fmaf(avg, 0.1f, cur);
@@ -1456,7 +1467,7 @@ static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
 hipError_t launch_stage_extract(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     if (ctx.d.n_audio % 256 == 0) launch_extract_ta<256>(ctx, r, s);
     else launch_extract_ta<128>(ctx, r, s);
-    hipLaunchKernelGGL(k_lmr_phase, dim3((unsigned)((ctx.d.C + 255) / 256)), dim3(256), 0, s, ctx.d, ctx.b.lmr_est, ctx.b.state);
+    hipLaunchKernelGGL(k_lmr_phase, dim3(serial_waves(ctx.d)), dim3(kWave), 0, s, ctx.d, ctx.b.lmr_est, ctx.b.state);
     return hipGetLastError();
 }
 

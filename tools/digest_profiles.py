@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/prof/ (written by tools/collect_profiles.sh on the GPU box) into the tracked summaries under profiles/."""
-import csv, glob, json, sys, collections, pathlib
+import csv, glob, json, os, sys, collections, pathlib
+
+
+def newest(pattern):
+    """gpurun merges every run's files into gpurun_out/: take the most recent match."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 src = ROOT / "gpurun_out" / "prof"
@@ -12,7 +18,7 @@ bench = json.loads((src / "bench_default.json").read_text().strip().splitlines()
 (dst / "bench_default.json").write_text(json.dumps(bench, indent=1) + "\n")
 under = json.loads((src / "bench_under_rocprof.json").read_text().strip().splitlines()[-1])
 
-stats = glob.glob(str(src / "stats" / "*" / "*kernel_stats.csv"))[0]
+stats = newest(str(src / "stats" / "*" / "*kernel_stats.csv"))
 rows = [r for r in csv.DictReader(open(stats))]
 with open(dst / "bench_default_kernel_stats.csv", "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline   (durations in ns)\n")
@@ -21,7 +27,7 @@ with open(dst / "bench_default_kernel_stats.csv", "w") as f:
     for r in rows:
         w.writerow(r)
     # the --stats averages include the pre-roll and warmup launches (loop acquisition); the timed region is the last `steps` launches
-    trace = glob.glob(str(src / "stats" / "*" / "*kernel_trace.csv"))[0]
+    trace = newest(str(src / "stats" / "*" / "*kernel_trace.csv"))
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
         per[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
@@ -35,7 +41,7 @@ with open(dst / "bench_default_kernel_stats.csv", "w") as f:
     f.write("# bench.py's own HIP-event averages in the same run (ms): " + json.dumps(under["roofline"]["kernels_ms_per_step"]) + "\n")
 
 def pmc(counter):
-    f = glob.glob(str(src / f"pmc_{counter}" / "*" / "*counter_collection.csv"))[0]
+    f = newest(str(src / f"pmc_{counter}" / "*" / "*counter_collection.csv"))
     agg = collections.defaultdict(list)
     per_dispatch = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
@@ -68,7 +74,7 @@ algo = bench["roofline"]["algorithmic_bytes_per_launch"]
     + "\n".join(lines) + f"\n\nSum over the chain: {sum(traffic.values()) / 1e6:.0f} MB per block (algorithmic: {algo / 1e6:.1f} MB).\n")
 # VALU instruction counts per launch (wave-instructions) -> how close the pipelined step is to the chip's issue capacity
 try:
-    f = glob.glob(str(src / "pmc_insts" / "*" / "*counter_collection.csv"))[0]
+    f = newest(str(src / "pmc_insts" / "*" / "*counter_collection.csv"))
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(f)):
         per[(r["Dispatch_Id"], r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
