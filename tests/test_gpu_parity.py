@@ -290,6 +290,33 @@ def test_gpu_runs_are_deterministic(pkg):
     assert np.array_equal(a["rds_count"], b["rds_count"])
 
 
+def test_pipelined_and_sequential_execution_agree_at_scale(pkg):
+    """1500 stations x 8 blocks: the five-stream pipeline with four blocks in flight against every stage back to back on one
+    stream — any missing dependency between stages of neighbouring blocks would show up as a difference (run twice: a race
+    need not fire every time)."""
+    import torch
+    n_ch, bs, nb = 1500, 16384, 8
+    base = _caps(6, nb * bs, fs=256_000.0, seed=1300)
+    idx = torch.from_numpy(np.arange(n_ch) % 6).cuda()
+    blocks = [torch.from_numpy(np.ascontiguousarray(base[:, b * bs:(b + 1) * bs])).cuda()[idx].contiguous() for b in range(nb)]
+
+    def run(pipelined):
+        dm = pkg.BatchDemod(n_ch, bs, 256_000, pipelined=pipelined)
+        for blk in blocks[:-1]:
+            assert dm.process(blk) == 0                      # queued back to back: up to four blocks in flight, no host sync
+        assert dm.process(blocks[-1]) == 0
+        a = dm.audio()                                       # every stage's state feeds forward: one wrong sample anywhere shows here
+        by, cnt = dm.rds_bytes()
+        syms, scnt = dm.rds_symbols()
+        dm.close()
+        return (hashlib.sha256(a.tobytes()).hexdigest(), hashlib.sha256(by.tobytes() + cnt.tobytes()).hexdigest(),
+                hashlib.sha256(syms.tobytes() + scnt.tobytes()).hexdigest())
+
+    ref = run(False)
+    assert run(True) == ref
+    assert run(True) == ref
+
+
 def test_cpp_host_adaptor_matches_oracle(pkg, tmp_path):
     """The C++ adaptor (fm-radio_amd/host/broadcast_fm_demod_gpu.hpp: reference method names over the C ABI, App-style u8
     re-blocking) driven like the reference's own mains, against the oracle."""
