@@ -57,6 +57,11 @@ struct fmd_handle_s {
 
 namespace {
 
+// The pipeline keeps five streams busy beside the caller's; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default
+// 4) and dependent stages sharing a queue block each other.  Ask for 8 when the library is loaded, unless the process already
+// chose (only effective before the HIP runtime initialises).
+__attribute__((constructor)) void fmd_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 thread_local std::string g_create_error;
 
 int fail(fmd_handle h, int code, const char* fmt, ...) {
