@@ -20,8 +20,8 @@
 using namespace fmd;
 
 // Stage placement: k_front on sF, k_pilot_power on sA, k_pilot_pll on sB, k_extract (+ k_lmr_phase) on sX, k_rds_sync on sR.
-// Blocks alternate between two buffer slots, so in steady state the serial PLL stage of block b runs while the
-// front end of block b+1 and the extract/RDS stages of block b-1 use the rest of the chip.
+// Blocks rotate through kSlots buffer slots and every stage waits only for its producer (HIP events), so in steady state
+// all stages run concurrently on different blocks.
 enum Stage { ST_FRONT = 0, ST_DEEMPH, ST_POWER, ST_PLL, ST_EXTRACT, ST_RDS, ST_COUNT };
 static const char* const kStageName[ST_COUNT] = {"k_front", "k_deemphasis+k_hilbert", "k_pilot_power", "k_pilot_pll", "k_extract", "k_rds_sync"};
 

@@ -6,10 +6,12 @@
 //   k_front        [parallel]  a0 u8->f32, a1 decimating FIR, a2 arctan discriminator, a3 decimating FIR,
 //                              a5 Hilbert FIR  -> fm_out_iq            (LDS-staged, halo recomputed per tile)
 //   k_pilot_power  [serial]    a6 pilot peak IIR + a7 AGC power sum     -> pilot   (lane per channel, LDS transpose)
-//   k_pilot_pll    [serial]    a7 gain, a8 PLL loop                     -> pll_dt
+//   k_pilot_pll    [serial*]   a7 gain, a8 PLL loop                     -> pll_dt  (*time-parallel under frequency speculation:
+//                              16 or 8 lanes = consecutive samples of one channel; k_pilot_pll_pairs = low-work variant)
 //   k_extract      [parallel]  a9 x2/x3 harmonic mixers fused into a10/a12 decimating FIRs, a11 phase
 //                              estimates, a15 audio mix                -> audio, rds, lmr_est
-//   k_rds_sync     [serial]    a11 phase integrate, a13 AGC, a14 BPSK synchroniser, Manchester decode
+//   k_lmr_phase    [tiny]      a11 phase integrate (the next block's k_extract needs it)
+//   k_rds_sync     [serial]    a13 AGC, a14 BPSK synchroniser, Manchester decode   (own stream)
 //
 // Arithmetic contract: this file is compiled with -ffp-contract=off; every fused multiply-add is an
 // explicit fmaf() and every sum is associated exactly as the reference's AVX2+FMA build associates it
