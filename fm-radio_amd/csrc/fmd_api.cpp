@@ -607,7 +607,7 @@ int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats
     return FMD_OK;
 }
 
-static int selftest_atan2_host(const float* y, const float* x, float* out, uint8_t* ok, size_t n) {
+static int selftest_atan2_host(const float* y, const float* x, float* out, uint8_t* ok, size_t n, int table_form = 0) {
     if (!y || !x || !out) return FMD_ERR_ARG;
     if (fmd_device_count() <= 0) return fail(nullptr, FMD_ERR_NO_DEVICE, "no gfx950 device");
     float *dy = nullptr, *dx = nullptr, *dout = nullptr;
@@ -617,7 +617,7 @@ static int selftest_atan2_host(const float* y, const float* x, float* out, uint8
     if (hipMalloc(&dy, bytes) != hipSuccess || hipMalloc(&dx, bytes) != hipSuccess || hipMalloc(&dout, bytes) != hipSuccess) rc = FMD_ERR_DEVICE;
     if (!rc && ok && hipMalloc(&dok, n) != hipSuccess) rc = FMD_ERR_DEVICE;
     if (!rc && (hipMemcpy(dy, y, bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice) != hipSuccess)) rc = FMD_ERR_DEVICE;
-    if (!rc && selftest_atan2(dy, dx, dout, dok, n, nullptr) != hipSuccess) rc = FMD_ERR_DEVICE;
+    if (!rc && selftest_atan2(dy, dx, dout, dok, n, table_form, nullptr) != hipSuccess) rc = FMD_ERR_DEVICE;
     if (!rc && hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = FMD_ERR_DEVICE;
     if (!rc && ok && hipMemcpy(ok, dok, n, hipMemcpyDeviceToHost) != hipSuccess) rc = FMD_ERR_DEVICE;
     if (dy) (void)hipFree(dy);
@@ -628,6 +628,8 @@ static int selftest_atan2_host(const float* y, const float* x, float* out, uint8
 }
 
 int fmd_selftest_atan2(const float* y, const float* x, float* out, size_t n) { return selftest_atan2_host(y, x, out, nullptr, n); }
+
+int fmd_selftest_atan2_table(const float* y, const float* x, float* out, size_t n) { return selftest_atan2_host(y, x, out, nullptr, n, 1); }
 
 int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t* ok, size_t n) {
     if (!ok) return FMD_ERR_ARG;

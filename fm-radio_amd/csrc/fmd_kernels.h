@@ -117,7 +117,7 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s);    
 hipError_t launch_stage_extract(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                           // k_extract
 hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                               // k_rds_sync
 hipError_t launch_reset_state(const LaunchCtx& ctx, hipStream_t stream);
-hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, unsigned char* d_ok, size_t n, hipStream_t s);
+hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, unsigned char* d_ok, size_t n, int table_form, hipStream_t s);
 hipError_t prepare_kernels();          // one-time function attributes (dynamic LDS sizes)
 int front_tail_len(int m);             // input-history samples k_front needs per channel
 

@@ -63,7 +63,8 @@ struct FrontGeom {
     static constexpr int OFF_THETA = 2 * M * PS * (M > 1);
     static constexpr int OFF_DEM = OFF_THETA + NWP;
     static constexpr int OFF_FO = OFF_DEM + NWP;
-    static constexpr int LDS_FLOATS = OFF_FO + (T + 64);
+    static constexpr int OFF_ATAN = (OFF_FO + (T + 64) + 7) & ~7;        // AtanTable (32-byte aligned rows)
+    static constexpr int LDS_FLOATS = OFF_ATAN + kAtanTableWords;
     static_assert(OFF_THETA % 4 == 0 && OFF_DEM % 4 == 0 && OFF_FO % 4 == 0, "LDS sub-arrays must be 16-byte aligned");
 };
 
@@ -92,7 +93,9 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
     float* theta = smem + G::OFF_THETA;                           // [NW]
     float* dem = smem + G::OFF_DEM;                               // [NW-1]
     float* fo = smem + G::OFF_FO;                                 // [T+64]
+    AtanTable* atab = reinterpret_cast<AtanTable*>(smem + G::OFF_ATAN);
     (void)ph;
+    atan_table_fill(atab, threadIdx.x, 256);                      // visible after the first barrier below
 
     const int tiles = d.n_fm_out / T;
     const int c = blockIdx.x / tiles;
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
             }
             const float re = (ar[0] + ar[2]) + (ar[1] + ar[3]);
             const float im = (ai[0] + ai[2]) + (ai[1] + ai[3]);
-            theta[i] = fmd_atan2f(im, re);
+            theta[i] = fmd_atan2f_table(im, re, atab);
         }
     } else {
         constexpr int PER = (NW + 255) / 256;
@@ -163,10 +166,11 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
                 buf[r] = (g < 0) ? tail_c[G::TAIL + g] : load_iq(in_c, (size_t)g);
             }
         }
+        __syncthreads();   // the arctangent table
 #pragma unroll
         for (int r = 0; r < PER; r++) {
             const int i = tid + 256 * r;
-            if (i < NW) theta[i] = fmd_atan2f(buf[r].y, buf[r].x);
+            if (i < NW) theta[i] = fmd_atan2f_table(buf[r].y, buf[r].x, atab);
         }
     }
     __syncthreads();
@@ -1366,10 +1370,15 @@ __global__ __launch_bounds__(256) void k_hilbert(Dims d, const float* __restrict
 }
 
 __global__ void k_selftest_atan2(const float* __restrict__ y, const float* __restrict__ x, float* __restrict__ out,
-                                 unsigned char* __restrict__ ok_out, size_t n) {
+                                 unsigned char* __restrict__ ok_out, size_t n, int table_form) {
+    __shared__ AtanTable atab;
+    atan_table_fill(&atab, threadIdx.x, blockDim.x);
+    __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (ok_out) {   // the locked-loop short form of k_pilot_pll's phase detector and its domain predicate
+    if (table_form) {   // k_front's discriminator
+        out[i] = fmd_atan2f_table(y[i], x[i], &atab);
+    } else if (ok_out) {   // the locked-loop short form of k_pilot_pll's phase detector and its domain predicate
         LoopCoeffs k{};
         const PllConsts c = make_pll_consts(k);
         bool ok;
@@ -1380,8 +1389,8 @@ __global__ void k_selftest_atan2(const float* __restrict__ y, const float* __res
     }
 }
 
-hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, unsigned char* d_ok, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_selftest_atan2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_y, d_x, d_out, d_ok, n);
+hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, unsigned char* d_ok, size_t n, int table_form, hipStream_t s) {
+    hipLaunchKernelGGL(k_selftest_atan2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_y, d_x, d_out, d_ok, n, table_form);
     return hipGetLastError();
 }
 

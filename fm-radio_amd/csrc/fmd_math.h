@@ -237,6 +237,106 @@ FMD_HD float div_unscaled(float y, float x) {
     return fmaf(e2, r, q);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Throughput form of atan2f for the discriminator (k_front: two of these per output sample, every range equally likely).
+// Same operations as fmd_atan2f, arranged for the fewest issued instructions rather than the shortest dependent chain:
+//  * the five argument ranges differ only in constants, so they come from a 5-row table indexed through a byte map of
+//    bits(|y/x|) >> 18 (all four range thresholds are multiples of 2^18):  num = fma(cn, a, bn), den = ce*a + bd,
+//    result = hi - ((p - lo) - num/den).  Row 0 (|a| < 7/16: num = a, den = 1, hi = lo = 0) reproduces 'a - p', and the
+//    |a| < 2^-29 early return as well, because there p is far below half an ulp of a.
+//  * num/den never needs the IEEE division's operand scaling or special-value fix-up (den in [1, 2^25), num 0 or in
+//    [2^-24, 2^25), or num = a, den = 1), so it is the bare expansion div_unscaled();
+//  * |a| >= 2^25 (including the infinity of a zero x) and the sign/quadrant fix-up are two selects and a sign transplant.
+// The table lives in LDS on the device (AtanTable filled by atan_table_fill) and in ordinary memory on the host.
+// ---------------------------------------------------------------------------------------------
+struct alignas(32) AtanTable {
+    float cls[5][8];   // cn, bn, ce, bd, hi, lo, -, -
+    uint8_t idx[96];   // byte offset of the row for clamp(bits >> 18 & 0x1fff, kAtanIdxLo, kAtanIdxHi) - kAtanIdxLo
+};
+constexpr uint32_t kAtanIdxLo = 0x0fb7u;     // anything below 0x3ee00000 (7/16)
+constexpr uint32_t kAtanIdxHi = 0x1007u;     // 0x401c0000 (39/16) and above
+constexpr uint32_t kAtanIdxHuge = 0x1300u;   // 0x4c000000 (2^25) and above, infinity included
+constexpr int kAtanTableWords = (int)(sizeof(AtanTable) / 4);
+
+// word w of the table image (the idx bytes packed little-endian four to a word)
+FMD_HD uint32_t atan_table_word(int w) {
+    if (w < 40) {
+        const int row = w >> 3, col = w & 7;
+        const uint32_t one = 0x3f800000u, two = 0x40000000u, m_one = 0xbf800000u;
+        switch (row * 8 + col) {
+            case 0: return one;  case 3: return one;                                  // |a| < 7/16: a / 1
+            case 8: return two;  case 9: return m_one; case 10: return one; case 11: return two;      // (2a - 1) / (2 + a)
+            case 12: return 0x3eed6338u; case 13: return 0x31ac3769u;
+            case 16: return one; case 17: return m_one; case 18: return one; case 19: return one;     // (a - 1) / (a + 1)
+            case 20: return 0x3f490fdau; case 21: return 0x33222168u;
+            case 24: return one; case 25: return 0xbfc00000u; case 26: return 0x3fc00000u; case 27: return one;  // (a - 1.5) / (1 + 1.5a)
+            case 28: return 0x3f7b985eu; case 29: return 0x33140fb4u;
+            case 33: return m_one; case 34: return one;                               // -1 / a
+            case 36: return 0x3fc90fdau; case 37: return 0x33a22168u;
+            default: return 0u;
+        }
+    }
+    uint32_t v = 0;
+    for (int b = 0; b < 4; b++) {
+        const uint32_t e = kAtanIdxLo + (uint32_t)((w - 40) * 4 + b);
+        const uint32_t row = (e >= 0x1007u) ? 4u : (e >= 0x0fe6u) ? 3u : (e >= 0x0fccu) ? 2u : (e >= 0x0fb8u) ? 1u : 0u;
+        v |= (row * 32u) << (8 * b);
+    }
+    return v;
+}
+FMD_HD void atan_table_fill(AtanTable* t, int first, int stride) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(t);
+    for (int i = first; i < kAtanTableWords; i += stride) w[i] = atan_table_word(i);
+}
+
+struct alignas(16) AtanRowA { float cn, bn, ce, bd; };
+struct alignas(8) AtanRowB { float hi, lo; };
+
+FMD_HD float fmd_atan2f_table(float y, float x, const AtanTable* t) {
+    const uint32_t hx = f32_bits(x), hy = f32_bits(y);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // zero, infinity or NaN in either operand
+    const bool special = __builtin_amdgcn_classf(x, 0x267) | __builtin_amdgcn_classf(y, 0x267);
+#else
+    const uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+    const bool special = (ix == 0u) | (iy == 0u) | (ix >= 0x7f800000u) | (iy >= 0x7f800000u);
+#endif
+    const float q = y / x;
+    const float a = fabsf(q);
+    uint32_t e = (f32_bits(q) >> 18) & 0x1fffu;
+    const bool huge = e >= kAtanIdxHuge;
+    e = e < kAtanIdxLo ? kAtanIdxLo : e;
+    e = e > kAtanIdxHi ? kAtanIdxHi : e;
+    const char* row = reinterpret_cast<const char*>(t->cls) + t->idx[e - kAtanIdxLo];
+    const AtanRowA ra = *reinterpret_cast<const AtanRowA*>(row);
+    const AtanRowB rb = *reinterpret_cast<const AtanRowB*>(row + 16);
+    const float num = fmaf(ra.cn, a, ra.bn);
+    const float den = ra.ce * a + ra.bd;
+    const float xr = div_unscaled(num, den);
+    const float z = xr * xr;
+    const float w = z * z;
+    float s1 = bits_f32(0x3d4bda59u) + w * bits_f32(0x3c8569d7u);
+    s1 = bits_f32(0x3d886b35u) + w * s1;
+    s1 = bits_f32(0x3dba2e6eu) + w * s1;
+    s1 = bits_f32(0x3e124925u) + w * s1;
+    s1 = bits_f32(0x3eaaaaabu) + w * s1;
+    s1 = z * s1;
+    float s2 = bits_f32(0xbd6ef16bu) + w * bits_f32(0xbd15a221u);
+    s2 = bits_f32(0xbd9d8795u) + w * s2;
+    s2 = bits_f32(0xbde38e38u) + w * s2;
+    s2 = bits_f32(0xbe4ccccdu) + w * s2;
+    s2 = w * s2;
+    const float p = xr * (s1 + s2);
+    float at = rb.hi - ((p - rb.lo) - xr);
+    at = huge ? bits_f32(kHalfPiBits) : at;
+    // x < 0: pi - (at - pi_lo); then the sign of y (the published m = 1 and m = 3 cases are the negations of m = 0 and m = 2)
+    const float refl = bits_f32(kPiBits) - (at - bits_f32(0xb3bbbd2eu));
+    const float mag = (hx >> 31) ? refl : at;
+    float r = bits_f32((f32_bits(mag) & 0x7fffffffu) | (hy & 0x80000000u));
+    if (special) r = fmd_atan2f_full(y, x);
+    return r;
+}
+
 // std::round as the reference build inlines it: trunc(x + copysign(pred(0.5), x))
 FMD_HD float round_half_away(float x) { return truncf(x + copysignf(bits_f32(kPredHalfBits), x)); }
 

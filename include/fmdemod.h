@@ -161,6 +161,8 @@ typedef struct {
 /* Self-test hook: evaluates the kernels' atan2f on the device for n host-side (y, x) pairs, so tests can compare
  * the device math bit-for-bit with the host libm the reference links (std::atan2, reference fm_demod.cpp:40). */
 int fmd_selftest_atan2(const float* y, const float* x, float* out, size_t n);
+/* Same for the table-driven form the discriminator (k_front) uses: identical values, fewer issued instructions. */
+int fmd_selftest_atan2_table(const float* y, const float* x, float* out, size_t n);
 /* Same for the short form k_pilot_pll's phase detector uses on a locked loop: out[i] is only meaningful where ok[i] != 0, and
  * there it must equal atan2f(y[i], x[i]) bit-for-bit (DESIGN.md "Pilot PLL"). */
 int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t* ok, size_t n);

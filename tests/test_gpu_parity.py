@@ -196,11 +196,13 @@ def test_device_atan2_equals_host_libm(pkg):
     gy, gx = np.meshgrid(sp, sp)
     ys.append(gy.reshape(-1)); xs.append(gx.reshape(-1))
     y = np.concatenate(ys); x = np.concatenate(xs)
-    dev = pkg.selftest_atan2(y, x)
     host = O.libm_atan2f(y, x)
-    nan = np.isnan(host) & np.isnan(dev)
-    neq = (dev.view(np.uint32) != host.view(np.uint32)) & ~nan
-    assert not neq.any(), f"{int(neq.sum())} mismatches, first: y={y[neq][0]!r} x={x[neq][0]!r} dev={dev[neq][0]!r} host={host[neq][0]!r}"
+    for table_form in (False, True):   # the general form (serial loops, phase estimate) and the discriminator's table-driven form
+        dev = pkg.selftest_atan2(y, x, table_form=table_form)
+        nan = np.isnan(host) & np.isnan(dev)
+        neq = (dev.view(np.uint32) != host.view(np.uint32)) & ~nan
+        assert not neq.any(), (f"table_form={table_form}: {int(neq.sum())} mismatches, first: y={y[neq][0]!r} x={x[neq][0]!r} "
+                               f"dev={dev[neq][0]!r} host={host[neq][0]!r}")
 
 
 def test_device_atan2_short_form_is_exact_where_it_claims(pkg):
