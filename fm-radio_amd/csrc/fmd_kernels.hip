@@ -60,20 +60,12 @@ struct FrontGeom {
     // LDS carve-up in floats; every sub-array starts on a 16-byte boundary (a ds_read_b64 that is only 4-byte
     // aligned is replayed at ~64 cycles per wave instruction)
     static constexpr int NWP = (NW + 3) & ~3;
-    // The two real FIRs run as MFMA chains over groups of 52 outputs (see fir_rows_mfma): G3 groups of the decimate-by-2
-    // stage, G5 groups (of 52 even + 52 odd outputs) of the Hilbert stage.  Their inputs are kept split into even and odd
-    // samples; NH / FH = entries per half, including what the last group's unused lanes read past the end.
-    static constexpr int G3 = (T + 64 + 51) / 52;
-    static constexpr int G5 = (T / 2 + 51) / 52;
-    static constexpr int NH = (52 * G3 + 12 + 28 + 3) & ~3;
-    static constexpr int FH = (52 * G5 + 12 + 29 + 3) & ~3;
     static constexpr int OFF_THETA = 2 * M * PS * (M > 1);
-    static constexpr int OFF_DEM = OFF_THETA + NWP;                       // [2][NH]  demodulated signal, even / odd samples
-    static constexpr int OFF_FO = OFF_DEM + 2 * NH;                       // [2][FH]  fm_out incl. 64 history samples, even / odd
-    static constexpr int OFF_ATAN = (OFF_FO + 2 * FH + 7) & ~7;           // AtanTable (32-byte aligned rows)
+    static constexpr int OFF_DEM = OFF_THETA + NWP;
+    static constexpr int OFF_FO = OFF_DEM + NWP;
+    static constexpr int OFF_ATAN = (OFF_FO + (T + 64) + 7) & ~7;        // AtanTable (32-byte aligned rows)
     static constexpr int LDS_FLOATS = OFF_ATAN + kAtanTableWords;
     static_assert(OFF_THETA % 4 == 0 && OFF_DEM % 4 == 0 && OFF_FO % 4 == 0, "LDS sub-arrays must be 16-byte aligned");
-    static_assert(2 * NH >= NW && 2 * FH >= T + 64, "split arrays hold the whole tile");
 };
 
 __device__ __forceinline__ float2 load_iq(const float2* p, size_t i) { return p[i]; }
@@ -89,32 +81,8 @@ __device__ __forceinline__ float4 load_iq2(const uchar2* p, size_t i) {
     return make_float4((float)v.x - 127.0f, (float)v.y - 127.0f, (float)v.z - 127.0f, (float)v.w - 127.0f);
 }
 
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-// Lane i of a 16-lane row reads lane i + SH of the same row (rows' last SH lanes get 0: callers do not use them).
-template <int SH>
-__device__ __forceinline__ float dpp_row_shl(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + SH, 0xf, 0xf, true));
-}
-
-// The reference's 8-lane real FIRs (f32_cum_mul.cpp:52-78: accumulator lane L sums taps 8 jj + L in increasing jj) on the
-// matrix cores.  v_mfma_f32_4x4x1_16b_f32 is per element D = fmaf(a, b, C) (one rounding, subnormals kept), so a chain over
-// jj repeats the reference's accumulation order exactly.  For four accumulator lanes that read the same input parity
-// (L = 2 l + q, l = 0..3), with x_q[s] = x[2 s + q]:
-//     acc_L[t] = sum_jj b[8 jj + L] x[2 t + 8 jj + L] = R[l][t + l],   R[l][tau] = sum_jj A[l][jj] x_q[tau + 4 jj]
-// R is a dense 4 x 8 by 8 x 64 product: A[l][jj] = b[8 jj + L] (held in registers: lane & 3 = l), B[jj][tau] = x_q[tau + 4 jj]
-// (unit-stride LDS reads).  The row-dependent shift t + l is undone with DPP row shifts when the four rows are added, which
-// limits every 16-lane row to 13 outputs: lane (16 w + i) works on column tau = 13 w + i of its group of 52.
-// Returns (R0[tau] + R2[tau + 2]) + (R1[tau + 1] + R3[tau + 3]) = (acc_q + acc_{4+q}) + (acc_{2+q} + acc_{6+q}) for lanes i < 13.
-__device__ __forceinline__ float fir_rows_mfma(const float (&a)[8], const float* __restrict__ xq_tau) {
-    v4f acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int jj = 0; jj < 8; jj++) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[jj], xq_tau[4 * jj], acc, 0, 0, 0);
-    return (acc[0] + dpp_row_shl<2>(acc[2])) + (dpp_row_shl<1>(acc[1]) + dpp_row_shl<3>(acc[3]));
-}
-
 template <int M, typename InT, int TT = (M == 8) ? 256 : 512>
-__global__ __launch_bounds__(256, 2) void k_front(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
+__global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
                                                float2* __restrict__ tail_out, float2* __restrict__ fm_out_iq,
                                                float* __restrict__ fm_out_plain, float* __restrict__ fo_tail_out, FrontTaps taps,
                                                int deemph_path) {
@@ -123,9 +91,8 @@ __global__ __launch_bounds__(256, 2) void k_front(Dims d, const InT* __restrict_
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float2* ph = reinterpret_cast<float2*>(smem);                 // [M][PS]
     float* theta = smem + G::OFF_THETA;                           // [NW]
-    float* dem = smem + G::OFF_DEM;                               // [2][NH]: dem[j] at [j & 1][j >> 1]
-    float* fo = smem + G::OFF_FO;                                 // [2][FH]: fo[u] at [u & 1][u >> 1]
-    constexpr int NH = G::NH, FH = G::FH;
+    float* dem = smem + G::OFF_DEM;                               // [NW-1]
+    float* fo = smem + G::OFF_FO;                                 // [T+64]
     AtanTable* atab = reinterpret_cast<AtanTable*>(smem + G::OFF_ATAN);
     (void)ph;
     atan_table_fill(atab, threadIdx.x, 256);                      // visible after the first barrier below
@@ -214,47 +181,39 @@ __global__ __launch_bounds__(256, 2) void k_front(Dims d, const InT* __restrict_
             float dlt = theta[j + 1] - theta[j];
             if (dlt >= pi) dlt = dlt - two_pi;
             else if (dlt <= -pi) dlt = dlt + two_pi;
-            dem[(j & 1) * NH + (j >> 1)] = dlt * taps.fm_gain;
+            dem[j] = dlt * taps.fm_gain;
         }
     }
     __syncthreads();
-    // a3: decimate-by-2 FIR, 8 accumulator lanes: even lanes over the even input samples, odd lanes over the odd ones
-    const int lane = tid & 63, wave = tid >> 6;
-    const int l = lane & 3;
-    const int tau0 = 13 * (lane >> 4) + (lane & 15);              // column within a group of 52
-    const bool col_ok = (lane & 15) < 13;
-    {
-        float a_even[8], a_odd[8];
+    // a3: decimate-by-2 FIR, 8 lane accumulators
+    for (int uu = tid; uu < T + 64; uu += 256) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float2* w2 = reinterpret_cast<const float2*>(dem + 2 * uu);
 #pragma unroll
-        for (int jj = 0; jj < 8; jj++) { a_even[jj] = taps.b_fm_out[8 * jj + 2 * l]; a_odd[jj] = taps.b_fm_out[8 * jj + 2 * l + 1]; }
-        for (int g = wave; g < G::G3; g += 4) {
-            const int uu = 52 * g + tau0;
-            const float ev = fir_rows_mfma(a_even, dem + uu);
-            const float od = fir_rows_mfma(a_odd, dem + NH + uu);
-            const float y = ev + od;
-            if (col_ok && uu < T + 64) {
-                fo[(uu & 1) * FH + (uu >> 1)] = y;
-                if (deemph_path && uu >= 64) fm_out_plain[(size_t)c * d.n_fm_out + o0 + (uu - 64)] = y;
-            }
+        for (int n = 0; n < 64; n += 2) {
+            const float2 v = w2[n / 2];
+            acc[n & 7] = fmaf(v.x, taps.b_fm_out[n], acc[n & 7]);
+            acc[(n + 1) & 7] = fmaf(v.y, taps.b_fm_out[n + 1], acc[(n + 1) & 7]);
         }
+        const float a0 = acc[0] + acc[4], a1 = acc[1] + acc[5], a2 = acc[2] + acc[6], a3 = acc[3] + acc[7];
+        const float y = (a0 + a2) + (a1 + a3);
+        fo[uu] = y;
+        if (deemph_path && uu >= 64) fm_out_plain[(size_t)c * d.n_fm_out + o0 + (uu - 64)] = y;
     }
     __syncthreads();
-    // a5: Hilbert FIR; only lanes 1,3,5,7 of the reference's 8-lane accumulator see non-zero taps: lane 2 i + 1 sums
-    // h[8 k + 2 i + 1] fo[oo + 2 i + 1 + 8 k], i.e. for even oo = 2 w the odd samples from w + i on, for odd oo the even samples
-    // from w + 1 + i on.
+    // a5: Hilbert FIR; only lanes 1,3,5,7 of the reference's 8-lane accumulator see non-zero taps
     if (!deemph_path) {
-        float a_h[8];
+        for (int oo = tid; oo < T; oo += 256) {
+            float l1 = 0.f, l3 = 0.f, l5 = 0.f, l7 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; k++) a_h[k] = taps.b_hilbert_odd[4 * k + l];
-        float4* out4 = reinterpret_cast<float4*>(fm_out_iq + (size_t)c * d.n_fm_out + o0);
-        for (int g = wave; g < G::G5; g += 4) {
-            const int w = 52 * g + tau0;
-            const float s_even = fir_rows_mfma(a_h, fo + FH + w);        // oo = 2 w
-            const float s_odd = fir_rows_mfma(a_h, fo + w + 1);          // oo = 2 w + 1
-            if (col_ok && w < T / 2) {
-                const float im0 = (0.0f + s_even) + 0.0f, im1 = (0.0f + s_odd) + 0.0f;
-                out4[w] = make_float4(fo[w + 16], im0, fo[FH + w + 16], im1);   // real part: fo[oo + 32]
+            for (int k = 0; k < 8; k++) {
+                l1 = fmaf(fo[oo + 1 + 8 * k], taps.b_hilbert_odd[4 * k + 0], l1);
+                l3 = fmaf(fo[oo + 3 + 8 * k], taps.b_hilbert_odd[4 * k + 1], l3);
+                l5 = fmaf(fo[oo + 5 + 8 * k], taps.b_hilbert_odd[4 * k + 2], l5);
+                l7 = fmaf(fo[oo + 7 + 8 * k], taps.b_hilbert_odd[4 * k + 3], l7);
             }
+            const float im = (0.0f + ((l1 + l5) + (l3 + l7))) + 0.0f;
+            fm_out_iq[(size_t)c * d.n_fm_out + o0 + oo] = make_float2(fo[oo + 32], im);
         }
     }
     // keep the last TAIL input samples of the stream for the next block (and, when the de-emphasis path is
@@ -262,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void k_front(Dims d, const InT* __restrict_
     if (tile == tiles - 1) {
         float2* tout = tail_out + (size_t)c * G::TAIL;
         for (int idx = tid; idx < G::TAIL; idx += 256) tout[idx] = load_iq(in_c, (size_t)(d.N - G::TAIL + idx));
-        if (!deemph_path && tid < 64) fo_tail_out[(size_t)c * 64 + tid] = fo[((T + tid) & 1) * FH + ((T + tid) >> 1)];
+        if (!deemph_path && tid < 64) fo_tail_out[(size_t)c * 64 + tid] = fo[T + tid];
     }
 }
 
@@ -954,32 +913,17 @@ __global__ __launch_bounds__(2 * kWave) void k_pilot_pll_pairs(Dims d, const flo
 //   PolyphaseDownsampler<cf32> 4x128 (L+R: real rail only; L-R: imaginary rail, plus the real rail of every 10th
 //   output for the phase estimate :496-510) and 8x128 (RDS); stereo mix.
 // One workgroup = one channel x TA audio samples (4 TA fm_out samples, TA/2 RDS samples), TA threads.
-//
-// The three decimating FIRs run on the matrix cores.  On gfx950 v_mfma_f32_4x4x1_16b_f32 is, per output element, exactly
-// D = fmaf(a, b, C) — one product, one rounding, f32 subnormals kept — so a chain of them over k reproduces the reference's
-// fmaf accumulation order bit for bit (tools/mfma_probe.hip checks layout and equality).  The reference accumulates
-// c32_f32_cum_mul_avx style: accumulator lane p sums taps 4jj+p in increasing jj, then (l0+l2)+(l1+l3).  Per lane p that
-// is a 32-tap FIR over the input's decimation phase, which is a banded-Toeplitz product:
-//     acc_p[4 col + r] = sum_k A[r][k] B[k][col],   A[r][k] = b_p[k - r] (0 outside 0..31),   B[k][col] = x_p[4 col + k]
-// One instruction does rows r = 0..3 x columns col = 0..63 for one k (256 multiply-adds, 32 of every 35 on real taps); the
-// four lanes p are four independent accumulators, which also covers the instruction's dependent latency.  The products
-// with the zero taps add (+-0) to an accumulator, which leaves it unchanged (it starts at +0 and is never -0).
-// A comes from a zero-padded copy of the taps in LDS (lane reads b_p[k - (lane & 3)]: four addresses, broadcast).  B is the
-// lane's window x_p[4 col .. 4 col + 34] of the phase array — contiguous and 16-byte aligned, fetched four k at a time with
-// ds_read_b128 (lane stride 16 B: conflict-free).  Neither needs address arithmetic inside the chain.
+// The mixed signals are staged in LDS split into decimation phases; every FIR thread produces FOUR consecutive
+// outputs from one sliding register window (ds_read_b128), so an LDS byte feeds ~4 FMAs instead of 1.
 // =============================================================================================
-
 template <int TA>
 struct ExtractGeom {
     static constexpr int XS = 4 * TA + 124;      // fm_out samples staged
     static constexpr int P4 = TA + 40;           // phase stride (floats) for the decimate-by-4 signals: == 8 (mod 32), multiple of 4
     static constexpr int P8 = TA / 2 + 20;       // phase stride for the decimate-by-8 signal: == 20 (mod 32), multiple of 4
-    static constexpr int NC4 = TA / 4;           // columns (of 4 outputs) of a decimate-by-4 job
-    static constexpr int NC8 = TA / 8;           // columns per rail of the decimate-by-8 job
-    static constexpr int TP4 = 36 + 3, TP8 = 40 + 6;   // padded tap rows: 3 / 6 zeros in front, the chain's overhang behind
-    static constexpr int NW = TA / kWave;        // wavefronts
+    static constexpr int NQ = TA / 4;            // threads per FIR job (each makes 4 outputs)
     static constexpr int NEST = TA / 10 + 2;     // upper bound of phase-estimate outputs per tile
-    static_assert(P4 % 4 == 0 && P8 % 4 == 0 && P4 >= TA + 32 && P8 >= TA / 2 + 20, "phase strides");
+    static_assert(P4 % 4 == 0 && P8 % 4 == 0 && P4 >= TA + 31 && P8 >= TA / 2 + 15, "phase strides");
 };
 
 __device__ __forceinline__ float2 harmonic_mix(float2 x, float dt, float harmonic, float off, float off_cos) {
@@ -991,66 +935,64 @@ __device__ __forceinline__ float2 harmonic_mix(float2 x, float dt, float harmoni
     return make_float2(fmaf(pc, x.x, -(x.y * ps)), fmaf(pc, x.y, x.x * ps));
 }
 
-// One decimate-by-4 job.  ph: 4 phase arrays of stride P (ph[p][u] = x[4 u + p]); tp: padded taps, row p holds b[4 jj + p]
-// at 3 + jj.  Returns the four outputs 4 col + 0..3 of this lane's column; r = lane & 3 is the lane's row of the A operand.
-template <int P, int TP4>
-__device__ __forceinline__ v4f fir4_mfma(const float* __restrict__ ph, const float* __restrict__ tp, int col, int r) {
-    v4f acc[4];
+// Four consecutive outputs of a decimate-by-4, 128-tap FIR on one rail.  ph: 4 phase arrays of stride P, window of
+// output i starts at phase index i.  Accumulation order per output = c32_f32_cum_mul_avx: lane p sums taps 4jj+p in
+// increasing jj, then (l0+l2)+(l1+l3).
+template <typename TapFn>
+__device__ __forceinline__ void fir4_quad(const float* __restrict__ ph, int P, int u, TapFn tap, float out[4]) {
+    float acc[4][4];
 #pragma unroll
-    for (int p = 0; p < 4; p++) acc[p] = (v4f){0.f, 0.f, 0.f, 0.f};
-    const float* a_base = tp + 3 - r;
-    const float4* b_base = reinterpret_cast<const float4*>(ph + 4 * col);
+    for (int v = 0; v < 4; v++) { acc[v][0] = acc[v][1] = acc[v][2] = acc[v][3] = 0.0f; }
 #pragma unroll
-    for (int j = 0; j < 9; j++) {
-        float4 w[4];
+    for (int p = 0; p < 4; p++) {
+        float w[36];
+        const float4* src = reinterpret_cast<const float4*>(ph + p * P + 4 * u);
 #pragma unroll
-        for (int p = 0; p < 4; p++) w[p] = b_base[p * (P / 4) + j];
+        for (int k = 0; k < 9; k++) { const float4 t = src[k]; w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w; }
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const int k = 4 * j + s;
-            if (k >= 35) break;
+        for (int jj = 0; jj < 32; jj++) {
+            const float b = tap(4 * jj + p);
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const float bv = (s == 0) ? w[p].x : (s == 1) ? w[p].y : (s == 2) ? w[p].z : w[p].w;
-                acc[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_base[p * TP4 + k], bv, acc[p], 0, 0, 0);
-            }
+            for (int v = 0; v < 4; v++) acc[v][p] = fmaf(w[v + jj], b, acc[v][p]);
         }
     }
-    return (acc[0] + acc[2]) + (acc[1] + acc[3]);
+#pragma unroll
+    for (int v = 0; v < 4; v++) out[v] = (acc[v][0] + acc[v][2]) + (acc[v][1] + acc[v][3]);
 }
 
-// The decimate-by-8 job (one rail per half-wave): accumulator lane l sums taps 4 i + l over x8[8 t + 4 i + l], a
-// decimate-by-2 32-tap FIR on the 4-phase stream: A[r][k] = b_l[k - 2 r], B[k][col] = x8[32 col + 4 k + l], i.e. element
-// 4 col + k/2 of phase array l (k even) or l + 4 (k odd).  ph: 8 phase arrays of stride P; tp row l holds b[4 i + l] at 6 + i.
-template <int P, int TP8>
-__device__ __forceinline__ v4f fir8_mfma(const float* __restrict__ ph, const float* __restrict__ tp, int col, int r) {
-    v4f acc[4];
+// Four consecutive outputs of a decimate-by-8, 128-tap FIR on one rail: 8 phase arrays; lane (n & 3) sums taps n = 8jj+p
+// in increasing n, so phases p and p+4 feed the same accumulator alternately.
+template <typename TapFn>
+__device__ __forceinline__ void fir8_quad(const float* __restrict__ ph, int P, int u, TapFn tap, float out[4]) {
+    float acc[4][4];
 #pragma unroll
-    for (int l = 0; l < 4; l++) acc[l] = (v4f){0.f, 0.f, 0.f, 0.f};
-    const float* a_base = tp + 6 - 2 * r;
-    const float4* b_base = reinterpret_cast<const float4*>(ph + 4 * col);
+    for (int v = 0; v < 4; v++) { acc[v][0] = acc[v][1] = acc[v][2] = acc[v][3] = 0.0f; }
 #pragma unroll
-    for (int j = 0; j < 5; j++) {
-        float4 wa[4], wb[4];
+    for (int p = 0; p < 4; p++) {
+        float wa[20], wb[20];
+        const float4* sa = reinterpret_cast<const float4*>(ph + p * P + 4 * u);
+        const float4* sb = reinterpret_cast<const float4*>(ph + (p + 4) * P + 4 * u);
 #pragma unroll
-        for (int l = 0; l < 4; l++) { wa[l] = b_base[l * (P / 4) + j]; wb[l] = b_base[(l + 4) * (P / 4) + j]; }
+        for (int k = 0; k < 5; k++) {
+            const float4 t = sa[k]; wa[4 * k] = t.x; wa[4 * k + 1] = t.y; wa[4 * k + 2] = t.z; wa[4 * k + 3] = t.w;
+            const float4 r = sb[k]; wb[4 * k] = r.x; wb[4 * k + 1] = r.y; wb[4 * k + 2] = r.z; wb[4 * k + 3] = r.w;
+        }
 #pragma unroll
-        for (int s = 0; s < 8; s++) {
-            const int k = 8 * j + s;
-            if (k >= 38) break;
+        for (int jj = 0; jj < 16; jj++) {
+            const float ba = tap(8 * jj + p), bb = tap(8 * jj + p + 4);
 #pragma unroll
-            for (int l = 0; l < 4; l++) {
-                const float4 w = (s & 1) ? wb[l] : wa[l];
-                const float bv = (s >> 1 == 0) ? w.x : (s >> 1 == 1) ? w.y : (s >> 1 == 2) ? w.z : w.w;
-                acc[l] = __builtin_amdgcn_mfma_f32_4x4x1f32(a_base[l * TP8 + k], bv, acc[l], 0, 0, 0);
+            for (int v = 0; v < 4; v++) {
+                acc[v][p] = fmaf(wa[v + jj], ba, acc[v][p]);
+                acc[v][p] = fmaf(wb[v + jj], bb, acc[v][p]);
             }
         }
     }
-    return (acc[0] + acc[2]) + (acc[1] + acc[3]);
+#pragma unroll
+    for (int v = 0; v < 4; v++) out[v] = (acc[v][0] + acc[v][2]) + (acc[v][1] + acc[v][3]);
 }
 
 template <int TA>
-__global__ __launch_bounds__(TA, 2) void k_extract(Dims d, const float2* __restrict__ fm_out_iq, const float* __restrict__ pll_dt,
+__global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict__ fm_out_iq, const float* __restrict__ pll_dt,
                                                 const float2* __restrict__ iq_tail_in, const float* __restrict__ dt_tail_in,
                                                 float2* __restrict__ iq_tail_out, float* __restrict__ dt_tail_out,
                                                 const float* __restrict__ b_lpr, const float* __restrict__ b_lmr, RdsTaps rds_taps,
@@ -1058,17 +1000,15 @@ __global__ __launch_bounds__(TA, 2) void k_extract(Dims d, const float2* __restr
                                                 float* __restrict__ audio, float2* __restrict__ rds, float* __restrict__ lmr_est,
                                                 float* __restrict__ lpr_out, float* __restrict__ lmr_out, int keep_taps) {
     using G = ExtractGeom<TA>;
-    constexpr int XS = G::XS, P4 = G::P4, P8 = G::P8, TP4 = G::TP4, TP8 = G::TP8;
+    constexpr int XS = G::XS, P4 = G::P4, P8 = G::P8, NQ = G::NQ;
     __shared__ __attribute__((aligned(16))) float lpr_ph[4 * P4];     // Re fm_out_iq, 4 phases
     __shared__ __attribute__((aligned(16))) float lmr_re_ph[4 * P4];  // x2-mixed signal, real / imaginary rail
     __shared__ __attribute__((aligned(16))) float lmr_im_ph[4 * P4];
-    __shared__ __attribute__((aligned(16))) float rds_ph[2][8 * P8];  // x3-mixed signal, real / imaginary rail, 8 phases
-    __shared__ __attribute__((aligned(16))) float tap_lpr[4 * TP4];
-    __shared__ __attribute__((aligned(16))) float tap_lmr[4 * TP4];
-    __shared__ __attribute__((aligned(16))) float tap_rds[4 * TP8];
+    __shared__ __attribute__((aligned(16))) float rds_re_ph[8 * P8];  // x3-mixed signal
+    __shared__ __attribute__((aligned(16))) float rds_im_ph[8 * P8];
     __shared__ __attribute__((aligned(16))) float res_lpr[TA];
     __shared__ __attribute__((aligned(16))) float res_lmr[TA];
-    __shared__ __attribute__((aligned(16))) float res_rds[TA];            // [TA/2][2]
+    __shared__ __attribute__((aligned(16))) float res_rds[TA];        // [TA/2][2]
     __shared__ float res_est_re[G::NEST];
 
     const int tiles = d.n_audio / TA;
@@ -1080,8 +1020,6 @@ __global__ __launch_bounds__(TA, 2) void k_extract(Dims d, const float2* __restr
     const float2* x_c = fm_out_iq + (size_t)c * n;
     const float* dt_c = pll_dt + (size_t)c * n;
     const float off_cur = st(state, S_LMR_PHASE_CUR, d.C, c), off_prev = st(state, S_LMR_PHASE_PREV, d.C, c);
-    const float* taps_lpr = b_lpr + (size_t)c * 128;
-    const float* taps_lmr = b_lmr + (size_t)c * 128;
 
     // stage + mix: all loads first, then the arithmetic
     {
@@ -1104,17 +1042,6 @@ __global__ __launch_bounds__(TA, 2) void k_extract(Dims d, const float2* __restr
                 }
             }
         }
-        // zero-padded tap rows for the chains' A operands
-        for (int i = tid; i < 4 * TP4; i += TA) {
-            const int p = i / TP4, jj = i % TP4 - 3;
-            const bool in = (jj >= 0) & (jj < 32);
-            tap_lpr[i] = in ? taps_lpr[4 * jj + p] : 0.0f;
-            tap_lmr[i] = in ? taps_lmr[4 * jj + p] : 0.0f;
-        }
-        for (int i = tid; i < 4 * TP8; i += TA) {
-            const int l = i / TP8, ii = i % TP8 - 6;
-            tap_rds[i] = ((ii >= 0) & (ii < 32)) ? rds_taps.b[(4 * ii + l) & 127] : 0.0f;
-        }
 #pragma unroll
         for (int r = 0; r < PER; r++) {
             const int e = tid + TA * r;
@@ -1128,40 +1055,44 @@ __global__ __launch_bounds__(TA, 2) void k_extract(Dims d, const float2* __restr
                 if (e >= 4) {
                     const float2 m3 = harmonic_mix(xv[r], dv[r], 3.0f, 0.0f, 0.25f);
                     const int e8 = e - 4, a8 = (e8 & 7) * P8 + (e8 >> 3);
-                    rds_ph[0][a8] = m3.x;
-                    rds_ph[1][a8] = m3.y;
+                    rds_re_ph[a8] = m3.x;
+                    rds_im_ph[a8] = m3.y;
                 }
             }
         }
     }
     __syncthreads();
 
-    const int wave = tid / kWave, lane = tid % kWave;
+    const int job = tid / NQ, u = tid % NQ;
+    const float* taps_lpr = b_lpr + (size_t)c * 128;
+    const float* taps_lmr = b_lmr + (size_t)c * 128;
     const int est_first = (10 - (i0 % 10)) % 10;   // first output of this tile whose block index is a multiple of 10
-    for (int job = wave; job < 4; job += G::NW) {   // wave-uniform
-        if (job < 2) {
-            const int col = (lane < G::NC4) ? lane : G::NC4 - 1;     // (TA = 128: the upper half-wave repeats a column)
-            const v4f o = fir4_mfma<P4, TP4>(job ? lmr_im_ph : lpr_ph, job ? tap_lmr : tap_lpr, col, lane & 3);
-            if (lane < G::NC4) *reinterpret_cast<float4*>((job ? res_lmr : res_lpr) + 4 * lane) = make_float4(o[0], o[1], o[2], o[3]);
-        } else if (job == 2) {
-            const int rail = (lane / G::NC8) & 1, col = lane % G::NC8;
-            const v4f o = fir8_mfma<P8, TP8>(rds_ph[rail], tap_rds, col, lane & 3);
-            if (lane < 2 * G::NC8) {
+    if (job == 0) {
+        float o[4];
+        fir4_quad(lpr_ph, P4, u, [&](int k) { return taps_lpr[k]; }, o);
+        *reinterpret_cast<float4*>(res_lpr + 4 * u) = make_float4(o[0], o[1], o[2], o[3]);
+    } else if (job == 1) {
+        float o[4];
+        fir4_quad(lmr_im_ph, P4, u, [&](int k) { return taps_lmr[k]; }, o);
+        *reinterpret_cast<float4*>(res_lmr + 4 * u) = make_float4(o[0], o[1], o[2], o[3]);
+    } else if (job == 2) {
+        // RDS: first half of the job's threads take the real rail, second half the imaginary rail
+        const int rail = u / (NQ / 2), uu = u % (NQ / 2);
+        float o[4];
+        fir8_quad(rail ? rds_im_ph : rds_re_ph, P8, uu, [&](int k) { return rds_taps.b[k]; }, o);
 #pragma unroll
-                for (int v = 0; v < 4; v++) res_rds[2 * (4 * col + v) + rail] = o[v];
-            }
-        } else {
-            // real rail of the L-R outputs that feed the phase estimate (one output per lane)
-            const int ii = est_first + 10 * lane;
-            if (ii < TA) {
-                float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int v = 0; v < 4; v++) res_rds[2 * (4 * uu + v) + rail] = o[v];
+    } else {
+        // real rail of the L-R outputs that feed the phase estimate (one output per thread)
+        const int ii = est_first + 10 * u;
+        if (ii < TA) {
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-                for (int jj = 0; jj < 32; jj++) {
+            for (int jj = 0; jj < 32; jj++) {
 #pragma unroll
-                    for (int p = 0; p < 4; p++) a[p] = fmaf(lmr_re_ph[p * P4 + ii + jj], taps_lmr[4 * jj + p], a[p]);
-                }
-                res_est_re[lane] = (a[0] + a[2]) + (a[1] + a[3]);
+                for (int p = 0; p < 4; p++) a[p] = fmaf(lmr_re_ph[p * P4 + ii + jj], taps_lmr[4 * jj + p], a[p]);
             }
+            res_est_re[u] = (a[0] + a[2]) + (a[1] + a[3]);
         }
     }
     __syncthreads();
