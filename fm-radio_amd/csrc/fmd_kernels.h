@@ -63,7 +63,9 @@ static constexpr int kSlots = 4;
 static_assert(kSlots <= 4, "one S_PILOT_POWER state field per slot");
 // buf = block % kSlots (stream buffers), par = block & 1 (history tails); t0/t1: optional events that receive the stage's
 // first kernel's start and last kernel's end timestamps (attached to the dispatch packets themselves: no extra queue packets)
-struct SlotRef { int buf; int par; hipEvent_t t0 = nullptr; hipEvent_t t1 = nullptr; };
+// done: optional event that is to fire when the stage's last kernel has completed, carried by that kernel's own dispatch
+// packet (a separate hipEventRecord is one more queue packet between two dependent kernels, ~25 us on the PLL stream)
+struct SlotRef { int buf; int par; hipEvent_t t0 = nullptr; hipEvent_t t1 = nullptr; hipEvent_t done = nullptr; };
 struct Buffers {
     // history tails: stage of block b reads [par], writes [par^1] (producer and consumer are the same stage, same stream)
     float2* base_tail[2];   // [C][tail_base]

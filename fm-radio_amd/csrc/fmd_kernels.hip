@@ -24,7 +24,7 @@
 // launch with the stage's timing events attached to the dispatch packet when the caller asked for them
 #define FMD_LAUNCH(r, first, last, kern, grid, block, lds, s, ...)                                                   \
     do {                                                                                                             \
-        hipEvent_t e0_ = (first) ? (r).t0 : nullptr, e1_ = (last) ? (r).t1 : nullptr;                                \
+        hipEvent_t e0_ = (first) ? (r).t0 : nullptr, e1_ = (last) ? ((r).t1 ? (r).t1 : (r).done) : nullptr;         \
         if (e0_ || e1_) hipExtLaunchKernelGGL(kern, grid, block, lds, s, e0_, e1_, 0, __VA_ARGS__);                  \
         else hipLaunchKernelGGL(kern, grid, block, lds, s, __VA_ARGS__);                                             \
     } while (0)
