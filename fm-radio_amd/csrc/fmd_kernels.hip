@@ -138,22 +138,47 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
             }
         }
         __syncthreads();
-        // a1 + a2: fm_in[w] then theta[w] = atan2(Q, I)
-        for (int i = tid; i < NW; i += 256) {
-            float ar[4] = {0.f, 0.f, 0.f, 0.f}, ai[4] = {0.f, 0.f, 0.f, 0.f};
+        // a1 + a2: fm_in[w] then theta[w] = atan2(Q, I).  Every thread makes TWO consecutive outputs from one sliding
+        // window per phase (ds_read_b128 = two samples, lane stride 16 B: conflict-free): an LDS byte feeds two FMAs and
+        // the loop is bound by the VALU, not by one ds_read_b64 per complex tap.  Accumulation order per output as in
+        // c32_f32_cum_mul_avx: lane (n & 3) sums taps n in increasing n, then (l0+l2)+(l1+l3).
+        constexpr int NJ = 64 / M;                 // taps per phase
+        constexpr int NV = (NJ + 2) / 2;           // float4 loads covering the NJ + 1 samples of a two-output window
+        for (int i = 2 * tid; i < NW; i += 512) {
+            float ar[2][4], ai[2][4];
 #pragma unroll
-            for (int jj = 0; jj < 64 / M; jj++) {
+            for (int v = 0; v < 2; v++)
 #pragma unroll
-                for (int p = 0; p < M; p++) {
-                    const float2 x = ph[p * PS + i + jj];
-                    const float b = taps.b_fm_in[M * jj + p];
-                    ar[p & 3] = fmaf(x.x, b, ar[p & 3]);
-                    ai[p & 3] = fmaf(x.y, b, ai[p & 3]);
+                for (int q = 0; q < 4; q++) { ar[v][q] = 0.f; ai[v][q] = 0.f; }
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                // phases p (and p + 4 at M = 8) feed accumulator lane p, alternating in tap order
+                float2 w[M / 4][2 * NV];
+#pragma unroll
+                for (int h = 0; h < M / 4; h++) {
+                    const float4* src = reinterpret_cast<const float4*>(ph + (p + 4 * h) * PS + i);
+#pragma unroll
+                    for (int k = 0; k < NV; k++) { const float4 t = src[k]; w[h][2 * k] = make_float2(t.x, t.y); w[h][2 * k + 1] = make_float2(t.z, t.w); }
+                }
+#pragma unroll
+                for (int jj = 0; jj < NJ; jj++) {
+#pragma unroll
+                    for (int h = 0; h < M / 4; h++) {
+                        const float b = taps.b_fm_in[M * jj + p + 4 * h];
+#pragma unroll
+                        for (int v = 0; v < 2; v++) {
+                            ar[v][p] = fmaf(w[h][jj + v].x, b, ar[v][p]);
+                            ai[v][p] = fmaf(w[h][jj + v].y, b, ai[v][p]);
+                        }
+                    }
                 }
             }
-            const float re = (ar[0] + ar[2]) + (ar[1] + ar[3]);
-            const float im = (ai[0] + ai[2]) + (ai[1] + ai[3]);
-            theta[i] = fmd_atan2f_table(im, re, atab);
+#pragma unroll
+            for (int v = 0; v < 2; v++) {
+                const float re = (ar[v][0] + ar[v][2]) + (ar[v][1] + ar[v][3]);
+                const float im = (ai[v][0] + ai[v][2]) + (ai[v][1] + ai[v][3]);
+                if (i + v < NW) theta[i + v] = fmd_atan2f_table(im, re, atab);
+            }
         }
     } else {
         constexpr int PER = (NW + 255) / 256;

@@ -9,7 +9,7 @@ cd $R
 i=0
 for grp in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_F32"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $O/g$i -- ./tools/stage_probe ${1:-4096} 1 3 > /dev/null 2> $O/g$i.err
+  rocprofv3 --pmc $grp --output-format csv -d $O/g$i -- ./tools/stage_probe ${1:-4096} ${2:-1} 3 > /dev/null 2> $O/g$i.err
 done
 python3 - <<PY
 import csv, glob, collections
