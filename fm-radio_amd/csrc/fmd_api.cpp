@@ -212,18 +212,16 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     // event bracketing perturbs the pipeline it measures (extra queue packets between dependent kernels): mode 2 keeps it
     // on the dominant kernel and samples the others
     auto prof_stage = [&](int st) { return h->profiling == 1 || st == ST_PLL || (h->n_blocks & 3) == 0; };
-    // The event that orders the next stage behind this one rides on the stage's last dispatch packet, unless that packet
-    // already carries a timing event: then it is recorded separately (recorded = false).
-    bool recorded = false;
+    // The event that orders the next stage behind this one rides on the stage's last dispatch packet (SlotRef::done).  A
+    // stage that is being timed already carries its stop event there: the next stage then waits on that one (dep).
+    hipEvent_t dep = nullptr;
     auto run = [&](Stage st, hipStream_t on, hipError_t (*fn)(const LaunchCtx&, SlotRef, hipStream_t), hipEvent_t done) -> hipError_t {
         SlotRef r = ref;
         if (pm && prof_stage(st)) { r.t0 = pm->t0[st]; r.t1 = pm->t1[st]; pm->used[st] = true; }
-        recorded = pipe && done && !r.t1;
-        if (recorded) r.done = done;
-        hipError_t e = fn(h->ctx, r, on);
-        return e;
+        if (pipe && !r.t1) r.done = done;
+        dep = r.t1 ? r.t1 : done;
+        return fn(h->ctx, r, on);
     };
-    auto record = [&](hipEvent_t ev, hipStream_t on) -> hipError_t { return recorded ? hipSuccess : hipEventRecord(ev, on); };
     hipError_t e = hipSuccess;
     if (pipe) {
         // input is ready once everything queued so far on the caller's stream has run
@@ -235,36 +233,27 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     {
         SlotRef r = ref;
         if (pm && prof_stage(ST_FRONT)) { r.t0 = pm->t0[ST_FRONT]; r.t1 = pm->t1[ST_FRONT]; pm->used[ST_FRONT] = true; }
-        recorded = pipe && !r.t1 && !h->ctx.any_deemph;
-        if (recorded) r.done = h->ev_F[slot];
+        if (pipe && !r.t1 && !h->ctx.any_deemph) r.done = h->ev_F[slot];
+        dep = r.t1 ? r.t1 : h->ev_F[slot];
         e = launch_stage_front(h->ctx, r, d_iq, u8, sF);
     }
     if (e != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_front launch: %s", hipGetErrorString(e));
     if (h->ctx.any_deemph && (e = run(ST_DEEMPH, sF, launch_stage_deemph, h->ev_F[slot])) != hipSuccess)
         return fail(h, FMD_ERR_DEVICE, "de-emphasis launch: %s", hipGetErrorString(e));
     if (pipe) {
-        HIP_TRY(h, record(h->ev_F[slot], sF));
-        HIP_TRY(h, hipStreamWaitEvent(s, h->ev_F[slot], 0));    // the caller may reuse `iq` in stream order after this call
-        HIP_TRY(h, hipStreamWaitEvent(sA, h->ev_F[slot], 0));
+        HIP_TRY(h, hipStreamWaitEvent(s, dep, 0));     // the caller may reuse `iq` in stream order after this call
+        HIP_TRY(h, hipStreamWaitEvent(sA, dep, 0));
     }
     if ((e = run(ST_POWER, sA, launch_stage_power, h->ev_A[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_pilot_power launch: %s", hipGetErrorString(e));
-    if (pipe) {
-        HIP_TRY(h, record(h->ev_A[slot], sA));
-        HIP_TRY(h, hipStreamWaitEvent(sB, h->ev_A[slot], 0));
-    }
+    if (pipe) HIP_TRY(h, hipStreamWaitEvent(sB, dep, 0));
     if ((e = run(ST_PLL, sB, launch_stage_pll, h->ev_B[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_pilot_pll launch: %s", hipGetErrorString(e));
-    if (pipe) {
-        HIP_TRY(h, record(h->ev_B[slot], sB));
-        HIP_TRY(h, hipStreamWaitEvent(sX, h->ev_B[slot], 0));
-    }
-    // ev_E fires behind k_extract itself: k_rds_sync does not need k_lmr_phase (same stream, behind it)
+    if (pipe) HIP_TRY(h, hipStreamWaitEvent(sX, dep, 0));
+    // the extract stage's event fires behind k_extract itself: k_rds_sync does not need k_lmr_phase (same stream, behind it)
     if ((e = run(ST_EXTRACT, sX, launch_stage_extract, h->ev_E[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_extract launch: %s", hipGetErrorString(e));
-    if (pipe) {
-        HIP_TRY(h, record(h->ev_E[slot], sX));
-        HIP_TRY(h, hipStreamWaitEvent(sR, h->ev_E[slot], 0));
-    }
+    if (pipe) HIP_TRY(h, hipStreamWaitEvent(sR, dep, 0));
     if ((e = run(ST_RDS, sR, launch_stage_rds, h->ev_X[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_rds_sync launch: %s", hipGetErrorString(e));
-    if (pipe) HIP_TRY(h, record(h->ev_X[slot], sR));   // the last consumer of this slot's buffers
+    // ev_X outlives this call (slot reuse, fmd_wait_outputs): when the dispatch carried a timing event instead, record it
+    if (pipe && dep != h->ev_X[slot]) HIP_TRY(h, hipEventRecord(h->ev_X[slot], sR));
     h->slot_used[slot] = true;
     h->out_slot = slot;
     h->n_blocks++;

@@ -25,6 +25,7 @@ with open(dst / "bench_default_kernel_stats.csv", "w") as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
     w.writeheader()
     for r in rows:
+        if len(r["Name"]) > 160: r["Name"] = r["Name"][:157] + "..."   # torch's synthetic-data kernels carry kilobyte-long names
         w.writerow(r)
     # the --stats averages include the pre-roll and warmup launches (loop acquisition); the timed region is the last `steps` launches
     trace = newest(str(src / "stats" / "*" / "*kernel_trace.csv"))
