@@ -512,7 +512,8 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
 
     int pos = 0;                 // next sample of this channel (absolute within the block); identical in its 16 lanes
     int seq_left = 0, hold = 0;  // wave-uniform: serial chunks still to run / back-off
-    unsigned long long n_spans = 0, n_committed = 0, n_exact = 0, n_seq = 0;
+    unsigned long long n_exact = 0, n_seq = 0;   // wave-uniform counters (scalar registers)
+    int n_spans = 0;
     for (int q = 0; q < chunks; q++) {
         const int cend = (q + 1) * CH;
         int spans = 0;
@@ -621,7 +622,6 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
                 }
                 if (active) {
                     lx1 = nx; ly1 = ny; integ = ni; err_prev = ne; tph_prev = nt; pos += m;
-                    if (j == 0) { n_spans++; n_committed += (unsigned long long)m; }
                 }
                 ex[g][0] = err_prev;
             }
@@ -637,6 +637,7 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
         FMD_PLL_STASH(q + 2)
         FMD_PLL_FETCH(q + 3)
         if (speculative) {   // a speculative chunk that went badly sends the wavefront serial for a while, doubling each time in a row
+            n_spans += spans;
             if (spans > kPllSlowSpans) { seq_left = hold ? hold : 1; hold = hold ? (2 * hold < kSlowHoldMax ? 2 * hold : kSlowHoldMax) : 1; }
             else hold = 0;
         }
@@ -649,7 +650,8 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
     if (spec_stats) {
         // per wavefront: chunks / chunks run serially / spans redone with the reference forms; per channel: spans, samples
         if (lane == 0) { atomicAdd(&spec_stats[0], (unsigned long long)chunks); atomicAdd(&spec_stats[1], n_seq); atomicAdd(&spec_stats[2], n_exact); }
-        if (live && j == 0) { atomicAdd(&spec_stats[3], n_spans); atomicAdd(&spec_stats[4], n_committed); }
+        // per channel: the spans its wavefront ran, and the samples they covered (every sample of a speculative chunk)
+        if (live && j == 0) { atomicAdd(&spec_stats[3], (unsigned long long)n_spans); atomicAdd(&spec_stats[4], ((unsigned long long)chunks - n_seq) * CH); }
         // shader-clock cycles and 100 MHz real-time ticks this wavefront ran: their ratio is the core clock the power
         // management granted while the other stages' kernels ran beside it (DESIGN.md "Clocks")
         if (lane == 0 && blockIdx.x == 0) { atomicAdd(&spec_stats[6], __builtin_readcyclecounter() - clk0); atomicAdd(&spec_stats[7], __builtin_amdgcn_s_memrealtime() - rt0); }
