@@ -7,7 +7,7 @@ One "step" = one `fmd_process_cf32_dev` call = one block of every channel throug
 (decimating FIRs -> discriminator -> Hilbert -> pilot PLL -> x2/x3 mixers -> audio/RDS decimators -> stereo mix,
 RDS AGC + BPSK symbol sync + Manchester).  Workload at N=1: BASELINE.json configs[2] — 4096 synthetic FM channels
 @ 256 kSa/s batched on one MI355X, 16384-sample blocks (64 ms), inputs resident in HBM before the timed region.
-Channels shard across ranks (weak scaling: 4096 per GPU); the only collective is the per-step audio all-gather
+Channels shard across ranks (weak scaling: 4096 per GPU); the only collective is the per-step audio gather
 (RCCL), overlapped with the next step's compute.
 
 The JSON line carries `roofline` (dominant kernel, HIP-event timed inside the library on the processing stream)
@@ -219,7 +219,12 @@ def main() -> None:
     ap.add_argument("--block", type=int, default=0, help="baseband samples per channel per step (default: 64 ms)")
     ap.add_argument("--u8", action="store_true", help="u8 IQ ingest (2 B/sample) instead of cf32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="skip the per-step audio all-gather at N>1")
+    ap.add_argument("--gather", default="root", choices=["root", "all", "none"],
+                    help="N>1: per-step audio collective — 'root': every rank sends its block to rank 0 (point-to-point over the "
+                         "direct xGMI links; default), 'all': all-gather to every rank, 'none': no collective")
+    ap.add_argument("--gather-format", default="pcm16", choices=["pcm16", "f32"],
+                    help="payload of the audio collective: the 16-bit PCM frames the reference's scraper writes (default) or raw f32")
+    ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--no-kernel-times", action="store_true", help="do not attach HIP timing events to the kernels of the timed region (no roofline object; ~2 %% faster)")
     ap.add_argument("--pll-kernel", default="auto", choices=["auto", "time_parallel", "time_parallel8", "low_work"],
                     help="force one of the pilot-PLL kernels (default: chosen by batch size; same results either way)")
@@ -269,17 +274,24 @@ def main() -> None:
     x = x.view(C, n_blocks_resident, block, 2).permute(1, 0, 2, 3).contiguous()  # [blocks][C][N][2]
     dm = pkg.BatchDemod(C, block, fs, device=local_rank, pipelined=not args.no_pipeline, pll_kernel=args.pll_kernel)
 
-    do_gather = world > 1 and not args.no_gather
+    do_gather = world > 1 and not args.no_gather and args.gather != "none"
+    pcm16 = args.gather_format == "pcm16"
     if do_gather:
-        gather = pkg.AudioGather(dist, torch, C, dm.rates.n_audio, world, device)
+        gather = pkg.AudioGather(dist, torch, C, dm.rates.n_audio, world, device, mode=args.gather,
+                                 dtype=torch.int16 if pcm16 else torch.float32)
         gstream = torch.cuda.Stream(device)   # consumes outputs; the submitting stream never waits on them
 
     def step(k: int):
         dm.process(x[k % n_blocks_resident])
         if do_gather:
             with torch.cuda.stream(gstream):
-                dm.wait_outputs(gstream)
-                gather.issue(k, dm.audio_tensor())
+                s = gather.slot(k)
+                if pcm16:
+                    dm.audio_pcm16_into(gather.stage[s], gstream)       # waits for the block's outputs on gstream, then converts
+                else:
+                    dm.wait_outputs(gstream)
+                    gather.stage[s].copy_(dm.audio_tensor(), non_blocking=True)
+                gather.launch(s)
 
     def drain():
         if do_gather:
@@ -314,6 +326,8 @@ def main() -> None:
     ktimes = dm.profile_read()
     spec = dm.spec_stats()
 
+    gather_note = "" if not do_gather else (f", per-step audio gather to rank 0 ({args.gather_format}, RCCL)" if args.gather == "root"
+                                            else f", per-step audio all-gather ({args.gather_format}, RCCL)")
     samples_per_step = C * block * world
     value = samples_per_step * K / el / 1e6
     bps = algorithmic_bytes_per_sample(fs, args.u8)
@@ -370,7 +384,7 @@ def main() -> None:
                                f"{'u8' if args.u8 else 'cf32'} IQ resident in HBM, full stereo + pilot PLL + RDS",
                    "channels_per_gpu": C, "fs_baseband": fs, "block_size": block, "ingest": "u8" if args.u8 else "cf32",
                    "preroll_blocks": P,
-                   "parallelism": f"channel-sharded x{world}" + (", per-step audio all-gather (RCCL)" if do_gather else "")},
+                   "parallelism": f"channel-sharded x{world}" + gather_note},
         "channels_at_realtime": value * 1e6 / fs,
         "msa_per_gpu": value / world,
         "roofline": roofline,

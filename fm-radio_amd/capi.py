@@ -126,6 +126,7 @@ def load_library():
     L.fmd_synchronize.argtypes = [H]
     L.fmd_wait_outputs.argtypes = [H, C.c_void_p]
     L.fmd_audio_dev.argtypes = [H, C.POINTER(C.c_void_p)]
+    L.fmd_audio_pcm16_dev.argtypes = [H, C.c_void_p, C.c_void_p]
     L.fmd_rds_dev.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.fmd_get_audio.argtypes = [H, C.c_void_p]
     L.fmd_get_rds_symbols.argtypes = [H, C.c_void_p, C.c_void_p]
@@ -313,6 +314,18 @@ class BatchDemod:
         n = C.c_int(0)
         self._check(self.L.fmd_profile_read(self.h, arr, 16, C.byref(n)))
         return {arr[i].name.decode(): (arr[i].total_ms, arr[i].launches) for i in range(n.value)}
+
+    def audio_pcm16_into(self, out, stream=None):
+        """Convert the newest block's audio to the reference scraper's 16-bit PCM frames into `out` (torch int16 CUDA tensor
+        [C, n_audio, 2]) on `stream` (default: torch current stream), ordered behind the block's outputs."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        elif hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+        assert out.dtype == torch.int16 and out.is_contiguous() and out.numel() == self.n_channels * self.rates.n_audio * 2
+        self._check(self.L.fmd_audio_pcm16_dev(self.h, C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+        return out
 
     def audio_tensor(self):
         """Zero-copy torch view of the newest block's device audio buffer [C, n_audio, 2] (the library alternates

@@ -529,6 +529,17 @@ int fmd_audio_dev(fmd_handle h, const float** d_audio) {
     return FMD_OK;
 }
 
+int fmd_audio_pcm16_dev(fmd_handle h, int16_t* d_pcm, void* stream) {
+    if (!h || !d_pcm) return FMD_ERR_ARG;
+    if (h->n_blocks == 0) return fail(h, FMD_ERR_ARG, "no block has been processed");
+    int rc = fmd_wait_outputs(h, stream);
+    if (rc) return rc;
+    const Dims& d = h->ctx.d;
+    hipError_t e = launch_audio_pcm16(h->ctx.b.audio[h->out_slot], d_pcm, (size_t)d.C * d.n_audio * 2, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_audio_pcm16 launch: %s", hipGetErrorString(e));
+    return FMD_OK;
+}
+
 int fmd_rds_dev(fmd_handle h, const float** d_syms, const int** d_counts) {
     if (!h || !d_syms || !d_counts) return FMD_ERR_ARG;
     *d_syms = h->ctx.b.rds_sym[h->out_slot];

@@ -120,6 +120,7 @@ hipError_t launch_stage_extract(const LaunchCtx& ctx, SlotRef r, hipStream_t s);
 hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                               // k_rds_sync
 hipError_t launch_reset_state(const LaunchCtx& ctx, hipStream_t stream);
 hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, unsigned char* d_ok, size_t n, int table_form, hipStream_t s);
+hipError_t launch_audio_pcm16(const float* d_audio, int16_t* d_pcm, size_t n_values, hipStream_t s);   // k_audio_pcm16
 hipError_t prepare_kernels();          // one-time function attributes (dynamic LDS sizes)
 int front_tail_len(int m);             // input-history samples k_front needs per channel
 

@@ -1421,6 +1421,24 @@ hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, unsi
     return hipGetLastError();
 }
 
+// The audio block as the 16-bit PCM frames the reference's scraper writes (fm_scraper.cpp:79-82 through Frame<float> ->
+// Frame<int16_t>): sample * (32767 * 0.95f), truncated toward zero.  Half the bytes of the f32 block: what the multi-GPU
+// audio gather moves.
+__global__ __launch_bounds__(256) void k_audio_pcm16(const float4* __restrict__ in, short4* __restrict__ out, size_t n4) {
+    const float scale = 32767.0f * 0.95f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = in[i];
+        out[i] = make_short4((short)(int)(v.x * scale), (short)(int)(v.y * scale), (short)(int)(v.z * scale), (short)(int)(v.w * scale));
+    }
+}
+
+hipError_t launch_audio_pcm16(const float* d_audio, int16_t* d_pcm, size_t n_values, hipStream_t s) {
+    const size_t n4 = n_values / 4;
+    const unsigned blocks = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_audio_pcm16, dim3(blocks ? blocks : 1), dim3(256), 0, s, reinterpret_cast<const float4*>(d_audio), reinterpret_cast<short4*>(d_pcm), n4);
+    return hipGetLastError();
+}
+
 // fresh-construction state (reference constructors: AGC gain 0.1 agc.h:10, everything else zero)
 __global__ void k_reset(Dims d, float* __restrict__ state) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -126,6 +126,11 @@ int fmd_wait_outputs(fmd_handle h, void* stream);
 
 /* OnAudioOut() / GetAudioOut() (broadcast_fm_demod.h:256,297): device views of the current block */
 int fmd_audio_dev(fmd_handle h, const float** d_audio /* [C][n_audio][2] */);
+/* The newest block's audio as the 16-bit PCM frames the reference's headless scraper writes to its WAV files
+ * (fm_scraper.cpp:79-82: sample * (32767 * 0.95f), truncated toward zero): d_pcm [C][n_audio][2] int16 on the device,
+ * converted on `stream` once the block's outputs are complete.  Half the bytes of the f32 block: the payload of the
+ * multi-GPU audio gather. */
+int fmd_audio_pcm16_dev(fmd_handle h, int16_t* d_pcm /* [C][n_audio][2] */, void* stream);
 /* OnRDSOut() / GetRDSPredSymbols() (broadcast_fm_demod.h:253,298) */
 int fmd_rds_dev(fmd_handle h, const float** d_syms /* [C][n_rds] */, const int** d_counts /* [C] */);
 /* host copies (synchronise first) */

@@ -283,6 +283,24 @@ def test_pll_speculation_commits_long_spans_in_lock_and_short_ones_before(pkg):
     assert sum(p["serial_chunks"] for p in locked) == 0
 
 
+def test_pcm16_audio_frames_match_the_scraper_conversion(pkg):
+    """fmd_audio_pcm16_dev (the multi-GPU gather's payload): the reference scraper's float -> int16 conversion of the audio
+    block (fm_scraper.cpp:79-82: sample * (32767 * 0.95f), truncated toward zero), on the device, behind the block's outputs."""
+    import torch
+    caps = _caps(3, 4 * 16384, fs=256_000.0, seed=77)
+    dm = pkg.BatchDemod(3, 16384, 256_000)
+    out = torch.empty((3, dm.rates.n_audio, 2), dtype=torch.int16, device="cuda")
+    side = torch.cuda.Stream()
+    for b in range(4):
+        dm.process(caps[:, b * 16384:(b + 1) * 16384])
+        dm.audio_pcm16_into(out, side)
+        side.synchronize()
+        want = (dm.audio() * (np.float32(32767.0) * np.float32(0.95))).astype(np.int32).astype(np.int16)
+        assert np.array_equal(out.cpu().numpy(), want), b
+        assert np.abs(want).max() > 1000      # a real signal, not silence
+    dm.close()
+
+
 def test_gpu_runs_are_deterministic(pkg):
     caps = _caps(3, 6 * 65536, seed=17, u8=True)
     a = run_gpu(pkg, caps, 65536, 1_024_000)
