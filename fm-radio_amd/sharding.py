@@ -63,11 +63,18 @@ class AudioGather:
         """Start the gather of staging slot s (already filled on the current stream)."""
         # the collectives move bytes: neither RCCL nor gloo has a 16-bit integer type
         as_bytes = (lambda t: t.view(self.torch.uint8)) if self.dtype == self.torch.int16 else (lambda t: t)
-        if self.mode == "all":
-            self.handles[s] = self.dist.all_gather_into_tensor(as_bytes(self.out[s]), as_bytes(self.stage[s]), async_op=True)
-        else:
+        if self.mode == "root":
             parts = [as_bytes(t) for t in self.out[s].chunk(self.world, dim=0)] if self.rank == self.dst else None
-            self.handles[s] = self.dist.gather(as_bytes(self.stage[s]), parts, dst=self.dst, async_op=True)
+            try:
+                self.handles[s] = self.dist.gather(as_bytes(self.stage[s]), parts, dst=self.dst, async_op=True)
+                return s
+            except (RuntimeError, NotImplementedError) as e:   # a backend without gather: raised before anything is sent, on every rank alike
+                import sys
+                print(f"AudioGather: dist.gather unavailable ({e}); falling back to all_gather", file=sys.stderr)
+                self.mode = "all"
+                self.out = [o if o is not None else self.torch.empty((self.world * self.stage[0].shape[0],) + tuple(self.stage[0].shape[1:]),
+                                                                       dtype=self.dtype, device=self.stage[0].device) for o in self.out]
+        self.handles[s] = self.dist.all_gather_into_tensor(as_bytes(self.out[s]), as_bytes(self.stage[s]), async_op=True)
         return s
 
     def issue(self, k: int, audio_local):
