@@ -377,9 +377,9 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     // VALU throughput bounds the step the low-work kernel is faster (measured cross-over: between 6144 and 8192 channels at
     // 256 kSa/s, about 8192 at 1.024 MSa/s).
     h->ctx.pll_time_parallel_max_channels = (cfg->flags & FMD_FLAG_PLL_LOW_WORK) ? 0 : ((cfg->flags & FMD_FLAG_PLL_TIME_PARALLEL) ? 0x7fffffff : 6144);
-    // within the time-parallel kernel: 16 lanes per channel while a lone wavefront's latency is all that matters (measured:
-    // 10 % faster at 1024 channels), 8 lanes per channel (30 % fewer VALU instructions) beyond (2-3 % faster at 4096 and 8192)
-    h->ctx.pll_k16_max_channels = (cfg->flags & FMD_FLAG_PLL_K8) ? 0 : 2048;
+    // within the time-parallel kernel: 16 lanes per channel while a lone wavefront's latency is what matters (same-box A/B:
+    // 8 % faster at 2560 channels, 6 % at 3072), 8 lanes per channel (30 % fewer VALU instructions) beyond (2 % faster at 4096)
+    h->ctx.pll_k16_max_channels = (cfg->flags & FMD_FLAG_PLL_K8) ? 0 : 3584;
     d.n_fm_in = d.N / m; d.n_fm_out = d.n_fm_in / 2; d.n_rds = d.n_fm_out / 8; d.n_audio = d.n_fm_out / 4;
     d.n_est = (d.n_audio + 9) / 10;
     d.tail_base = front_tail_len(m);
