@@ -129,7 +129,7 @@ def bench_wideband(args, torch, pkg, device) -> dict:
     dm.synchronize(); torch.cuda.synchronize(device)
     el = time.perf_counter() - t0
     dm.profile(0)
-    ktimes = dm.profile_read() if not args.no_kernel_times else {}
+    ktimes = {k: v for k, v in (dm.profile_read() if not args.no_kernel_times else {}).items() if not k.startswith("gap:")}
     value = C * block * K / el / 1e6
     return {
         "metric": "IQ MSamples/sec demodulated to stereo+RDS per GPU; channels @ real-time",
@@ -324,6 +324,8 @@ def main() -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         el = float(tmax.item())
     ktimes = dm.profile_read()
+    gaps = {k[4:]: v[0] / max(v[1], 1) for k, v in ktimes.items() if k.startswith("gap:")}   # stream hand-over between launches
+    ktimes = {k: v for k, v in ktimes.items() if not k.startswith("gap:")}
     spec = dm.spec_stats()
 
     gather_note = "" if not do_gather else (f", per-step audio gather to rank 0 ({args.gather_format}, RCCL)" if args.gather == "root"
@@ -365,6 +367,7 @@ def main() -> None:
                     "algorithmic_bytes_per_launch": algo_bytes,
                     "whole_step_frac": (bps * C * block * K / el / 1e9) / HBM_PEAK_GBS if world == 1 else None,
                     "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in ktimes.items()},
+                    "handover_ms": gaps,
                     "valu": valu}
 
     out = {

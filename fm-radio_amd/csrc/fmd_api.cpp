@@ -682,6 +682,22 @@ int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out) {
             out[slot].launches += 1;
         }
     }
+    // hand-over on the PLL stream: end of one block's k_pilot_pll to the start of the next block's (the chain that bounds
+    // the pipelined step at moderate batch sizes)
+    if (n < cap) {
+        double gap = 0.0; int cnt = 0;
+        for (size_t b = 1; b < h->marks.size(); b++) {
+            if (!h->marks[b - 1]->used[ST_PLL] || !h->marks[b]->used[ST_PLL]) continue;
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, h->marks[b - 1]->t1[ST_PLL], h->marks[b]->t0[ST_PLL]) == hipSuccess) { gap += ms; cnt++; }
+        }
+        if (cnt) {
+            std::memset(&out[n], 0, sizeof(out[n]));
+            std::strncpy(out[n].name, "gap:k_pilot_pll", sizeof(out[n].name) - 1);
+            out[n].total_ms = gap; out[n].launches = cnt;
+            n++;
+        }
+    }
     free_marks(h);
     *n_out = n;
     return FMD_OK;
