@@ -26,6 +26,7 @@ FMD_FLAG_NO_PIPELINE = 2
 FMD_FLAG_PLL_TIME_PARALLEL = 4
 FMD_FLAG_PLL_LOW_WORK = 8
 FMD_FLAG_PLL_K8 = 16
+FMD_FLAG_PLL_STREAM_ORDER = 32
 FMD_OK, FMD_ERR_ARG, FMD_ERR_SIZE, FMD_ERR_DEVICE, FMD_ERR_NO_DEVICE, FMD_ERR_NAME = 0, -1, -2, -3, -4, -5
 
 
@@ -185,12 +186,13 @@ class BatchDemod:
     """C broadcast-FM demodulators advanced in lock-step on one MI355X."""
 
     def __init__(self, n_channels: int, block_size: int = 65536, fs_baseband: int = 1_024_000, device: int = -1, keep_taps: bool = False,
-                 pipelined: bool = True, pll_kernel: str = "auto"):
+                 pipelined: bool = True, pll_kernel: str = "auto", pll_stream_order: bool = False):
         self.L = load_library()
         self.h = C.c_void_p()
         flags = (FMD_FLAG_KEEP_TAPS if keep_taps else 0) | (0 if pipelined else FMD_FLAG_NO_PIPELINE)
         flags |= {"auto": 0, "time_parallel": FMD_FLAG_PLL_TIME_PARALLEL, "time_parallel8": FMD_FLAG_PLL_TIME_PARALLEL | FMD_FLAG_PLL_K8,
                   "low_work": FMD_FLAG_PLL_LOW_WORK}[pll_kernel]
+        flags |= FMD_FLAG_PLL_STREAM_ORDER if pll_stream_order else 0
         cfg = Config(n_channels, block_size, fs_baseband, device, flags)
         rc = self.L.fmd_create(C.byref(cfg), C.byref(self.h))
         if rc != FMD_OK:

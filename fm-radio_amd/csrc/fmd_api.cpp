@@ -41,7 +41,10 @@ struct fmd_handle_s {
     size_t d_in_bytes = 0;
     hipStream_t own_stream = nullptr;        // host-pointer entry points, uploads, resets
     hipStream_t last_stream = nullptr;
-    hipStream_t sF = nullptr, sA = nullptr, sB = nullptr, sX = nullptr, sR = nullptr;
+    hipStream_t sF = nullptr, sA = nullptr, sB = nullptr, sB2 = nullptr, sX = nullptr, sR = nullptr;
+    unsigned pll_seq = 0;                    // k_pilot_pll launches handed over per wavefront so far (0: hand-over by stream order)
+    bool pll_chained = false;
+    int pll_waves = 0;
     hipEvent_t ev_in = nullptr, ev_F[kSlots] = {}, ev_A[kSlots] = {}, ev_B[kSlots] = {}, ev_E[kSlots] = {}, ev_X[kSlots] = {};
     bool slot_used[kSlots] = {};
     bool pipelined = true;
@@ -180,8 +183,13 @@ int zero_history(fmd_handle h, hipStream_t s) {
 
 int sync_all(fmd_handle h) {
     HIP_TRY(h, hipSetDevice(h->device));
-    for (hipStream_t st : {h->sF, h->sA, h->sB, h->sX, h->sR, h->own_stream}) if (st) HIP_TRY(h, hipStreamSynchronize(st));
+    for (hipStream_t st : {h->sF, h->sA, h->sB, h->sB2, h->sX, h->sR, h->own_stream}) if (st) HIP_TRY(h, hipStreamSynchronize(st));
     if (!h->pipelined && h->n_blocks > 0) HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    if (h->pll_chained && h->pll_seq) {   // the hand-over watchdog of k_pilot_pll
+        unsigned timed_out = 0;
+        HIP_TRY(h, hipMemcpy(&timed_out, h->ctx.b.pll_chain + h->pll_waves, sizeof(unsigned), hipMemcpyDeviceToHost));
+        if (timed_out) return fail(h, FMD_ERR_DEVICE, "k_pilot_pll: a wavefront's predecessor never published its state");
+    }
     return FMD_OK;
 }
 
@@ -202,7 +210,10 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     const SlotRef ref{slot, (int)(h->n_blocks & 1), nullptr, nullptr};
     const bool u8 = sizeof(InT) == 2;
     const bool pipe = h->pipelined;
-    hipStream_t sF = pipe ? h->sF : s, sA = pipe ? h->sA : s, sB = pipe ? h->sB : s, sX = pipe ? h->sX : s, sR = pipe ? h->sR : s;
+    hipStream_t sF = pipe ? h->sF : s, sA = pipe ? h->sA : s, sX = pipe ? h->sX : s, sR = pipe ? h->sR : s;
+    // consecutive blocks' PLL launches alternate between two streams when they hand over per wavefront (fmd_kernels.hip)
+    const bool chained = pipe && h->pll_chained;
+    hipStream_t sB = pipe ? ((chained && (h->n_blocks & 1)) ? h->sB2 : h->sB) : s;
     ProfiledBlock* pm = nullptr;
     if (h->profiling) {
         pm = new ProfiledBlock();
@@ -219,6 +230,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         SlotRef r = ref;
         if (pm && prof_stage(st)) { r.t0 = pm->t0[st]; r.t1 = pm->t1[st]; pm->used[st] = true; }
         if (pipe && !r.t1) r.done = done;
+        if (st == ST_PLL && chained) r.seq = ++h->pll_seq;
         dep = r.t1 ? r.t1 : done;
         return fn(h->ctx, r, on);
     };
@@ -359,6 +371,9 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     // (A CU-mask split between the serial and the FIR streams was measured: it shields the PLL wave from FIR waves
     //  sharing its SIMD — 3.06 -> 2.75 ms — but CU-masked streams did not overlap with each other on this runtime, so
     //  the step got slower overall.  Plain streams + s_setprio in the serial kernels it is.)
+    // (the second PLL stream is own_stream: one more stream would be the ninth on the device with the caller's and would share a
+    //  hardware queue with another stage; everything else own_stream does is preceded by a full synchronisation)
+    h->sB2 = h->own_stream;
     for (hipStream_t* st : {&h->sF, &h->sA, &h->sB, &h->sX, &h->sR}) {
         hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
         if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e)));
@@ -424,6 +439,10 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     if (!rc) rc = dev_alloc(h, &b.mix, C * 2);
     if (!rc) rc = dev_alloc(h, &b.state, (size_t)S_NUM_FIELDS * C);
     if (!rc) rc = dev_alloc(h, &b.spec_stats, 8);
+    // per-wavefront hand-over between consecutive k_pilot_pll launches: the time-parallel kernel only, pipelined mode only
+    h->pll_chained = h->pipelined && d.C * d.m <= 2816 && !(cfg->flags & FMD_FLAG_PLL_STREAM_ORDER);
+    h->pll_waves = (d.C * d.m <= h->ctx.pll_k16_max_channels) ? (d.C + 3) / 4 : (d.C + 7) / 8;
+    if (!rc) rc = dev_alloc(h, &b.pll_chain, (size_t)h->pll_waves + 1);
     if (rc) return bail(rc);
     rc = zero_history(h, h->own_stream);
     if (!rc) rc = upload_controls(h, h->own_stream);

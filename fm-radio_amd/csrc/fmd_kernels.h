@@ -65,7 +65,9 @@ static_assert(kSlots <= 4, "one S_PILOT_POWER state field per slot");
 // first kernel's start and last kernel's end timestamps (attached to the dispatch packets themselves: no extra queue packets)
 // done: optional event that is to fire when the stage's last kernel has completed, carried by that kernel's own dispatch
 // packet (a separate hipEventRecord is one more queue packet between two dependent kernels, ~25 us on the PLL stream)
-struct SlotRef { int buf; int par; hipEvent_t t0 = nullptr; hipEvent_t t1 = nullptr; hipEvent_t done = nullptr; };
+// seq: 1-based number of the block when consecutive blocks' k_pilot_pll launches hand over per wavefront (Buffers::pll_chain),
+// 0: plain stream order
+struct SlotRef { int buf; int par; hipEvent_t t0 = nullptr; hipEvent_t t1 = nullptr; hipEvent_t done = nullptr; unsigned seq = 0; };
 struct Buffers {
     // history tails: stage of block b reads [par], writes [par^1] (producer and consumer are the same stage, same stream)
     float2* base_tail[2];   // [C][tail_base]
@@ -94,6 +96,7 @@ struct Buffers {
     float*  deemph;         // [C][4]  b0,b1,a0,flag
     float*  mix;            // [C][2]  audio mode (as float), stereo mix factor
     float*  state;          // [S_NUM_FIELDS][C]
+    unsigned int* pll_chain;         // [wavefronts of k_pilot_pll + 1] last block number each wavefront completed; [last] = watchdog flag
     unsigned long long* spec_stats;  // [8] speculation counters: pll {chunks, general, replayed, -}, rds {chunks, general, replayed, -}
 };
 

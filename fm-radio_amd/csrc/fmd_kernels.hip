@@ -458,7 +458,7 @@ __device__ __forceinline__ float atan2f_locked(float y, float x, const PllConsts
     return t - t * (s1 + s2);
 }
 
-static constexpr int kPllChunk = 128;         // samples per chunk
+static constexpr int kPllChunk = 128;         // samples per chunk (64 for the 8-lane variant, to halve its 24.5 KB of LDS, cost 10 % of the step)
 static constexpr int kPllRing = 2 * kPllChunk;
 static constexpr int kSlowHoldMax = 16;       // longest run of serial chunks between two speculation attempts
 
@@ -468,7 +468,8 @@ static constexpr int kSlowHoldMax = 16;       // longest run of serial chunks be
 template <int K>
 __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
                                                      float* __restrict__ state, LoopCoeffs k, int power_field,
-                                                     unsigned long long* __restrict__ spec_stats) {
+                                                     unsigned long long* __restrict__ spec_stats,
+                                                     unsigned int* __restrict__ chain, unsigned int seq) {
     constexpr int G = kWave / K, CH = kPllChunk, RING = kPllRing;
     constexpr int kPllSlowSpans = 3 * CH / K;     // a chunk that needed more spans than this is "out of lock"
     __shared__ __attribute__((aligned(16))) float2 xin[G][RING];   // pilot samples, ring by (sample index & 255)
@@ -482,18 +483,7 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
     const bool live = c < d.C;
     const int cs = live ? c : d.C - 1;
     const int n = d.n_fm_out, chunks = n / CH;
-    // AGC_Filter::process (agc.h:12-19) as compiled: target_gain = sqrt((target/sum) * N)
-    float gain = st(state, S_AGC_PILOT_GAIN, d.C, cs);
-    {
-        const float sum = st(state, power_field, d.C, cs);
-        const float target_gain = sqrtf((1.0f / sum) * (float)n);
-        gain = fmaf(target_gain - gain, 0.2f, gain);
-    }
-    // loop state, identical in the 16 lanes of a channel
-    float lx1 = st(state, S_PLL_X1, d.C, cs), ly1 = st(state, S_PLL_Y1, d.C, cs), integ = st(state, S_PLL_INT, d.C, cs);
-    float err_prev = st(state, S_PLL_ERR, d.C, cs), tph_prev = st(state, S_PLL_T, d.C, cs);
     const PllConsts kc = make_pll_consts(k);
-    ex[g][0] = err_prev;
 
     // global <-> LDS: lane (g, j) moves row g; chunk q of the pilot = 4 float4 (2 samples each) per lane
     const int srow = c0 + g < d.C ? c0 + g : d.C - 1;
@@ -509,6 +499,38 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
     FMD_PLL_FETCH(0) FMD_PLL_STASH(0)
     FMD_PLL_FETCH(1) FMD_PLL_STASH(1)
     FMD_PLL_FETCH(2)
+
+    // Block-to-block hand-over per WAVEFRONT instead of per kernel.  The loop state of these channels is written by the same
+    // wavefront of the previous block's launch; with `chain` the launches of consecutive blocks sit on two streams, this one
+    // may start (and has its first chunks in flight, above) while the previous one still runs, and waits here until its
+    // predecessor wavefront has published its state: chain[wave] == seq - 1 (release/acquire at agent scope).  No queue
+    // packet, no kernel boundary and no launch ramp between the two ends of the serial chain any more.  The predecessor was
+    // submitted earlier and never waits on anything later, and 2 x 512 such workgroups cannot fill the chip, so the wait
+    // cannot deadlock; a 2 s watchdog turns a lost predecessor (a failed launch) into an error flag instead of a hang.
+    // Used for batches up to 2816 stations x m (fmd_api.cpp): beyond, two launches' workgroups resident at once take more
+    // from the FIR kernels than the hand-over gap gives back (same-box A/B: -13 % at 1024 stations, -5 % at 2560, +3 % at 3072).
+    if (chain) {
+        const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(&chain[blockIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq - 1u) {
+            __builtin_amdgcn_s_sleep(4);
+            if (__builtin_amdgcn_s_memrealtime() - w0 > 200000000ull) {   // 100 MHz ticks
+                if (lane == 0) __hip_atomic_store(&chain[gridDim.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    // AGC_Filter::process (agc.h:12-19) as compiled: target_gain = sqrt((target/sum) * N)
+    float gain = st(state, S_AGC_PILOT_GAIN, d.C, cs);
+    {
+        const float sum = st(state, power_field, d.C, cs);
+        const float target_gain = sqrtf((1.0f / sum) * (float)n);
+        gain = fmaf(target_gain - gain, 0.2f, gain);
+    }
+    // loop state, identical in the 16 lanes of a channel
+    float lx1 = st(state, S_PLL_X1, d.C, cs), ly1 = st(state, S_PLL_Y1, d.C, cs), integ = st(state, S_PLL_INT, d.C, cs);
+    float err_prev = st(state, S_PLL_ERR, d.C, cs), tph_prev = st(state, S_PLL_T, d.C, cs);
+    ex[g][0] = err_prev;
+
 
     int pos = 0;                 // next sample of this channel (absolute within the block); identical in its 16 lanes
     int seq_left = 0, hold = 0;  // wave-uniform: serial chunks still to run / back-off
@@ -646,6 +668,10 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
         st(state, S_AGC_PILOT_GAIN, d.C, c) = gain;
         st(state, S_PLL_X1, d.C, c) = lx1; st(state, S_PLL_Y1, d.C, c) = ly1;
         st(state, S_PLL_INT, d.C, c) = integ; st(state, S_PLL_ERR, d.C, c) = err_prev; st(state, S_PLL_T, d.C, c) = tph_prev;
+    }
+    if (chain) {   // publish: the state stores above, then the sequence number
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_store(&chain[blockIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (spec_stats) {
         // per wavefront: chunks / chunks run serially / spans redone with the reference forms; per channel: spans, samples
@@ -1501,12 +1527,13 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
                    ctx.b.state, ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
         return hipGetLastError();
     }
+    unsigned int* chain = r.seq ? ctx.b.pll_chain : nullptr;
     if (d.C * d.m <= ctx.pll_k16_max_channels) {
         FMD_LAUNCH(r, true, true, k_pilot_pll<16>, dim3((unsigned)((d.C + 3) / 4)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
-                   ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
+                   ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats, chain, r.seq);
     } else {
         FMD_LAUNCH(r, true, true, k_pilot_pll<8>, dim3((unsigned)((d.C + 7) / 8)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
-                   ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
+                   ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats, chain, r.seq);
     }
     return hipGetLastError();
 }

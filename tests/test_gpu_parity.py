@@ -301,6 +301,29 @@ def test_pcm16_audio_frames_match_the_scraper_conversion(pkg):
     dm.close()
 
 
+def test_pll_handover_per_wavefront_equals_stream_order(pkg):
+    """Batches up to 2816 stations hand the PLL state from one block's k_pilot_pll launch to the next per wavefront, while both
+    launches are resident (two streams, release/acquire on a per-wavefront sequence number) — the same bits as ordering the two
+    launches by the stream (FMD_FLAG_PLL_STREAM_ORDER), block after block, for a batch that spans many wavefronts."""
+    import torch
+    n_ch, bs, nb = 600, 16384, 10
+    base = _caps(5, nb * bs, fs=256_000.0, seed=2100)
+    caps = torch.from_numpy(np.ascontiguousarray(base[np.arange(n_ch) % 5])).cuda()
+    outs = []
+    for stream_order in (False, True):
+        dm = pkg.BatchDemod(n_ch, bs, 256_000, keep_taps=True, pll_stream_order=stream_order)
+        got = []
+        for b in range(nb):
+            dm.process(caps[:, b * bs:(b + 1) * bs].contiguous())
+            if b % 3 == 2 or b == nb - 1:      # not after every block: let several launches be in flight
+                got.append((dm.stream("pll_dt").copy(), dm.audio().copy()))
+        dm.close()
+        outs.append(got)
+    for (dt_a, au_a), (dt_b, au_b) in zip(*outs):
+        assert np.array_equal(dt_a.view(np.uint32), dt_b.view(np.uint32))
+        assert np.array_equal(au_a.view(np.uint32), au_b.view(np.uint32))
+
+
 def test_gpu_runs_are_deterministic(pkg):
     caps = _caps(3, 6 * 65536, seed=17, u8=True)
     a = run_gpu(pkg, caps, 65536, 1_024_000)

@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
         hipMemset(stats, 0, 64);
         hipLaunchKernelGGL(k_pll_ref, g, dim3(64), 0, nullptr, d, pilot, dt[0], state[0], k, (int)S_PILOT_POWER0);
         hipEventRecord(e0, nullptr);
-        hipLaunchKernelGGL(k_pilot_pll<16>, dim3((C + 3) / 4), dim3(64), 0, nullptr, d, pilot, dt[1], state[1], k, (int)S_PILOT_POWER0, stats);
+        hipLaunchKernelGGL(k_pilot_pll<16>, dim3((C + 3) / 4), dim3(64), 0, nullptr, d, pilot, dt[1], state[1], k, (int)S_PILOT_POWER0, stats, (unsigned int*)nullptr, 0u);
         hipEventRecord(e1, nullptr); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         hipMemcpy(a.data(), dt[0], a.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), dt[1], b.size() * 4, hipMemcpyDeviceToHost);
@@ -96,7 +96,7 @@ int main(int argc, char** argv) {
         if (mode == 1) for (int i = 0; i < 6; i++) hipLaunchKernelGGL(k_spin_valu, dim3(2048), dim3(256), 0, s2, dt[0], 40000);
         if (mode == 2) for (int i = 0; i < 6; i++) hipLaunchKernelGGL(k_stream_copy, dim3(4096), dim3(256), 0, s2, ca, cb, nb);
         hipEventRecord(e0, s1);
-        hipLaunchKernelGGL(k_pilot_pll<16>, dim3((C + 3) / 4), dim3(64), 0, s1, d, pilot, dt[1], state[1], k, (int)S_PILOT_POWER0, stats);
+        hipLaunchKernelGGL(k_pilot_pll<16>, dim3((C + 3) / 4), dim3(64), 0, s1, d, pilot, dt[1], state[1], k, (int)S_PILOT_POWER0, stats, (unsigned int*)nullptr, 0u);
         hipEventRecord(e1, s1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         hipDeviceSynchronize();
