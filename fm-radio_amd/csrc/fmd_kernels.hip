@@ -322,31 +322,56 @@ struct PilotIIR {
 
 // a6 + power sum of a7 — reference LockOntoPilot :421-423 (IIR -> pilot_buf) and AGC_Filter::calculate_average_power
 // (agc.h:21-30).  Writes the un-gained pilot so the latency-critical PLL kernel does not have to recompute the IIR.
+// ROW: the lane's 32-sample row is read from LDS in one go, filtered from registers and written back in one go (no LDS latency
+// inside the recurrence: 8 % off the step at 1024 stations, where this kernel's latency is the step) — at the price of ~300
+// VGPRs, which costs 2.5 % at 4096 stations (same-box A/B), so larger batches use the sample-by-sample form.
+template <bool ROW>
 __global__ __launch_bounds__(kWave) void k_pilot_power(Dims d, const float2* __restrict__ fm_out_iq, float2* __restrict__ pilot,
                                                        float* __restrict__ state, LoopCoeffs k, int power_field) {
-    __shared__ __attribute__((aligned(16))) float2 xin[2][kWave * kRowC];
+    __shared__ __attribute__((aligned(16))) float2 xin[kWave * kRowC];
     __builtin_amdgcn_s_setprio(3);  // latency-bound recurrence: win issue arbitration against co-resident FIR waves
     const int lane = threadIdx.x, c0 = blockIdx.x * kWave, c = c0 + lane;
     const bool live = c < d.C;
     const int cs = live ? c : d.C - 1;
     PilotIIR f; f.load(state, SA_X1R, d.C, cs);
     float power = 0.0f;
-    const int n = d.n_fm_out, chunks = n / kChunk;
-    ChunkRegsC regs = chunk_load_c(fm_out_iq, n, c0, d.C, 0);
-    for (int ch = 0; ch < chunks; ch++) {
-        float2* buf = xin[ch & 1];
-        chunk_store_c(regs, buf);
-        __syncthreads();
-        regs = chunk_load_c(fm_out_iq, n, c0, d.C, (ch + 1 < chunks ? ch + 1 : ch) * kChunk);
-#pragma unroll 4
-        for (int t = 0; t < kChunk; t++) {
-            const float2 y = f.step(buf[lane * kRowC + t], k);
-            power = power + fmaf(y.x, y.x, y.y * y.y);
-            buf[lane * kRowC + t] = y;
-        }
-        __syncthreads();
-        chunk_flush_c(buf, pilot, n, c0, d.C, ch * kChunk);
+    const int n = d.n_fm_out, chunks = n / kChunk;     // even: n_fm_out is a multiple of 128
+    // TWO chunks in flight in registers (a chunk's 32 IIR steps take ~1.2 us, an HBM load under the pipeline's traffic 2-4 us:
+    // with one chunk ahead the kernel sat on the memory latency, 0.52 ms per block alone), one LDS buffer processed in place
+    ChunkRegsC ra = chunk_load_c(fm_out_iq, n, c0, d.C, 0);
+    ChunkRegsC rb = chunk_load_c(fm_out_iq, n, c0, d.C, kChunk);
+#define FMD_POWER_CHUNK(regs, ch_)                                                                                     \
+    {                                                                                                                  \
+        chunk_store_c(regs, xin);                                                                                      \
+        __syncthreads();                                                                                               \
+        regs = chunk_load_c(fm_out_iq, n, c0, d.C, ((ch_) + 2 < chunks ? (ch_) + 2 : (ch_)) * kChunk);                  \
+        if constexpr (ROW) {                                                                                           \
+            float4* row_ = reinterpret_cast<float4*>(xin + lane * kRowC);                                              \
+            float4 w_[kChunk / 2];                                                                                     \
+            _Pragma("unroll") for (int t = 0; t < kChunk / 2; t++) w_[t] = row_[t];                                    \
+            _Pragma("unroll") for (int t = 0; t < kChunk / 2; t++) {                                                   \
+                const float2 y0 = f.step(make_float2(w_[t].x, w_[t].y), k);                                            \
+                power = power + fmaf(y0.x, y0.x, y0.y * y0.y);                                                         \
+                const float2 y1 = f.step(make_float2(w_[t].z, w_[t].w), k);                                            \
+                power = power + fmaf(y1.x, y1.x, y1.y * y1.y);                                                         \
+                w_[t] = make_float4(y0.x, y0.y, y1.x, y1.y);                                                           \
+            }                                                                                                          \
+            _Pragma("unroll") for (int t = 0; t < kChunk / 2; t++) row_[t] = w_[t];                                    \
+        } else {                                                                                                       \
+            _Pragma("unroll 4") for (int t = 0; t < kChunk; t++) {                                                     \
+                const float2 y = f.step(xin[lane * kRowC + t], k);                                                     \
+                power = power + fmaf(y.x, y.x, y.y * y.y);                                                             \
+                xin[lane * kRowC + t] = y;                                                                             \
+            }                                                                                                          \
+        }                                                                                                              \
+        __syncthreads();                                                                                               \
+        chunk_flush_c(xin, pilot, n, c0, d.C, (ch_) * kChunk);                                                         \
     }
+    for (int ch = 0; ch < chunks; ch += 2) {
+        FMD_POWER_CHUNK(ra, ch)
+        FMD_POWER_CHUNK(rb, ch + 1)
+    }
+#undef FMD_POWER_CHUNK
     if (live) { f.store(state, SA_X1R, d.C, c); st(state, power_field, d.C, c) = power; }
 }
 
@@ -1515,8 +1540,13 @@ hipError_t launch_stage_deemph(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
 
 hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
-    FMD_LAUNCH(r, true, true, k_pilot_power, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[r.buf], ctx.b.pilot[r.buf], ctx.b.state,
-                       ctx.loops, (int)S_PILOT_POWER0 + r.buf);
+    if (d.C * d.m <= 2816) {   // the batches whose step is this kernel's latency (and whose PLL launches hand over per wavefront)
+        FMD_LAUNCH(r, true, true, k_pilot_power<true>, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[r.buf], ctx.b.pilot[r.buf], ctx.b.state,
+                   ctx.loops, (int)S_PILOT_POWER0 + r.buf);
+    } else {
+        FMD_LAUNCH(r, true, true, k_pilot_power<false>, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[r.buf], ctx.b.pilot[r.buf], ctx.b.state,
+                   ctx.loops, (int)S_PILOT_POWER0 + r.buf);
+    }
     return hipGetLastError();
 }
 
