@@ -31,7 +31,7 @@ struct LoopCoeffs {
 enum StateField : int {
     // pilot peak IIR
     SA_X1R, SA_X1I, SA_X2R, SA_X2I, SA_Y1R, SA_Y1I, SA_Y2R, SA_Y2I,
-    S_PILOT_POWER0, S_PILOT_POWER1, S_PILOT_POWER2, S_PILOT_POWER3, // sum |pilot|^2 of the block in pipeline slot 0..3 (power pass -> PLL pass)
+    S_PILOT_POWER0, S_PILOT_POWER1, S_PILOT_POWER2, S_PILOT_POWER3, S_PILOT_POWER4, S_PILOT_POWER5, S_PILOT_POWER6, S_PILOT_POWER7, // sum |pilot|^2 of the block in pipeline slot 0..7 (power pass -> PLL pass)
     S_AGC_PILOT_GAIN,
     S_PLL_X1, S_PLL_Y1, S_PLL_INT, S_PLL_ERR, S_PLL_T,
     S_LMR_PHASE_CUR, S_LMR_PHASE_PREV,
@@ -57,10 +57,11 @@ struct Dims {
 
 // Stream buffers are indexed by pipeline slot (= block index % kSlots): the stages of consecutive blocks run concurrently
 // on different streams, so a producer of block b+1 must not overwrite what a consumer of block b (or b-1) still reads.
-// Four slots: the chain 'extract+RDS of block b -> front end of the block that reuses its slot -> power pass -> PLL' must be
-// shorter than the PLL passes that separate the two blocks, with every stage slowed by the others running beside it.
-static constexpr int kSlots = 4;
-static_assert(kSlots <= 4, "one S_PILOT_POWER state field per slot");
+// Six slots: the front end and the power pass of a block must be able to run far enough ahead of the PLL that the next PLL
+// launch's inputs are ready before the running one ends (with four, the front end of block b+4 waited for the RDS stage of
+// block b and the power pass came in ~90 us before the PLL needed it: no room for the per-wavefront hand-over to overlap).
+static constexpr int kSlots = 6;
+static_assert(kSlots <= 8, "one S_PILOT_POWER state field per slot");
 // buf = block % kSlots (stream buffers), par = block & 1 (history tails); t0/t1: optional events that receive the stage's
 // first kernel's start and last kernel's end timestamps (attached to the dispatch packets themselves: no extra queue packets)
 // done: optional event that is to fire when the stage's last kernel has completed, carried by that kernel's own dispatch
