@@ -389,9 +389,9 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     Dims& d = h->ctx.d;
     d.C = cfg->n_channels; d.N = cfg->block_size; d.m = m;
     // Which pilot-PLL kernel: the time-parallel one halves a lone wavefront's latency for 2.6x the VALU work.  Once the chip's
-    // VALU throughput bounds the step the low-work kernel is faster (measured cross-over: between 6144 and 8192 channels at
+    // VALU throughput bounds the step the low-work kernel is faster (measured cross-over: between 7168 and 8192 channels at
     // 256 kSa/s, about 8192 at 1.024 MSa/s).
-    h->ctx.pll_time_parallel_max_channels = (cfg->flags & FMD_FLAG_PLL_LOW_WORK) ? 0 : ((cfg->flags & FMD_FLAG_PLL_TIME_PARALLEL) ? 0x7fffffff : 6144);
+    h->ctx.pll_time_parallel_max_channels = (cfg->flags & FMD_FLAG_PLL_LOW_WORK) ? 0 : ((cfg->flags & FMD_FLAG_PLL_TIME_PARALLEL) ? 0x7fffffff : 7168);
     // within the time-parallel kernel: 16 lanes per channel while a lone wavefront's latency is what matters (same-box A/B:
     // 8 % faster at 2560 channels, 6 % at 3072), 8 lanes per channel (30 % fewer VALU instructions) beyond (2 % faster at 4096)
     h->ctx.pll_k16_max_channels = (cfg->flags & FMD_FLAG_PLL_K8) ? 0 : 3584;

@@ -53,7 +53,7 @@ typedef struct {
 
 #define FMD_FLAG_KEEP_TAPS   1u  /* keep the intermediate streams readable through fmd_get_stream */
 #define FMD_FLAG_NO_PIPELINE 2u  /* run every stage on the caller's stream, one after the other (debugging / profiling) */
-#define FMD_FLAG_PLL_TIME_PARALLEL 4u  /* force the time-parallel pilot-PLL kernel (default: batches <= 6144 channels) */
+#define FMD_FLAG_PLL_TIME_PARALLEL 4u  /* force the time-parallel pilot-PLL kernel (default: batches <= 7168 channels) */
 #define FMD_FLAG_PLL_K8           16u  /* time-parallel kernel with 8 (not 16) lanes per channel whatever the batch size (default: batches x m > 3584) */
 #define FMD_FLAG_PLL_STREAM_ORDER  32u  /* consecutive blocks' pilot-PLL launches ordered by the stream (kernel boundary) instead of handing over per wavefront while both run (A/B and debugging; same results) */
 #define FMD_FLAG_PLL_LOW_WORK      8u  /* force the low-work pilot-PLL kernel (default: larger batches); same results either way */
