@@ -210,20 +210,27 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
         }
     }
     __syncthreads();
-    // a3: decimate-by-2 FIR, 8 lane accumulators
-    for (int uu = tid; uu < T + 64; uu += 256) {
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float2* w2 = reinterpret_cast<const float2*>(dem + 2 * uu);
+    // a3: decimate-by-2 FIR, 8 lane accumulators.  Every thread makes TWO consecutive outputs from one window of 66 input
+    // samples read as 17 ds_read_b128 (16 B lane stride: conflict-free, full LDS rate): 136 B of LDS traffic per output instead
+    // of 256 B — and left to one output per thread the compiler pairs the 32 ds_read_b64 into ds_read2_b64, which move only
+    // 128 B/clk.  This loop is the kernel's LDS hot spot.
+    for (int pp = tid; 2 * pp < T + 64; pp += 256) {
+        const int uu = 2 * pp;
+        float w[68];
+        const float4* src = reinterpret_cast<const float4*>(dem + 2 * uu);
 #pragma unroll
-        for (int n = 0; n < 64; n += 2) {
-            const float2 v = w2[n / 2];
-            acc[n & 7] = fmaf(v.x, taps.b_fm_out[n], acc[n & 7]);
-            acc[(n + 1) & 7] = fmaf(v.y, taps.b_fm_out[n + 1], acc[(n + 1) & 7]);
+        for (int q = 0; q < 17; q++) { const float4 t = src[q]; w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w; }
+        float y[2];
+#pragma unroll
+        for (int v = 0; v < 2; v++) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int n = 0; n < 64; n++) acc[n & 7] = fmaf(w[2 * v + n], taps.b_fm_out[n], acc[n & 7]);
+            const float a0 = acc[0] + acc[4], a1 = acc[1] + acc[5], a2 = acc[2] + acc[6], a3 = acc[3] + acc[7];
+            y[v] = (a0 + a2) + (a1 + a3);
         }
-        const float a0 = acc[0] + acc[4], a1 = acc[1] + acc[5], a2 = acc[2] + acc[6], a3 = acc[3] + acc[7];
-        const float y = (a0 + a2) + (a1 + a3);
-        fo[uu] = y;
-        if (deemph_path && uu >= 64) fm_out_plain[(size_t)c * d.n_fm_out + o0 + (uu - 64)] = y;
+        *reinterpret_cast<float2*>(fo + uu) = make_float2(y[0], y[1]);
+        if (deemph_path && uu >= 64) *reinterpret_cast<float2*>(fm_out_plain + (size_t)c * d.n_fm_out + o0 + (uu - 64)) = make_float2(y[0], y[1]);
     }
     __syncthreads();
     // a5: Hilbert FIR; only lanes 1,3,5,7 of the reference's 8-lane accumulator see non-zero taps
