@@ -331,7 +331,8 @@ class BatchDemod:
 
     def audio_tensor(self):
         """Zero-copy torch view of the newest block's device audio buffer [C, n_audio, 2] (the library alternates
-        between two buffers: call again after each process(); contents are complete after wait_outputs/synchronize)."""
+        between its pipeline slots: call again after each process(); contents are complete after wait_outputs/synchronize and stay
+        valid until five more blocks have been submitted)."""
         import torch
         p = C.c_void_p()
         self._check(self.L.fmd_audio_dev(self.h, C.byref(p)))
