@@ -324,6 +324,36 @@ def test_pll_handover_per_wavefront_equals_stream_order(pkg):
         assert np.array_equal(au_a.view(np.uint32), au_b.view(np.uint32))
 
 
+def test_two_demodulators_interleaved_and_reset_midstream(pkg):
+    """Two handles advanced alternately (each with its own per-wavefront PLL hand-over chain and streams), one of them reset
+    half way: every block equals what a lone, sequentially executed demodulator produces for the same input history."""
+    n_ch, bs, nb = 96, 16384, 6
+    caps = _caps(4, nb * bs, fs=256_000.0, seed=909)
+    caps = np.ascontiguousarray(caps[np.arange(n_ch) % 4])
+    def lone(reset_at):
+        dm = pkg.BatchDemod(n_ch, bs, 256_000, pipelined=False)
+        out = []
+        for b in range(nb):
+            if b == reset_at:
+                dm.reset()
+            dm.process(caps[:, b * bs:(b + 1) * bs])
+            out.append((dm.audio().copy(), dm.stream("pll_dt").copy()))
+        dm.close()
+        return out
+    want_a, want_b = lone(None), lone(3)
+    a = pkg.BatchDemod(n_ch, bs, 256_000)
+    b_ = pkg.BatchDemod(n_ch, bs, 256_000)
+    for blk in range(nb):
+        if blk == 3:
+            b_.reset()
+        a.process(caps[:, blk * bs:(blk + 1) * bs])
+        b_.process(caps[:, blk * bs:(blk + 1) * bs])
+        for dm, want in ((a, want_a), (b_, want_b)):
+            assert np.array_equal(dm.audio().view(np.uint32), want[blk][0].view(np.uint32)), blk
+            assert np.array_equal(dm.stream("pll_dt").view(np.uint32), want[blk][1].view(np.uint32)), blk
+    a.close(); b_.close()
+
+
 def test_gpu_runs_are_deterministic(pkg):
     caps = _caps(3, 6 * 65536, seed=17, u8=True)
     a = run_gpu(pkg, caps, 65536, 1_024_000)
