@@ -135,6 +135,7 @@ def load_library():
     L.fmd_get_stream.argtypes = [H, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.fmd_selftest_atan2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.fmd_selftest_atan2_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.fmd_selftest_atan2_table_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.fmd_selftest_atan2_small.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.fmd_get_spec_stats.argtypes = [H, C.c_void_p, C.c_int]
     L.fmd_profile_enable.argtypes = [H, C.c_int]
@@ -158,7 +159,8 @@ def selftest_atan2(y: np.ndarray, x: np.ndarray, table_form: bool = False) -> np
     """The kernels' atan2f evaluated on the device (fmd_selftest_atan2; table_form: the discriminator's variant)."""
     y = np.ascontiguousarray(y, np.float32); x = np.ascontiguousarray(x, np.float32)
     out = np.empty_like(y)
-    fn = load_library().fmd_selftest_atan2_table if table_form else load_library().fmd_selftest_atan2
+    L = load_library()
+    fn = L.fmd_selftest_atan2_table_u8 if table_form == "u8" else (L.fmd_selftest_atan2_table if table_form else L.fmd_selftest_atan2)
     rc = fn(y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), y.size)
     if rc != FMD_OK:
         raise FmdError(rc, load_library().fmd_last_error(None).decode())

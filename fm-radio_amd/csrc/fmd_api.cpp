@@ -658,6 +658,7 @@ static int selftest_atan2_host(const float* y, const float* x, float* out, uint8
 int fmd_selftest_atan2(const float* y, const float* x, float* out, size_t n) { return selftest_atan2_host(y, x, out, nullptr, n); }
 
 int fmd_selftest_atan2_table(const float* y, const float* x, float* out, size_t n) { return selftest_atan2_host(y, x, out, nullptr, n, 1); }
+int fmd_selftest_atan2_table_u8(const float* y, const float* x, float* out, size_t n) { return selftest_atan2_host(y, x, out, nullptr, n, 2); }
 
 int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t* ok, size_t n) {
     if (!ok) return FMD_ERR_ARG;

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
 #pragma unroll
         for (int r = 0; r < PER; r++) {
             const int i = tid + 256 * r;
-            if (i < NW) theta[i] = fmd_atan2f_table(buf[r].y, buf[r].x, atab);
+            if (i < NW) theta[i] = fmd_atan2f_table<sizeof(InT) == 2>(buf[r].y, buf[r].x, atab);   // u8 IQ: small integers
         }
     }
     __syncthreads();
@@ -1479,7 +1479,9 @@ __global__ void k_selftest_atan2(const float* __restrict__ y, const float* __res
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (table_form) {   // k_front's discriminator
+    if (table_form == 2) {   // k_front's discriminator on u8 IQ (operands are small integers)
+        out[i] = fmd_atan2f_table<true>(y[i], x[i], &atab);
+    } else if (table_form) {   // k_front's discriminator
         out[i] = fmd_atan2f_table(y[i], x[i], &atab);
     } else if (ok_out) {   // the locked-loop short form of k_pilot_pll's phase detector and its domain predicate
         LoopCoeffs k{};

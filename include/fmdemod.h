@@ -169,6 +169,8 @@ typedef struct {
 int fmd_selftest_atan2(const float* y, const float* x, float* out, size_t n);
 /* Same for the table-driven form the discriminator (k_front) uses: identical values, fewer issued instructions. */
 int fmd_selftest_atan2_table(const float* y, const float* x, float* out, size_t n);
+/* ... and its variant for u8 IQ at 256 kSa/s, whose operands are the integers -127..128 (only 0/0 is special there). */
+int fmd_selftest_atan2_table_u8(const float* y, const float* x, float* out, size_t n);
 /* Same for the short form k_pilot_pll's phase detector uses on a locked loop: out[i] is only meaningful where ok[i] != 0, and
  * there it must equal atan2f(y[i], x[i]) bit-for-bit (DESIGN.md "Pilot PLL"). */
 int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t* ok, size_t n);

@@ -205,6 +205,17 @@ def test_device_atan2_equals_host_libm(pkg):
                                f"dev={dev[neq][0]!r} host={host[neq][0]!r}")
 
 
+def test_device_atan2_on_u8_operands_is_libm_exhaustively(pkg):
+    """The discriminator's arctangent on u8 IQ at 256 kSa/s (operands are the integers -127..128, zeros included, only 0/0
+    treated specially): every one of the 65536 operand pairs against the host libm."""
+    v = np.arange(-127, 129, dtype=np.float32)
+    y, x = [a.reshape(-1).copy() for a in np.meshgrid(v, v)]
+    dev = pkg.selftest_atan2(y, x, table_form="u8")
+    host = O.libm_atan2f(y, x)
+    neq = dev.view(np.uint32) != host.view(np.uint32)
+    assert not neq.any(), f"{int(neq.sum())} mismatches, first: y={y[neq][0]!r} x={x[neq][0]!r} dev={dev[neq][0]!r} host={host[neq][0]!r}"
+
+
 def test_device_atan2_short_form_is_exact_where_it_claims(pkg):
     """The locked-loop short form (no range selection, shortened division): wherever its predicate holds, its value is
     libm's atan2f bit-for-bit; and the predicate does hold on the inputs a locked loop produces."""
