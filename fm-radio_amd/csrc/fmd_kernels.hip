@@ -112,6 +112,31 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
         constexpr int ITEMS = NB / 2;                       // items of 2 consecutive samples (g_lo and TAIL are even)
         constexpr int PER = (ITEMS + 255) / 256;
         float4 buf[PER];
+        if (sizeof(InT) == 2 && tile != 0) {
+            // u8 IQ: 16 bytes = 8 samples per lane and load (the 4-byte loads of the generic path move a quarter of a cache
+            // line per wavefront instruction); NB, TAIL and g_lo are multiples of 8
+            static_assert(NB % 8 == 0 && G::TAIL % 8 == 0, "u8 staging in items of 8 samples");
+            constexpr int ITEMS8 = NB / 8, PER8 = (ITEMS8 + 255) / 256;
+            uint4 raw[PER8];
+#pragma unroll
+            for (int r = 0; r < PER8; r++) {
+                const int j = tid + 256 * r;
+                if (j < ITEMS8) raw[r] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(in_c) + 2 * (g_lo + 8 * (long)j));
+            }
+#pragma unroll
+            for (int r = 0; r < PER8; r++) {
+                const int j = tid + 256 * r;
+                if (j < ITEMS8) {
+                    const unsigned int wds[4] = {raw[r].x, raw[r].y, raw[r].z, raw[r].w};
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const unsigned int h = wds[e >> 1] >> (16 * (e & 1));
+                        const int i = 8 * j + e;
+                        ph[(i % M) * PS + (i / M)] = make_float2((float)(h & 0xffu) - 127.0f, (float)((h >> 8) & 0xffu) - 127.0f);
+                    }
+                }
+            }
+        } else {
         if (tile != 0) {
 #pragma unroll
             for (int r = 0; r < PER; r++) {
@@ -136,6 +161,7 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
                 ph[(i0 % M) * PS + (i0 / M)] = make_float2(buf[r].x, buf[r].y);
                 ph[(i1 % M) * PS + (i1 / M)] = make_float2(buf[r].z, buf[r].w);
             }
+        }
         }
         __syncthreads();
         // a1 + a2: fm_in[w] then theta[w] = atan2(Q, I).  Every thread makes TWO consecutive outputs from one sliding
