@@ -166,6 +166,7 @@ int zero_history(fmd_handle h, hipStream_t s) {
     Buffers& b = h->ctx.b;
     for (int p = 0; p < 2; p++) {
         HIP_TRY(h, hipMemsetAsync(b.base_tail[p], 0, sizeof(float2) * (size_t)d.C * d.tail_base, s));
+        if (b.pre_tail[p]) HIP_TRY(h, hipMemsetAsync(b.pre_tail[p], 0, sizeof(float2) * (size_t)d.C * 64, s));
         HIP_TRY(h, hipMemsetAsync(b.iq_tail[p], 0, sizeof(float2) * (size_t)d.C * 128, s));
         HIP_TRY(h, hipMemsetAsync(b.dt_tail[p], 0, sizeof(float) * (size_t)d.C * 128, s));
         HIP_TRY(h, hipMemsetAsync(b.fo_tail[p], 0, sizeof(float) * (size_t)d.C * 64, s));
@@ -413,12 +414,14 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     int rc = FMD_OK;
     for (int p = 0; p < 2 && !rc; p++) {
         rc = dev_alloc(h, &b.base_tail[p], C * d.tail_base);
+        if (!rc && m > 1) rc = dev_alloc(h, &b.pre_tail[p], C * 64);
         if (!rc) rc = dev_alloc(h, &b.iq_tail[p], C * 128);
         if (!rc) rc = dev_alloc(h, &b.dt_tail[p], C * 128);
         if (!rc) rc = dev_alloc(h, &b.fo_tail[p], C * 64);
     }
     for (int p = 0; p < kSlots && !rc; p++) {
         rc = dev_alloc(h, &b.fm_out_iq[p], C * d.n_fm_out);
+        if (!rc && m > 1) rc = dev_alloc(h, &b.fm_in[p], C * d.n_fm_in);
         if (!rc) rc = dev_alloc(h, &b.fm_out[p], C * d.n_fm_out);
         if (!rc) rc = dev_alloc(h, &b.pilot[p], C * d.n_fm_out);
         if (!rc) rc = dev_alloc(h, &b.pll_dt[p], C * d.n_fm_out);

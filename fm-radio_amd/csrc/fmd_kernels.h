@@ -52,7 +52,7 @@ struct Dims {
     int N;          // baseband samples per block
     int m;          // stage-1 decimation (1, 4, 8)
     int n_fm_in, n_fm_out, n_rds, n_audio, n_est;
-    int tail_base;  // baseband (m>1) or fm_in (m==1) samples of history kept per channel
+    int tail_base;  // fm_in samples of history k_front keeps per channel
 };
 
 // Stream buffers are indexed by pipeline slot (= block index % kSlots): the stages of consecutive blocks run concurrently
@@ -71,7 +71,9 @@ static_assert(kSlots <= 8, "one S_PILOT_POWER state field per slot");
 struct SlotRef { int buf; int par; hipEvent_t t0 = nullptr; hipEvent_t t1 = nullptr; hipEvent_t done = nullptr; unsigned seq = 0; };
 struct Buffers {
     // history tails: stage of block b reads [par], writes [par^1] (producer and consumer are the same stage, same stream)
-    float2* base_tail[2];   // [C][tail_base]
+    float2* base_tail[2];   // [C][tail_base]  fm_in history of k_front
+    float2* pre_tail[2];    // [C][64]         baseband history of k_predecim (m > 1)
+    float2* fm_in[kSlots];  // [C][n_fm_in]    the first decimator's output (m > 1)
     float2* iq_tail[2];     // [C][128]   last fm_out_iq samples of the previous block
     float*  dt_tail[2];     // [C][128]   last pll_dt samples of the previous block
     float*  fo_tail[2];     // [C][64]    last fm_out samples (Hilbert FIR history, de-emphasis path)

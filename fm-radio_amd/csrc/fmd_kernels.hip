@@ -302,6 +302,104 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
 }
 
 // =============================================================================================
+// k_predecim — the first decimator on its own at 1.024 / 2.048 MSa/s: PolyphaseDownsampler<cf32> M x 64 taps
+// (polyphase_filter.h:41-64, c32_f32_cum_mul.cpp:70-111) from baseband (cf32 or u8, reference src/app.cpp:56-62) to the
+// 256 kSa/s stream fm_in, which k_front<1> then takes exactly as it takes a 256 kSa/s capture.
+// Fused into one kernel with the discriminator (k_front<4>, k_front<8>) the decimator had to be recomputed over the 191-sample
+// halo of the FIRs behind it (+19 % of the dominant work at 512-output tiles, which is all its 52 KB of LDS allowed); on its own
+// the halo is 64 - M input samples per 512 outputs, every lane is busy in the one pair-blocked pass, and the back half runs
+// on the 1024-output tiles of the 256 kSa/s path.  fm_in costs 16 B per 256 kSa/s sample of extra HBM traffic (written once,
+// read once) on a path that sits at a fifth of the HBM roofline.
+// One workgroup = one channel x 512 fm_in outputs; input split into M phases in LDS; accumulation order as in k_front.
+// =============================================================================================
+template <int M>
+struct PredecimGeom {
+    static constexpr int TP = 512;                    // outputs per workgroup
+    static constexpr int NJ = 64 / M;                 // taps per phase
+    static constexpr int NB = M * TP + 64;            // input samples staged (64 - M of history, M TP of the tile, M of overhang)
+    static constexpr int Q = NB / M;                  // entries per phase
+    static constexpr int PSR = 16 / M;
+    static constexpr int PS = ((Q - PSR + 15) / 16) * 16 + PSR;
+    static constexpr int HIST = 64;                   // input samples of history kept per channel (64 - M are used)
+};
+
+template <int M, typename InT>
+__global__ __launch_bounds__(256) void k_predecim(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
+                                                  float2* __restrict__ tail_out, float2* __restrict__ fm_in, FrontTaps taps) {
+    using G = PredecimGeom<M>;
+    constexpr int TP = G::TP, NJ = G::NJ, NB = G::NB, PS = G::PS;
+    __shared__ __attribute__((aligned(16))) float2 ph[M * PS];
+    const int tiles = d.n_fm_in / TP;
+    const int c = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int n0 = tile * TP, tid = threadIdx.x;
+    const long g_lo = (long)M * n0 + M - 64;          // first input sample of the tile's first output (block relative)
+    const InT* in_c = in + (size_t)c * d.N;
+    const float2* tail_c = tail_in + (size_t)c * G::HIST;
+    {
+        constexpr int ITEMS = NB / 2, PER = (ITEMS + 255) / 256;   // items of 2 consecutive samples (g_lo is even)
+        float4 buf[PER];
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int j = tid + 256 * r;
+            if (j < ITEMS) {
+                long g = g_lo + 2 * j;
+                g = g < d.N - 2 ? g : d.N - 2;                       // the last tile's overhang: read, never used
+                buf[r] = (g < 0) ? *reinterpret_cast<const float4*>(tail_c + (G::HIST + g)) : load_iq2(in_c, (size_t)g);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int j = tid + 256 * r;
+            if (j < ITEMS) {
+                const int i0 = 2 * j, i1 = 2 * j + 1;
+                ph[(i0 % M) * PS + (i0 / M)] = make_float2(buf[r].x, buf[r].y);
+                ph[(i1 % M) * PS + (i1 / M)] = make_float2(buf[r].z, buf[r].w);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        // two consecutive outputs per thread from one sliding window per phase (see k_front); lane (n & 3) sums taps n in
+        // increasing n, then (l0+l2)+(l1+l3)
+        constexpr int NV = (NJ + 2) / 2;
+        const int il = 2 * tid;
+        float ar[2][4], ai[2][4];
+#pragma unroll
+        for (int v = 0; v < 2; v++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) { ar[v][q] = 0.f; ai[v][q] = 0.f; }
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            float2 w[M / 4][2 * NV];
+#pragma unroll
+            for (int h = 0; h < M / 4; h++) {
+                const float4* src = reinterpret_cast<const float4*>(ph + (p + 4 * h) * PS + il);
+#pragma unroll
+                for (int k = 0; k < NV; k++) { const float4 t = src[k]; w[h][2 * k] = make_float2(t.x, t.y); w[h][2 * k + 1] = make_float2(t.z, t.w); }
+            }
+#pragma unroll
+            for (int jj = 0; jj < NJ; jj++) {
+#pragma unroll
+                for (int h = 0; h < M / 4; h++) {
+                    const float b = taps.b_fm_in[M * jj + p + 4 * h];
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        ar[v][p] = fmaf(w[h][jj + v].x, b, ar[v][p]);
+                        ai[v][p] = fmaf(w[h][jj + v].y, b, ai[v][p]);
+                    }
+                }
+            }
+        }
+        float4 o;
+        o.x = (ar[0][0] + ar[0][2]) + (ar[0][1] + ar[0][3]); o.y = (ai[0][0] + ai[0][2]) + (ai[0][1] + ai[0][3]);
+        o.z = (ar[1][0] + ar[1][2]) + (ar[1][1] + ar[1][3]); o.w = (ai[1][0] + ai[1][2]) + (ai[1][1] + ai[1][3]);
+        *reinterpret_cast<float4*>(fm_in + (size_t)c * d.n_fm_in + n0 + il) = o;
+    }
+    // the last 64 input samples of the block are the next block's history
+    if (tile == tiles - 1 && tid < G::HIST) tail_out[(size_t)c * G::HIST + tid] = load_iq(in_c, (size_t)(d.N - G::HIST + tid));
+}
+
+// =============================================================================================
 // Lane-per-channel serial kernels.  A wavefront owns 64 adjacent channels; time runs in chunks of
 // 32 samples that are loaded row-wise (coalesced, 16 B per lane) and transposed through LDS so each
 // lane then walks its own channel.  The next chunk's global loads are in flight while the current
@@ -1570,14 +1668,27 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
     return hipGetLastError();
 }
 
+template <int M, typename InT>
+static hipError_t launch_front_two_kernels(const LaunchCtx& ctx, SlotRef r, const InT* d_iq, hipStream_t s) {
+    const Dims& d = ctx.d;
+    using G = PredecimGeom<M>;
+    FMD_LAUNCH(r, true, false, (k_predecim<M, InT>), dim3((unsigned)(d.n_fm_in / G::TP * d.C)), dim3(256), 0, s, d, d_iq, ctx.b.pre_tail[r.par], ctx.b.pre_tail[r.par ^ 1],
+               ctx.b.fm_in[r.buf], ctx.front);
+    // the rest of the front end sees a 256 kSa/s capture
+    LaunchCtx c1 = ctx;
+    c1.d.N = d.n_fm_in; c1.d.m = 1;
+    SlotRef r1 = r; r1.t0 = nullptr;
+    return launch_front<1, float2>(c1, r1, ctx.b.fm_in[r.buf], s);
+}
+
 hipError_t launch_stage_front(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s) {
     const int m = ctx.d.m;
     if (u8) {
         const uchar2* p = static_cast<const uchar2*>(d_iq);
-        return m == 1 ? launch_front<1, uchar2>(ctx, r, p, s) : (m == 4 ? launch_front<4, uchar2>(ctx, r, p, s) : launch_front<8, uchar2>(ctx, r, p, s));
+        return m == 1 ? launch_front<1, uchar2>(ctx, r, p, s) : (m == 4 ? launch_front_two_kernels<4, uchar2>(ctx, r, p, s) : launch_front_two_kernels<8, uchar2>(ctx, r, p, s));
     }
     const float2* p = static_cast<const float2*>(d_iq);
-    return m == 1 ? launch_front<1, float2>(ctx, r, p, s) : (m == 4 ? launch_front<4, float2>(ctx, r, p, s) : launch_front<8, float2>(ctx, r, p, s));
+    return m == 1 ? launch_front<1, float2>(ctx, r, p, s) : (m == 4 ? launch_front_two_kernels<4, float2>(ctx, r, p, s) : launch_front_two_kernels<8, float2>(ctx, r, p, s));
 }
 
 static unsigned serial_waves(const Dims& d) { return (unsigned)((d.C + kWave - 1) / kWave); }
@@ -1664,7 +1775,7 @@ hipError_t prepare_kernels() {
     return hipSuccess;
 }
 
-int front_tail_len(int m) { return m == 1 ? FrontGeom<1>::TAIL : (m == 4 ? FrontGeom<4>::TAIL : FrontGeom<8>::TAIL); }
+int front_tail_len(int m) { (void)m; return FrontGeom<1>::TAIL; }   // k_front always runs at 256 kSa/s; the first decimator keeps its own 64 samples
 
 hipError_t launch_reset_state(const LaunchCtx& ctx, hipStream_t stream) {
     hipLaunchKernelGGL(k_reset, dim3((unsigned)((ctx.d.C + 255) / 256)), dim3(256), 0, stream, ctx.d, ctx.b.state);

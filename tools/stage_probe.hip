@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
         hipMemcpy(in, h.data(), nin * 8, hipMemcpyHostToDevice);
     }
     for (int p = 0; p < 2; p++) {
-        b.base_tail[p] = dalloc<float2>((size_t)C * d.tail_base); b.iq_tail[p] = dalloc<float2>((size_t)C * 128); b.dt_tail[p] = dalloc<float>((size_t)C * 128);
+        b.base_tail[p] = dalloc<float2>((size_t)C * d.tail_base); b.pre_tail[p] = dalloc<float2>((size_t)C * 64); b.fm_in[p] = dalloc<float2>((size_t)C * d.n_fm_in); b.iq_tail[p] = dalloc<float2>((size_t)C * 128); b.dt_tail[p] = dalloc<float>((size_t)C * 128);
         b.fo_tail[p] = dalloc<float>((size_t)C * 64); b.fm_out_iq[p] = dalloc<float2>((size_t)C * d.n_fm_out); b.fm_out[p] = dalloc<float>((size_t)C * d.n_fm_out);
         b.pll_dt[p] = dalloc<float>((size_t)C * d.n_fm_out); b.audio[p] = dalloc<float>((size_t)C * d.n_audio * 2); b.rds_sym[p] = dalloc<float>((size_t)C * d.n_rds);
         b.rds_raw_sym[p] = dalloc<float2>(4); b.rds_count[p] = dalloc<int>(C); b.lpr[p] = dalloc<float>(4); b.lmr[p] = dalloc<float>(4);
