@@ -37,35 +37,30 @@ static constexpr int kWave = 64;
 __device__ __forceinline__ float& st(float* state, int field, int C, int c) { return state[(size_t)field * C + c]; }
 
 // =============================================================================================
-// k_front — reference Run_FM_Demodulate (broadcast_fm_demod.cpp:391-416) without the optional IIR:
-//   PolyphaseDownsampler<cf32> M x 64 taps (polyphase_filter.h:41-64, c32_f32_cum_mul.cpp:70-111)
+// k_front — reference Run_FM_Demodulate (broadcast_fm_demod.cpp:391-416) without the optional IIR, from the 256 kSa/s stream
+// fm_in on (the capture itself at 256 kSa/s, k_predecim's output at 1.024 / 2.048 MSa/s):
 //   FM_Demod::Process (fm_demod.cpp:30-45)
 //   PolyphaseDownsampler<float> 2 x 64 taps (f32_cum_mul.cpp:52-78)
 //   Hilbert_FIR_Filter<float> 65 taps (hilbert_fir_filter.h:26-46), 33 zero taps skipped
-// One workgroup = one channel x T output samples (128 kHz).  The halo each stage needs is
-// recomputed from `tail ++ block` so tiles are independent; the baseband tile is staged in LDS
-// split into M decimation phases, which makes every FIR read unit-stride across lanes.
+// One workgroup = one channel x T output samples (128 kHz).  The halo each stage needs is recomputed from `tail ++ block`
+// so tiles are independent.
 // =============================================================================================
-// TT: fm_out samples per workgroup.  A larger tile recomputes less halo (the 191-sample halo of the three cascaded FIRs costs
-// 19 % extra discriminator work at 512, 9 % at 1024); 1024 is used at 256 kSa/s whenever the block length allows it.
-template <int M, int TT = (M == 8) ? 256 : 512>
+// TT: fm_out samples per workgroup.  A larger tile recomputes less halo (the 191-sample halo of the three cascaded stages costs
+// 19 % extra discriminator work at 512, 9 % at 1024); 1024 is used whenever the block length allows it.
+template <int TT = 512>
 struct FrontGeom {
     static constexpr int T = TT;
     static constexpr int NW = 2 * T + 191;                               // fm_in samples (incl. one for prev_theta)
-    static constexpr int TAIL = (M == 1) ? 191 : (190 * M + 64);         // history samples of the input stream
-    static constexpr int NB = (M == 1) ? NW : (2 * M * T + TAIL);        // input samples staged per tile
-    static constexpr int Q = (M == 1) ? 0 : (NB / M);                    // entries per phase
-    static constexpr int PSR = (M == 1) ? 0 : (16 / M);                  // wanted residue of the phase stride mod 16
-    static constexpr int PS = (M == 1) ? 0 : (((Q - PSR + 15) / 16) * 16 + PSR);
+    static constexpr int TAIL = 191;                                     // history samples of the input stream
     // LDS carve-up in floats; every sub-array starts on a 16-byte boundary (a ds_read_b64 that is only 4-byte
     // aligned is replayed at ~64 cycles per wave instruction)
     static constexpr int NWP = (NW + 3) & ~3;
-    static constexpr int OFF_THETA = 2 * M * PS * (M > 1);
+    static constexpr int OFF_THETA = 0;
     static constexpr int OFF_DEM = OFF_THETA + NWP;
     static constexpr int OFF_FO = OFF_DEM + NWP;
     static constexpr int OFF_ATAN = (OFF_FO + (T + 64) + 7) & ~7;        // AtanTable (32-byte aligned rows)
     static constexpr int LDS_FLOATS = OFF_ATAN + kAtanTableWords;
-    static_assert(OFF_THETA % 4 == 0 && OFF_DEM % 4 == 0 && OFF_FO % 4 == 0, "LDS sub-arrays must be 16-byte aligned");
+    static_assert(OFF_DEM % 4 == 0 && OFF_FO % 4 == 0, "LDS sub-arrays must be 16-byte aligned");
 };
 
 __device__ __forceinline__ float2 load_iq(const float2* p, size_t i) { return p[i]; }
@@ -81,20 +76,18 @@ __device__ __forceinline__ float4 load_iq2(const uchar2* p, size_t i) {
     return make_float4((float)v.x - 127.0f, (float)v.y - 127.0f, (float)v.z - 127.0f, (float)v.w - 127.0f);
 }
 
-template <int M, typename InT, int TT = (M == 8) ? 256 : 512>
+template <typename InT, int TT = 512>
 __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
                                                float2* __restrict__ tail_out, float2* __restrict__ fm_out_iq,
                                                float* __restrict__ fm_out_plain, float* __restrict__ fo_tail_out, FrontTaps taps,
                                                int deemph_path) {
-    using G = FrontGeom<M, TT>;
-    constexpr int T = G::T, NW = G::NW, NB = G::NB, PS = G::PS;
+    using G = FrontGeom<TT>;
+    constexpr int T = G::T, NW = G::NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float2* ph = reinterpret_cast<float2*>(smem);                 // [M][PS]
     float* theta = smem + G::OFF_THETA;                           // [NW]
     float* dem = smem + G::OFF_DEM;                               // [NW-1]
     float* fo = smem + G::OFF_FO;                                 // [T+64]
     AtanTable* atab = reinterpret_cast<AtanTable*>(smem + G::OFF_ATAN);
-    (void)ph;
     atan_table_fill(atab, threadIdx.x, 256);                      // visible after the first barrier below
 
     const int tiles = d.n_fm_out / T;
@@ -102,111 +95,13 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
     const int tile = blockIdx.x % tiles;
     const int o0 = tile * T;
     const int tid = threadIdx.x;
-    const long g_lo = (long)2 * M * o0 - G::TAIL;                 // first input index of the tile (block relative)
+    const long g_lo = (long)2 * o0 - G::TAIL;                     // first input index of the tile (block relative)
     const InT* in_c = in + (size_t)c * d.N;
     const float2* tail_c = tail_in + (size_t)c * G::TAIL;
 
     // Input staging: every thread first issues ALL of its global loads (independent, 16 B per lane for cf32), then
     // consumes them — the memory-level parallelism is what keeps this kernel off the HBM-latency floor.
-    if constexpr (M > 1) {
-        constexpr int ITEMS = NB / 2;                       // items of 2 consecutive samples (g_lo and TAIL are even)
-        constexpr int PER = (ITEMS + 255) / 256;
-        float4 buf[PER];
-        if (sizeof(InT) == 2 && tile != 0) {
-            // u8 IQ: 16 bytes = 8 samples per lane and load (the 4-byte loads of the generic path move a quarter of a cache
-            // line per wavefront instruction); NB, TAIL and g_lo are multiples of 8
-            static_assert(NB % 8 == 0 && G::TAIL % 8 == 0, "u8 staging in items of 8 samples");
-            constexpr int ITEMS8 = NB / 8, PER8 = (ITEMS8 + 255) / 256;
-            uint4 raw[PER8];
-#pragma unroll
-            for (int r = 0; r < PER8; r++) {
-                const int j = tid + 256 * r;
-                if (j < ITEMS8) raw[r] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(in_c) + 2 * (g_lo + 8 * (long)j));
-            }
-#pragma unroll
-            for (int r = 0; r < PER8; r++) {
-                const int j = tid + 256 * r;
-                if (j < ITEMS8) {
-                    const unsigned int wds[4] = {raw[r].x, raw[r].y, raw[r].z, raw[r].w};
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const unsigned int h = wds[e >> 1] >> (16 * (e & 1));
-                        const int i = 8 * j + e;
-                        ph[(i % M) * PS + (i / M)] = make_float2((float)(h & 0xffu) - 127.0f, (float)((h >> 8) & 0xffu) - 127.0f);
-                    }
-                }
-            }
-        } else {
-        if (tile != 0) {
-#pragma unroll
-            for (int r = 0; r < PER; r++) {
-                const int j = tid + 256 * r;
-                if (j < ITEMS) buf[r] = load_iq2(in_c, (size_t)(g_lo + 2 * j));
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < PER; r++) {
-                const int j = tid + 256 * r;
-                if (j < ITEMS) {
-                    const long g = g_lo + 2 * j;
-                    buf[r] = (g < 0) ? *reinterpret_cast<const float4*>(tail_c + (G::TAIL + g)) : load_iq2(in_c, (size_t)g);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < PER; r++) {
-            const int j = tid + 256 * r;
-            if (j < ITEMS) {
-                const int i0 = 2 * j, i1 = 2 * j + 1;
-                ph[(i0 % M) * PS + (i0 / M)] = make_float2(buf[r].x, buf[r].y);
-                ph[(i1 % M) * PS + (i1 / M)] = make_float2(buf[r].z, buf[r].w);
-            }
-        }
-        }
-        __syncthreads();
-        // a1 + a2: fm_in[w] then theta[w] = atan2(Q, I).  Every thread makes TWO consecutive outputs from one sliding
-        // window per phase (ds_read_b128 = two samples, lane stride 16 B: conflict-free): an LDS byte feeds two FMAs and
-        // the loop is bound by the VALU, not by one ds_read_b64 per complex tap.  Accumulation order per output as in
-        // c32_f32_cum_mul_avx: lane (n & 3) sums taps n in increasing n, then (l0+l2)+(l1+l3).
-        constexpr int NJ = 64 / M;                 // taps per phase
-        constexpr int NV = (NJ + 2) / 2;           // float4 loads covering the NJ + 1 samples of a two-output window
-        for (int i = 2 * tid; i < NW; i += 512) {
-            float ar[2][4], ai[2][4];
-#pragma unroll
-            for (int v = 0; v < 2; v++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) { ar[v][q] = 0.f; ai[v][q] = 0.f; }
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                // phases p (and p + 4 at M = 8) feed accumulator lane p, alternating in tap order
-                float2 w[M / 4][2 * NV];
-#pragma unroll
-                for (int h = 0; h < M / 4; h++) {
-                    const float4* src = reinterpret_cast<const float4*>(ph + (p + 4 * h) * PS + i);
-#pragma unroll
-                    for (int k = 0; k < NV; k++) { const float4 t = src[k]; w[h][2 * k] = make_float2(t.x, t.y); w[h][2 * k + 1] = make_float2(t.z, t.w); }
-                }
-#pragma unroll
-                for (int jj = 0; jj < NJ; jj++) {
-#pragma unroll
-                    for (int h = 0; h < M / 4; h++) {
-                        const float b = taps.b_fm_in[M * jj + p + 4 * h];
-#pragma unroll
-                        for (int v = 0; v < 2; v++) {
-                            ar[v][p] = fmaf(w[h][jj + v].x, b, ar[v][p]);
-                            ai[v][p] = fmaf(w[h][jj + v].y, b, ai[v][p]);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int v = 0; v < 2; v++) {
-                const float re = (ar[v][0] + ar[v][2]) + (ar[v][1] + ar[v][3]);
-                const float im = (ai[v][0] + ai[v][2]) + (ai[v][1] + ai[v][3]);
-                if (i + v < NW) theta[i + v] = fmd_atan2f_table(im, re, atab);
-            }
-        }
-    } else {
+    {
         constexpr int PER = (NW + 255) / 256;
         float2 buf[PER];
 #pragma unroll
@@ -240,8 +135,6 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
     // samples read as 17 ds_read_b128 (16 B lane stride: conflict-free, full LDS rate): 136 B of LDS traffic per output instead
     // of 256 B — and left to one output per thread the compiler pairs the 32 ds_read_b64 into ds_read2_b64, which move only
     // 128 B/clk.  This loop is the kernel's LDS hot spot.
-    // (The 256-output tiles of the ÷8 front end keep one output per thread: 160 pairs leave a quarter of the workgroup idle, 9 % slower.)
-    if constexpr (T >= 512) {
     for (int pp = tid; 2 * pp < T + 64; pp += 256) {
         const int uu = 2 * pp;
         float w[68];
@@ -259,22 +152,6 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
         }
         *reinterpret_cast<float2*>(fo + uu) = make_float2(y[0], y[1]);
         if (deemph_path && uu >= 64) *reinterpret_cast<float2*>(fm_out_plain + (size_t)c * d.n_fm_out + o0 + (uu - 64)) = make_float2(y[0], y[1]);
-    }
-    } else {
-    for (int uu = tid; uu < T + 64; uu += 256) {
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float2* w2 = reinterpret_cast<const float2*>(dem + 2 * uu);
-#pragma unroll
-        for (int n = 0; n < 64; n += 2) {
-            const float2 v = w2[n / 2];
-            acc[n & 7] = fmaf(v.x, taps.b_fm_out[n], acc[n & 7]);
-            acc[(n + 1) & 7] = fmaf(v.y, taps.b_fm_out[n + 1], acc[(n + 1) & 7]);
-        }
-        const float a0 = acc[0] + acc[4], a1 = acc[1] + acc[5], a2 = acc[2] + acc[6], a3 = acc[3] + acc[7];
-        const float y = (a0 + a2) + (a1 + a3);
-        fo[uu] = y;
-        if (deemph_path && uu >= 64) fm_out_plain[(size_t)c * d.n_fm_out + o0 + (uu - 64)] = y;
-    }
     }
     __syncthreads();
     // a5: Hilbert FIR; only lanes 1,3,5,7 of the reference's 8-lane accumulator see non-zero taps
@@ -304,8 +181,8 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
 // =============================================================================================
 // k_predecim — the first decimator on its own at 1.024 / 2.048 MSa/s: PolyphaseDownsampler<cf32> M x 64 taps
 // (polyphase_filter.h:41-64, c32_f32_cum_mul.cpp:70-111) from baseband (cf32 or u8, reference src/app.cpp:56-62) to the
-// 256 kSa/s stream fm_in, which k_front<1> then takes exactly as it takes a 256 kSa/s capture.
-// Fused into one kernel with the discriminator (k_front<4>, k_front<8>) the decimator had to be recomputed over the 191-sample
+// 256 kSa/s stream fm_in, which k_front then takes exactly as it takes a 256 kSa/s capture.
+// Fused into one kernel with the discriminator (as it was at first) the decimator had to be recomputed over the 191-sample
 // halo of the FIRs behind it (+19 % of the dominant work at 512-output tiles, which is all its 52 KB of LDS allowed); on its own
 // the halo is 64 - M input samples per 512 outputs, every lane is busy in the one pair-blocked pass, and the back half runs
 // on the 1024-output tiles of the 256 kSa/s path.  fm_in costs 16 B per 256 kSa/s sample of extra HBM traffic (written once,
@@ -1653,16 +1530,16 @@ __global__ void k_reset(Dims d, float* __restrict__ state) {
 // ---------------------------------------------------------------------------------------------
 // host-side stage launchers
 // ---------------------------------------------------------------------------------------------
-template <int M, typename InT, int TT = (M == 8) ? 256 : 512>
+template <typename InT, int TT = 512>
 static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq, hipStream_t s) {
-    using G = FrontGeom<M, TT>;
+    using G = FrontGeom<TT>;
     const Dims& d = ctx.d;
-    if constexpr (M == 1 && TT == 512) {
-        if (d.n_fm_out % 1024 == 0) return launch_front<1, InT, 1024>(ctx, r, d_iq, s);
+    if constexpr (TT == 512) {
+        if (d.n_fm_out % 1024 == 0) return launch_front<InT, 1024>(ctx, r, d_iq, s);
     }
     const int tiles = d.n_fm_out / G::T;
     const size_t lds = sizeof(float) * G::LDS_FLOATS;
-    auto kern = k_front<M, InT, TT>;
+    auto kern = k_front<InT, TT>;
     FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), lds, s, d, d_iq, ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1],
                        ctx.b.fm_out_iq[r.buf], ctx.b.fm_out[r.buf], ctx.b.fo_tail[r.par ^ 1], ctx.front, ctx.any_deemph);
     return hipGetLastError();
@@ -1678,17 +1555,17 @@ static hipError_t launch_front_two_kernels(const LaunchCtx& ctx, SlotRef r, cons
     LaunchCtx c1 = ctx;
     c1.d.N = d.n_fm_in; c1.d.m = 1;
     SlotRef r1 = r; r1.t0 = nullptr;
-    return launch_front<1, float2>(c1, r1, ctx.b.fm_in[r.buf], s);
+    return launch_front<float2>(c1, r1, ctx.b.fm_in[r.buf], s);
 }
 
 hipError_t launch_stage_front(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s) {
     const int m = ctx.d.m;
     if (u8) {
         const uchar2* p = static_cast<const uchar2*>(d_iq);
-        return m == 1 ? launch_front<1, uchar2>(ctx, r, p, s) : (m == 4 ? launch_front_two_kernels<4, uchar2>(ctx, r, p, s) : launch_front_two_kernels<8, uchar2>(ctx, r, p, s));
+        return m == 1 ? launch_front<uchar2>(ctx, r, p, s) : (m == 4 ? launch_front_two_kernels<4, uchar2>(ctx, r, p, s) : launch_front_two_kernels<8, uchar2>(ctx, r, p, s));
     }
     const float2* p = static_cast<const float2*>(d_iq);
-    return m == 1 ? launch_front<1, float2>(ctx, r, p, s) : (m == 4 ? launch_front_two_kernels<4, float2>(ctx, r, p, s) : launch_front_two_kernels<8, float2>(ctx, r, p, s));
+    return m == 1 ? launch_front<float2>(ctx, r, p, s) : (m == 4 ? launch_front_two_kernels<4, float2>(ctx, r, p, s) : launch_front_two_kernels<8, float2>(ctx, r, p, s));
 }
 
 static unsigned serial_waves(const Dims& d) { return (unsigned)((d.C + kWave - 1) / kWave); }
@@ -1756,26 +1633,22 @@ hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int M, typename InT, int TT = (M == 8) ? 256 : 512>
+template <typename InT, int TT = 512>
 static hipError_t prepare_front() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_front<M, InT, TT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(sizeof(float) * FrontGeom<M, TT>::LDS_FLOATS));
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_front<InT, TT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(sizeof(float) * FrontGeom<TT>::LDS_FLOATS));
 }
 
 hipError_t prepare_kernels() {
     hipError_t e;
-    if ((e = prepare_front<1, float2>()) != hipSuccess) return e;
-    if ((e = prepare_front<4, float2>()) != hipSuccess) return e;
-    if ((e = prepare_front<8, float2>()) != hipSuccess) return e;
-    if ((e = prepare_front<1, float2, 1024>()) != hipSuccess) return e;
-    if ((e = prepare_front<1, uchar2, 1024>()) != hipSuccess) return e;
-    if ((e = prepare_front<1, uchar2>()) != hipSuccess) return e;
-    if ((e = prepare_front<4, uchar2>()) != hipSuccess) return e;
-    if ((e = prepare_front<8, uchar2>()) != hipSuccess) return e;
+    if ((e = prepare_front<float2>()) != hipSuccess) return e;
+    if ((e = prepare_front<float2, 1024>()) != hipSuccess) return e;
+    if ((e = prepare_front<uchar2>()) != hipSuccess) return e;
+    if ((e = prepare_front<uchar2, 1024>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
-int front_tail_len(int m) { (void)m; return FrontGeom<1>::TAIL; }   // k_front always runs at 256 kSa/s; the first decimator keeps its own 64 samples
+int front_tail_len(int m) { (void)m; return FrontGeom<>::TAIL; }   // k_front always runs at 256 kSa/s; the first decimator keeps its own 64 samples
 
 hipError_t launch_reset_state(const LaunchCtx& ctx, hipStream_t stream) {
     hipLaunchKernelGGL(k_reset, dim3((unsigned)((ctx.d.C + 255) / 256)), dim3(256), 0, stream, ctx.d, ctx.b.state);
