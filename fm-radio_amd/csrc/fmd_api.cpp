@@ -443,8 +443,8 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     if (!rc) rc = dev_alloc(h, &b.state, (size_t)S_NUM_FIELDS * C);
     if (!rc) rc = dev_alloc(h, &b.spec_stats, 8);
     // per-wavefront hand-over between consecutive k_pilot_pll launches: the time-parallel kernel only, pipelined mode only
-    h->pll_chained = h->pipelined && d.C * d.m <= 3328 && !(cfg->flags & FMD_FLAG_PLL_STREAM_ORDER);
-    h->pll_waves = (d.C * d.m <= h->ctx.pll_k16_max_channels) ? (d.C + 3) / 4 : (d.C + 7) / 8;
+    h->pll_chained = h->pipelined && effective_channels(d) <= 3328 && !(cfg->flags & FMD_FLAG_PLL_STREAM_ORDER);
+    h->pll_waves = (effective_channels(d) <= h->ctx.pll_k16_max_channels) ? (d.C + 3) / 4 : (d.C + 7) / 8;
     if (!rc) rc = dev_alloc(h, &b.pll_chain, (size_t)h->pll_waves + 1);
     if (rc) return bail(rc);
     rc = zero_history(h, h->own_stream);

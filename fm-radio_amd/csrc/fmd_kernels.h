@@ -103,6 +103,10 @@ struct Buffers {
     unsigned long long* spec_stats;  // [8] speculation counters: pll {chunks, general, replayed, -}, rds {chunks, general, replayed, -}
 };
 
+// Batch size the latency/throughput switches are keyed on: the stages behind the first decimator cost the same at every input
+// rate; the decimator itself (m > 1) adds FIR work and HBM traffic that compete with the serial kernels (measured cross-overs: x 1.5).
+inline int effective_channels(const Dims& d) { return d.m == 1 ? d.C : d.C + d.C / 2; }
+
 struct LaunchCtx {
     Dims d;
     Buffers b;

@@ -1581,7 +1581,7 @@ hipError_t launch_stage_deemph(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
 
 hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
-    if (d.C * d.m <= 2816) {   // the batches whose step is this kernel's latency (and whose PLL launches hand over per wavefront)
+    if (effective_channels(d) <= 2816) {   // the batches whose step is this kernel's latency (and whose PLL launches hand over per wavefront)
         FMD_LAUNCH(r, true, true, k_pilot_power<true>, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[r.buf], ctx.b.pilot[r.buf], ctx.b.state,
                    ctx.loops, (int)S_PILOT_POWER0 + r.buf);
     } else {
@@ -1599,7 +1599,7 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
         return hipGetLastError();
     }
     unsigned int* chain = r.seq ? ctx.b.pll_chain : nullptr;
-    if (d.C * d.m <= ctx.pll_k16_max_channels) {
+    if (effective_channels(d) <= ctx.pll_k16_max_channels) {
         FMD_LAUNCH(r, true, true, k_pilot_pll<16>, dim3((unsigned)((d.C + 3) / 4)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
                    ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats, chain, r.seq);
     } else {
