@@ -558,7 +558,7 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
     // packet, no kernel boundary and no launch ramp between the two ends of the serial chain any more.  The predecessor was
     // submitted earlier and never waits on anything later, and 2 x 512 such workgroups cannot fill the chip, so the wait
     // cannot deadlock; a 2 s watchdog turns a lost predecessor (a failed launch) into an error flag instead of a hang.
-    // Used for batches up to 3328 stations x m (fmd_api.cpp): beyond, two launches' workgroups resident at once take more
+    // Used for effective batches up to 3328 stations (fmd_api.cpp, effective_channels): beyond, two launches' workgroups resident at once take more
     // from the FIR kernels than the hand-over gap gives back (same-box A/B: -13 % at 1024 stations, -7 % at 3072, +4 % at 4096).
     if (chain) {
         const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
