@@ -22,8 +22,8 @@ using namespace fmd;
 // Stage placement: k_front on sF, k_pilot_power on sA, k_pilot_pll on sB, k_extract (+ k_lmr_phase) on sX, k_rds_sync on sR.
 // Blocks rotate through kSlots buffer slots and every stage waits only for its producer (HIP events), so in steady state
 // all stages run concurrently on different blocks.
-enum Stage { ST_FRONT = 0, ST_DEEMPH, ST_POWER, ST_PLL, ST_EXTRACT, ST_RDS, ST_COUNT };
-static const char* const kStageName[ST_COUNT] = {"k_front", "k_deemphasis+k_hilbert", "k_pilot_power", "k_pilot_pll", "k_extract", "k_rds_sync"};
+enum Stage { ST_FRONT = 0, ST_DEEMPH, ST_POWER, ST_PLL, ST_EXTRACT, ST_RDS, ST_PREDECIM, ST_COUNT };
+static const char* const kStageName[ST_COUNT] = {"k_front", "k_deemphasis+k_hilbert", "k_pilot_power", "k_pilot_pll", "k_extract", "k_rds_sync", "k_predecim"};
 
 struct ProfiledBlock { hipEvent_t t0[ST_COUNT], t1[ST_COUNT]; bool used[ST_COUNT]; };
 
@@ -45,7 +45,7 @@ struct fmd_handle_s {
     unsigned pll_seq = 0;                    // k_pilot_pll launches handed over per wavefront so far (0: hand-over by stream order)
     bool pll_chained = false;
     int pll_waves = 0;
-    hipEvent_t ev_in = nullptr, ev_F[kSlots] = {}, ev_A[kSlots] = {}, ev_B[kSlots] = {}, ev_E[kSlots] = {}, ev_X[kSlots] = {};
+    hipEvent_t ev_in = nullptr, ev_P[kSlots] = {}, ev_F[kSlots] = {}, ev_A[kSlots] = {}, ev_B[kSlots] = {}, ev_E[kSlots] = {}, ev_X[kSlots] = {};
     bool slot_used[kSlots] = {};
     bool pipelined = true;
     long n_blocks = 0;                       // blocks submitted since create/reset; slot = n_blocks % kSlots
@@ -236,12 +236,30 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         return fn(h->ctx, r, on);
     };
     hipError_t e = hipSuccess;
+    // The first decimator (1.024 / 2.048 MSa/s) gets a stream of its own when the PLL launches do not need own_stream: it then
+    // works on block b+1 while k_front works on block b (back to back on one stream the two were the longest stage)
+    const bool predecim = h->ctx.d.m > 1;
+    hipStream_t sP = (pipe && predecim && !chained) ? h->own_stream : sF;
+    hipStream_t s_first = predecim ? sP : sF;      // the stream of the stage that reads the caller's input
     if (pipe) {
         // input is ready once everything queued so far on the caller's stream has run
         HIP_TRY(h, hipEventRecord(h->ev_in, s));
-        HIP_TRY(h, hipStreamWaitEvent(sF, h->ev_in, 0));
-        // WAR: this slot's fm_out_iq / pilot / pll_dt were last read by the stages of the block kSlots blocks ago
-        if (h->slot_used[slot]) HIP_TRY(h, hipStreamWaitEvent(sF, h->ev_X[slot], 0));
+        HIP_TRY(h, hipStreamWaitEvent(s_first, h->ev_in, 0));
+        // WAR: this slot's fm_in / fm_out_iq / pilot / pll_dt were last read by the stages of the block kSlots blocks ago
+        if (h->slot_used[slot]) {
+            HIP_TRY(h, hipStreamWaitEvent(sF, h->ev_X[slot], 0));
+            if (sP != sF) HIP_TRY(h, hipStreamWaitEvent(sP, h->ev_X[slot], 0));
+        }
+    }
+    hipEvent_t input_done = nullptr;               // fires when the caller's buffer has been consumed
+    if (predecim) {
+        SlotRef r = ref;
+        if (pm && prof_stage(ST_PREDECIM)) { r.t0 = pm->t0[ST_PREDECIM]; r.t1 = pm->t1[ST_PREDECIM]; pm->used[ST_PREDECIM] = true; }
+        if (pipe && !r.t1) r.done = h->ev_P[slot];
+        input_done = r.t1 ? r.t1 : h->ev_P[slot];
+        e = launch_stage_predecim(h->ctx, r, d_iq, u8, sP);
+        if (e != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_predecim launch: %s", hipGetErrorString(e));
+        if (pipe && sP != sF) HIP_TRY(h, hipStreamWaitEvent(sF, input_done, 0));
     }
     {
         SlotRef r = ref;
@@ -254,7 +272,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     if (h->ctx.any_deemph && (e = run(ST_DEEMPH, sF, launch_stage_deemph, h->ev_F[slot])) != hipSuccess)
         return fail(h, FMD_ERR_DEVICE, "de-emphasis launch: %s", hipGetErrorString(e));
     if (pipe) {
-        HIP_TRY(h, hipStreamWaitEvent(s, dep, 0));     // the caller may reuse `iq` in stream order after this call
+        HIP_TRY(h, hipStreamWaitEvent(s, input_done ? input_done : dep, 0));   // the caller may reuse `iq` in stream order after this call
         HIP_TRY(h, hipStreamWaitEvent(sA, dep, 0));
     }
     if ((e = run(ST_POWER, sA, launch_stage_power, h->ev_A[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_pilot_power launch: %s", hipGetErrorString(e));
@@ -381,7 +399,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     }
     {
         std::vector<hipEvent_t*> evs = {&h->ev_in};
-        for (int i = 0; i < kSlots; i++) { evs.push_back(&h->ev_F[i]); evs.push_back(&h->ev_A[i]); evs.push_back(&h->ev_B[i]); evs.push_back(&h->ev_E[i]); evs.push_back(&h->ev_X[i]); }
+        for (int i = 0; i < kSlots; i++) { evs.push_back(&h->ev_P[i]); evs.push_back(&h->ev_F[i]); evs.push_back(&h->ev_A[i]); evs.push_back(&h->ev_B[i]); evs.push_back(&h->ev_E[i]); evs.push_back(&h->ev_X[i]); }
         for (hipEvent_t* ev : evs) {
             hipError_t e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
             if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "event: %s", hipGetErrorString(e)));
@@ -463,7 +481,7 @@ int fmd_destroy(fmd_handle h) {
     for (hipStream_t st : {h->sF, h->sA, h->sB, h->sX, h->sR}) if (st) (void)hipStreamDestroy(st);
     {
         std::vector<hipEvent_t> evs = {h->ev_in};
-        for (int i = 0; i < kSlots; i++) { evs.push_back(h->ev_F[i]); evs.push_back(h->ev_A[i]); evs.push_back(h->ev_B[i]); evs.push_back(h->ev_E[i]); evs.push_back(h->ev_X[i]); }
+        for (int i = 0; i < kSlots; i++) { evs.push_back(h->ev_P[i]); evs.push_back(h->ev_F[i]); evs.push_back(h->ev_A[i]); evs.push_back(h->ev_B[i]); evs.push_back(h->ev_E[i]); evs.push_back(h->ev_X[i]); }
         for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     }
     for (void* p : h->allocs) (void)hipFree(p);

@@ -122,6 +122,7 @@ struct LaunchCtx {
 
 // One launcher per pipeline stage of one block.  The host (fmd_api.cpp) places the stages on
 // streams and orders them with events.
+hipError_t launch_stage_predecim(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s);   // k_predecim (m > 1)
 hipError_t launch_stage_front(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s);   // k_front
 hipError_t launch_stage_deemph(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                            // k_deemphasis + k_hilbert
 hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                             // k_pilot_power

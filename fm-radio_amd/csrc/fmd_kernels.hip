@@ -1546,26 +1546,34 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
 }
 
 template <int M, typename InT>
-static hipError_t launch_front_two_kernels(const LaunchCtx& ctx, SlotRef r, const InT* d_iq, hipStream_t s) {
+static hipError_t launch_predecim(const LaunchCtx& ctx, SlotRef r, const InT* d_iq, hipStream_t s) {
     const Dims& d = ctx.d;
     using G = PredecimGeom<M>;
-    FMD_LAUNCH(r, true, false, (k_predecim<M, InT>), dim3((unsigned)(d.n_fm_in / G::TP * d.C)), dim3(256), 0, s, d, d_iq, ctx.b.pre_tail[r.par], ctx.b.pre_tail[r.par ^ 1],
+    FMD_LAUNCH(r, true, true, (k_predecim<M, InT>), dim3((unsigned)(d.n_fm_in / G::TP * d.C)), dim3(256), 0, s, d, d_iq, ctx.b.pre_tail[r.par], ctx.b.pre_tail[r.par ^ 1],
                ctx.b.fm_in[r.buf], ctx.front);
-    // the rest of the front end sees a 256 kSa/s capture
-    LaunchCtx c1 = ctx;
-    c1.d.N = d.n_fm_in; c1.d.m = 1;
-    SlotRef r1 = r; r1.t0 = nullptr;
-    return launch_front<float2>(c1, r1, ctx.b.fm_in[r.buf], s);
+    return hipGetLastError();
 }
 
-hipError_t launch_stage_front(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s) {
+// the first decimator (m > 1 only): baseband -> fm_in[slot]
+hipError_t launch_stage_predecim(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s) {
     const int m = ctx.d.m;
     if (u8) {
         const uchar2* p = static_cast<const uchar2*>(d_iq);
-        return m == 1 ? launch_front<uchar2>(ctx, r, p, s) : (m == 4 ? launch_front_two_kernels<4, uchar2>(ctx, r, p, s) : launch_front_two_kernels<8, uchar2>(ctx, r, p, s));
+        return m == 4 ? launch_predecim<4, uchar2>(ctx, r, p, s) : launch_predecim<8, uchar2>(ctx, r, p, s);
     }
     const float2* p = static_cast<const float2*>(d_iq);
-    return m == 1 ? launch_front<float2>(ctx, r, p, s) : (m == 4 ? launch_front_two_kernels<4, float2>(ctx, r, p, s) : launch_front_two_kernels<8, float2>(ctx, r, p, s));
+    return m == 4 ? launch_predecim<4, float2>(ctx, r, p, s) : launch_predecim<8, float2>(ctx, r, p, s);
+}
+
+// k_front on the 256 kSa/s stream: the capture itself (m == 1) or fm_in[slot]
+hipError_t launch_stage_front(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s) {
+    if (ctx.d.m > 1) {
+        LaunchCtx c1 = ctx;
+        c1.d.N = ctx.d.n_fm_in; c1.d.m = 1;
+        return launch_front<float2>(c1, r, ctx.b.fm_in[r.buf], s);
+    }
+    if (u8) return launch_front<uchar2>(ctx, r, static_cast<const uchar2*>(d_iq), s);
+    return launch_front<float2>(ctx, r, static_cast<const float2*>(d_iq), s);
 }
 
 static unsigned serial_waves(const Dims& d) { return (unsigned)((d.C + kWave - 1) / kWave); }
