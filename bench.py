@@ -121,7 +121,7 @@ def bench_wideband(args, torch, pkg, device) -> dict:
         step(k)
     dm.synchronize(); torch.cuda.synchronize(device)
     dm.spec_stats(reset=True)
-    dm.profile(0 if args.no_kernel_times else 1)
+    dm.profile(0 if args.no_kernel_times else args.kernel_times_mode)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for k in range(P + W, P + W + K):
@@ -225,6 +225,9 @@ def main() -> None:
     ap.add_argument("--gather-format", default="pcm16", choices=["pcm16", "f32"],
                     help="payload of the audio collective: the 16-bit PCM frames the reference's scraper writes (default) or raw f32")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
+    ap.add_argument("--kernel-times-mode", type=int, default=3, choices=[1, 2, 3],
+                    help="1: HIP timing events on every kernel of every block (costs ~4 %% of the step); 3 (default): every kernel of "
+                         "every 4th block, plus the PLL kernel of the block behind it (for the hand-over gap)")
     ap.add_argument("--no-kernel-times", action="store_true", help="do not attach HIP timing events to the kernels of the timed region (no roofline object; ~2 %% faster)")
     ap.add_argument("--pll-kernel", default="auto", choices=["auto", "time_parallel", "time_parallel8", "low_work"],
                     help="force one of the pilot-PLL kernels (default: chosen by batch size; same results either way)")
@@ -307,7 +310,7 @@ def main() -> None:
     if world > 1:
         dist.barrier()
     dm.spec_stats(reset=True)
-    dm.profile(0 if args.no_kernel_times else 1)
+    dm.profile(0 if args.no_kernel_times else args.kernel_times_mode)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for k in range(P + W, P + W + K):

@@ -299,7 +299,8 @@ class BatchDemod:
         return out.reshape(self.n_channels, -1)
 
     def profile(self, on):
-        """False/0: off; True/1: bracket every kernel of every block; 2: the dominant kernel every block, the rest every 4th."""
+        """False/0: off; True/1: bracket every kernel of every block; 2: the dominant kernel every block, the rest every 4th;
+        3: every kernel of every 4th block, plus the dominant kernel of the block behind it."""
         self._check(self.L.fmd_profile_enable(self.h, int(on)))
 
     def spec_stats(self, reset: bool = False) -> dict:

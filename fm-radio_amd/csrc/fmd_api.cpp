@@ -223,7 +223,11 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     }
     // event bracketing perturbs the pipeline it measures (extra queue packets between dependent kernels): mode 2 keeps it
     // on the dominant kernel and samples the others
-    auto prof_stage = [&](int st) { return h->profiling == 1 || st == ST_PLL || (h->n_blocks & 3) == 0; };
+    // mode 3 samples: every stage of every 4th block, plus the PLL stage of the block behind it (for the hand-over gap)
+    auto prof_stage = [&](int st) {
+        if (h->profiling == 3) return (h->n_blocks & 3) == 0 || (st == ST_PLL && (h->n_blocks & 3) == 1);
+        return h->profiling == 1 || st == ST_PLL || (h->n_blocks & 3) == 0;
+    };
     // The event that orders the next stage behind this one rides on the stage's last dispatch packet (SlotRef::done).  A
     // stage that is being timed already carries its stop event there: the next stage then waits on that one (dep).
     hipEvent_t dep = nullptr;
@@ -697,7 +701,7 @@ int fmd_get_spec_stats(fmd_handle h, uint64_t* out8, int reset) {
 
 int fmd_profile_enable(fmd_handle h, int on) {
     if (!h) return FMD_ERR_ARG;
-    h->profiling = on < 0 ? 0 : (on > 2 ? 2 : on);
+    h->profiling = on < 0 ? 0 : (on > 3 ? 3 : on);
     return FMD_OK;
 }
 

@@ -183,6 +183,8 @@ int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t
  * Results never depend on any of them; they explain k_pilot_pll's duration. */
 int fmd_get_spec_stats(fmd_handle h, uint64_t* out8, int reset);
 
+/* on = 0: off; 1: timing events on every kernel of every block; 2: the dominant kernel every block, the others every 4th;
+ * 3: every kernel of every 4th block plus the dominant kernel of the block behind it (what bench.py uses: ~1 % of the step) */
 int fmd_profile_enable(fmd_handle h, int on);
 int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out);
 
