@@ -562,13 +562,16 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
     // from the FIR kernels than the hand-over gap gives back (same-box A/B: -13 % at 1024 stations, -7 % at 3072, +4 % at 4096).
     if (chain) {
         const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
-        while (__hip_atomic_load(&chain[blockIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq - 1u) {
+        // relaxed polls (an acquire load invalidates the caches at agent scope every time round: with hundreds of waiting
+        // wavefronts that slows every kernel on the chip), one acquire fence once the predecessor has published
+        while (__hip_atomic_load(&chain[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq - 1u) {
             __builtin_amdgcn_s_sleep(4);
             if (__builtin_amdgcn_s_memrealtime() - w0 > 200000000ull) {   // 100 MHz ticks
                 if (lane == 0) __hip_atomic_store(&chain[gridDim.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     // AGC_Filter::process (agc.h:12-19) as compiled: target_gain = sqrt((target/sum) * N)
     float gain = st(state, S_AGC_PILOT_GAIN, d.C, cs);
