@@ -460,8 +460,8 @@ __device__ __forceinline__ float pll_step(PllState& s, float p, float q, const L
 // A wavefront out of lock (acquisition, a station without pilot) commits ~1 sample per span; after a chunk that needed more
 // than 24 spans the wavefront runs the next chunks with the plain serial iteration (pll_step), backing off exponentially.
 //
-// Layout: one wavefront = 4 channels x 16 lanes, one workgroup = one wavefront (14 KB LDS, ~150 VGPRs: fits any hole a
-// retiring FIR workgroup leaves).  128-sample chunks; LDS rings of two chunks per channel for the pilot samples and the
+// Layout: one wavefront = 64 / K channels x K lanes (K = 16 or 8), one workgroup = one wavefront (12.6 KB LDS and 128 VGPRs
+// at K = 16: fits any hole a retiring FIR workgroup leaves; 24.8 KB and 169 VGPRs at K = 8).  128-sample chunks; LDS rings of two chunks per channel for the pilot samples and the
 // results; the chunk after next is in flight in 4 float4 registers per lane; all global traffic is 16-byte, row-contiguous.
 // Constants live in VGPRs (a 32-bit literal costs a lone wave ~2.7 cycles per instruction).
 // ---------------------------------------------------------------------------------------------------------------
