@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the MI355X FM demodulation hot path (driver contract: see the round prompt).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            (N>1: launched under torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    (N>1: either launched under torch.distributed.run by the caller, or — when WORLD_SIZE is not set — bench.py starts
+     `python -m torch.distributed.run --nproc-per-node N` itself as a CHILD process, before anything touches the GPU,
+     relays rank 0's JSON line and exits with the child's return code)
 
 One "step" = one `fmd_process_cf32_dev` call = one block of every channel through the whole chain
 (decimating FIRs -> discriminator -> Hilbert -> pilot PLL -> x2/x3 mixers -> audio/RDS decimators -> stereo mix,
@@ -44,10 +47,30 @@ def algorithmic_bytes_per_sample(fs: int, u8: bool) -> float:
     return in_b + audio + syms
 
 
-def synth_block_device(torch, n_ch: int, n_total: int, fs: float, seed: int, device, u8: bool, chunk: int = 256):
+UNLOCKED_KINDS = ("nopilot", "noise", "zero")
+
+
+def unlocked_plan(n_ch: int, frac: float, kind: str, seed: int) -> np.ndarray:
+    """Which channels cannot lock, and how: 0 = normal station, 1 = mono station (no 19 kHz pilot, no L-R, no RDS), 2 = empty
+    channel (receiver noise only), 3 = dead channel (all-zero IQ: pilot AGC divides by zero, reference agc.h:12-19).  The
+    affected channels are spread over the batch pseudo-randomly (seeded), as stations are over a band scan."""
+    plan = np.zeros(n_ch, np.int8)
+    n_bad = int(round(frac * n_ch))
+    if n_bad <= 0:
+        return plan
+    rng = np.random.default_rng(seed)
+    idx = rng.choice(n_ch, size=min(n_bad, n_ch), replace=False)
+    kinds = {"nopilot": [1], "noise": [2], "zero": [3], "mix": [1, 2, 3]}[kind]
+    plan[idx] = np.array([kinds[i % len(kinds)] for i in range(idx.size)], np.int8)
+    return plan
+
+
+def synth_block_device(torch, n_ch: int, n_total: int, fs: float, seed: int, device, u8: bool, chunk: int = 256, plan=None):
     """Synthetic multi-channel FM baseband on the GPU: stereo tones + pilot + L-R DSB-SC + BPSK RDS at 57 kHz, FM 75 kHz
-    deviation, noise 0.02/rail, scaled x100 (the RTL-SDR u8 amplitude) — the SURVEY §8(d) recipe.  Returns [C, n_total, 2]."""
+    deviation, noise 0.02/rail, scaled x100 (the RTL-SDR u8 amplitude) — the SURVEY §8(d) recipe.  Returns [C, n_total, 2].
+    plan: optional per-channel kinds from unlocked_plan()."""
     out = torch.empty((n_ch, n_total, 2), dtype=torch.uint8 if u8 else torch.float32, device=device)
+    kinds = torch.zeros(n_ch, dtype=torch.int64, device=device) if plan is None else torch.from_numpy(np.asarray(plan, np.int64)).to(device)
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     t = torch.arange(n_total, device=device, dtype=torch.float64) / fs
@@ -68,13 +91,17 @@ def synth_block_device(torch, n_ch: int, n_total: int, fs: float, seed: int, dev
         idx = torch.floor(t * 2375.0).to(torch.int64)
         rds = sym[:, idx]
         p = two_pi * 19000.0 * tt
-        mpx = 0.40 * (left + right) / 1.6 + 0.10 * torch.sin(p) + 0.40 * (left - right) / 1.6 * torch.sin(2.0 * p) + 0.06 * rds * torch.sin(3.0 * p)
+        kd = kinds[c0:c1, None]
+        stereo = (kd == 0).to(torch.float64)          # pilot, L-R and RDS present
+        carrier = (kd <= 1).to(torch.float64)         # an FM carrier at all (kind 2: noise only; kind 3: nothing)
+        live = (kd <= 2).to(torch.float64)
+        mpx = 0.40 * (left + right) / 1.6 + stereo * (0.10 * torch.sin(p) + 0.40 * (left - right) / 1.6 * torch.sin(2.0 * p) + 0.06 * rds * torch.sin(3.0 * p))
         phase = two_pi * 75000.0 * torch.cumsum(mpx, dim=1) / fs
-        i = torch.cos(phase) + 0.02 * torch.randn((m, n_total), generator=g, device=device, dtype=torch.float64)
-        q = torch.sin(phase) + 0.02 * torch.randn((m, n_total), generator=g, device=device, dtype=torch.float64)
+        i = carrier * torch.cos(phase) + live * 0.02 * torch.randn((m, n_total), generator=g, device=device, dtype=torch.float64)
+        q = carrier * torch.sin(phase) + live * 0.02 * torch.randn((m, n_total), generator=g, device=device, dtype=torch.float64)
         iq = torch.stack([i, q], dim=2)
         if u8:
-            out[c0:c1] = torch.clamp(torch.round(127.0 + 100.0 * iq), 0, 255).to(torch.uint8)
+            out[c0:c1] = torch.clamp(torch.round(127.0 + 100.0 * iq), 0, 255).to(torch.uint8)   # a dead channel is 127 = exactly 0 after the conversion
         else:
             out[c0:c1] = (100.0 * iq).to(torch.float32)
         del left, right, rds, mpx, phase, i, q, iq, sym, lvl, diff, bits
@@ -207,6 +234,34 @@ def cpu_reference(budget_s: float = 10.0) -> dict | None:
             "sample": f"{n_proc} processes x {n} u8 samples @ 1.024 MSa/s (20.5 s of signal each) in {el:.1f} s, reference fm_demod_benchmark incl. RDS decode"}
 
 
+def launch_ranks(n: int) -> int:
+    """Start `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child process, pass its
+    stderr through, print exactly one JSON line (rank 0's) on stdout and return the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in proc.stdout:
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        print("bench.py: the ranks exited without printing a result line", file=sys.stderr)
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,7 +291,23 @@ def main() -> None:
                     "through the on-GPU channeliser, then the batched demodulator (single GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--share-gpu", action="store_true", help="plumbing test: every rank uses cuda:0")
+    ap.add_argument("--unlocked-frac", type=float, default=0.0, help="fraction of the channels that cannot hold pilot lock "
+                    "(mono stations, empty channels, dead inputs: see --unlocked-kind), spread over the batch")
+    ap.add_argument("--unlocked-kind", default="mix", choices=["mix", *UNLOCKED_KINDS],
+                    help="nopilot: mono FM station without pilot/L-R/RDS; noise: no carrier, receiver noise only; zero: all-zero IQ "
+                         "(the pilot AGC divides by zero, as in the reference); mix: the three in turn")
+    ap.add_argument("--deemphasis", type=int, default=0, metavar="US", help="enable the de-emphasis IIR on every channel with this time constant (50 / 75)")
+    ap.add_argument("--fast-math", action="store_true", help="FMD_FLAG_FAST_MATH: the tolerance mode (north-star parity: audio within 1e-4 RMS, RDS bits identical)")
     args = ap.parse_args()
+
+    # --gpus N without a launcher: start the ranks ourselves, as a CHILD process, before this process has touched the GPU
+    # (no torch.cuda / HIP call has happened yet; a process that has initialised the GPU must never exec another program)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: launch with --nproc-per-node equal to --gpus "
+                         "(or without a launcher: bench.py starts the ranks itself)")
 
     import torch
     import torch.distributed as dist
@@ -245,12 +316,9 @@ def main() -> None:
     pkg = fmradio_loader.load()
     pkg.load_library()  # raises when the HIP extension is missing: there is no fallback to measure
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = world_env
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -273,9 +341,14 @@ def main() -> None:
     C = args.channels
     K, W, P = args.steps, args.warmup, max(args.preroll, 0)
     n_blocks_resident = min(K + W + P, 8)  # distinct consecutive blocks kept in HBM, cycled
-    x = synth_block_device(torch, C, n_blocks_resident * block, float(fs), 1234 + rank, device, args.u8)
+    plan = unlocked_plan(C, args.unlocked_frac, args.unlocked_kind, 99 + rank)
+    x = synth_block_device(torch, C, n_blocks_resident * block, float(fs), 1234 + rank, device, args.u8, plan=plan)
     x = x.view(C, n_blocks_resident, block, 2).permute(1, 0, 2, 3).contiguous()  # [blocks][C][N][2]
-    dm = pkg.BatchDemod(C, block, fs, device=local_rank, pipelined=not args.no_pipeline, pll_kernel=args.pll_kernel)
+    dm = pkg.BatchDemod(C, block, fs, device=local_rank, pipelined=not args.no_pipeline, pll_kernel=args.pll_kernel, fast_math=args.fast_math)
+    if args.deemphasis:
+        ctl = pkg.default_controls()
+        ctl.use_deemphasis, ctl.deemphasis_tus = 1, args.deemphasis
+        dm.set_controls(ctl)
 
     do_gather = world > 1 and not args.no_gather and args.gather != "none"
     pcm16 = args.gather_format == "pcm16"
@@ -294,6 +367,9 @@ def main() -> None:
                 else:
                     dm.wait_outputs(gstream)
                     gather.stage[s].copy_(dm.audio_tensor(), non_blocking=True)
+                # the output views of this block have been read into the staging buffer once gstream gets here: the library
+                # must not reuse them earlier, however far the submitting side runs ahead of the collective
+                dm.release_outputs(gstream)
                 gather.launch(s)
 
     def drain():
@@ -326,6 +402,18 @@ def main() -> None:
         tmax = torch.tensor([el], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         el = float(tmax.item())
+    # the collective's result is checked (outside the timed region): every rank's last staged block must be what the
+    # collector holds for that rank — a slot reused too early or a desynchronised collective shows up here
+    gather_verified = None
+    if do_gather:
+        s_last = (P + W + K - 1) % gather.depth
+        mine = gather.stage[s_last].to(torch.float64).sum().item(), int(gather.stage[s_last].ne(0).sum().item())
+        sums = [None] * world
+        dist.all_gather_object(sums, mine)
+        if gather.out[s_last] is not None:
+            parts = gather.out[s_last].chunk(world, dim=0)
+            gather_verified = all((pt.to(torch.float64).sum().item(), int(pt.ne(0).sum().item())) == tuple(sm) for pt, sm in zip(parts, sums))
+            gather_verified = gather_verified and torch.equal(parts[rank], gather.stage[s_last]) and sums[0][1] > 0
     ktimes = dm.profile_read()
     gaps = {k[4:]: v[0] / max(v[1], 1) for k, v in ktimes.items() if k.startswith("gap:")}   # stream hand-over between launches
     ktimes = {k: v for k, v in ktimes.items() if not k.startswith("gap:")}
@@ -366,7 +454,10 @@ def main() -> None:
             except Exception:
                 valu = None
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": None if traffic is None else "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                      "configuration (tools/collect_profiles.sh), committed; not re-measured by this run",
+                    "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_launch": algo_bytes,
                     "whole_step_frac": (bps * C * block * K / el / 1e9) / HBM_PEAK_GBS if world == 1 else None,
                     "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in ktimes.items()},
@@ -389,8 +480,12 @@ def main() -> None:
         "config": {"workload": f"BASELINE configs[2]: {C} synthetic FM channels/GPU @ {fs} Sa/s, {block}-sample blocks, "
                                f"{'u8' if args.u8 else 'cf32'} IQ resident in HBM, full stereo + pilot PLL + RDS",
                    "channels_per_gpu": C, "fs_baseband": fs, "block_size": block, "ingest": "u8" if args.u8 else "cf32",
-                   "preroll_blocks": P,
+                   "preroll_blocks": P, "resident_signal": f"{n_blocks_resident} consecutive blocks cycled (phase-continuous for the 19 kHz pilot)",
+                   "mode": "fast_math (tolerance: audio within 1e-4 RMS of the reference, RDS bits identical)" if args.fast_math else "exact (bit-identical to the CPU oracle)",
+                   "unlocked_frac": args.unlocked_frac, "unlocked_kind": args.unlocked_kind if args.unlocked_frac > 0 else None,
+                   "deemphasis_us": args.deemphasis or None,
                    "parallelism": f"channel-sharded x{world}" + gather_note},
+        "gather_verified": gather_verified,
         "channels_at_realtime": value * 1e6 / fs,
         "msa_per_gpu": value / world,
         "roofline": roofline,

@@ -19,6 +19,7 @@ PKG_DIR = Path(__file__).resolve().parent
 ROOT = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
 HEADER = ROOT / "include" / "fmdemod.h"
+DEBUG_HEADER = ROOT / "include" / "fmdemod_debug.h"   # self-test / profiling hooks: not part of the drop-in boundary
 
 FMD_AUDIO_LPR, FMD_AUDIO_LMR, FMD_AUDIO_STEREO = 0, 1, 2
 FMD_FLAG_KEEP_TAPS = 1
@@ -27,7 +28,9 @@ FMD_FLAG_PLL_TIME_PARALLEL = 4
 FMD_FLAG_PLL_LOW_WORK = 8
 FMD_FLAG_PLL_K8 = 16
 FMD_FLAG_PLL_STREAM_ORDER = 32
-FMD_OK, FMD_ERR_ARG, FMD_ERR_SIZE, FMD_ERR_DEVICE, FMD_ERR_NO_DEVICE, FMD_ERR_NAME = 0, -1, -2, -3, -4, -5
+FMD_FLAG_FAST_MATH = 64
+FMD_OK, FMD_ERR_ARG, FMD_ERR_SIZE, FMD_ERR_DEVICE, FMD_ERR_NO_DEVICE, FMD_ERR_NAME, FMD_ERR_STATE = 0, -1, -2, -3, -4, -5, -6
+FMD_OUTPUT_LIFETIME_BLOCKS = 5   # include/fmdemod.h; checked against the loaded library in load_library()
 
 
 class FmdError(RuntimeError):
@@ -80,11 +83,13 @@ def build_library(force: bool = False) -> Path:
     return lib_path()
 
 
-def declared_symbols() -> list[str]:
-    """Every function include/fmdemod.h declares."""
-    text = HEADER.read_text()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(fmd_[a-z0-9_]+)\s*\(", text)))
+def declared_symbols(debug: bool = True) -> list[str]:
+    """Every function include/fmdemod.h declares (+ include/fmdemod_debug.h's hooks)."""
+    names = set()
+    for hdr in (HEADER, DEBUG_HEADER) if debug else (HEADER,):
+        text = re.sub(r"/\*.*?\*/", "", hdr.read_text(), flags=re.S)
+        names |= set(re.findall(r"\b(fmd_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 _lib = None
@@ -126,6 +131,12 @@ def load_library():
         getattr(L, name).argtypes = [H, C.c_void_p, C.c_int, C.c_int]
     L.fmd_synchronize.argtypes = [H]
     L.fmd_wait_outputs.argtypes = [H, C.c_void_p]
+    L.fmd_release_outputs.argtypes = [H, C.c_void_p]
+    L.fmd_output_lifetime_blocks.restype = C.c_int
+    L.fmd_state_size.restype = C.c_size_t
+    L.fmd_state_size.argtypes = [H]
+    L.fmd_get_state.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t]
+    L.fmd_set_state.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t]
     L.fmd_audio_dev.argtypes = [H, C.POINTER(C.c_void_p)]
     L.fmd_audio_pcm16_dev.argtypes = [H, C.c_void_p, C.c_void_p]
     L.fmd_rds_dev.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
@@ -151,6 +162,8 @@ def load_library():
     L.fmd_chan_last_error.argtypes = [C.c_void_p]
     L.fmd_last_error.restype = C.c_char_p
     L.fmd_last_error.argtypes = [H]
+    if L.fmd_output_lifetime_blocks() != FMD_OUTPUT_LIFETIME_BLOCKS:
+        raise RuntimeError("libfmdemod.so and capi.py disagree on FMD_OUTPUT_LIFETIME_BLOCKS")
     _lib = L
     return L
 
@@ -188,13 +201,14 @@ class BatchDemod:
     """C broadcast-FM demodulators advanced in lock-step on one MI355X."""
 
     def __init__(self, n_channels: int, block_size: int = 65536, fs_baseband: int = 1_024_000, device: int = -1, keep_taps: bool = False,
-                 pipelined: bool = True, pll_kernel: str = "auto", pll_stream_order: bool = False):
+                 pipelined: bool = True, pll_kernel: str = "auto", pll_stream_order: bool = False, fast_math: bool = False):
         self.L = load_library()
         self.h = C.c_void_p()
         flags = (FMD_FLAG_KEEP_TAPS if keep_taps else 0) | (0 if pipelined else FMD_FLAG_NO_PIPELINE)
         flags |= {"auto": 0, "time_parallel": FMD_FLAG_PLL_TIME_PARALLEL, "time_parallel8": FMD_FLAG_PLL_TIME_PARALLEL | FMD_FLAG_PLL_K8,
                   "low_work": FMD_FLAG_PLL_LOW_WORK}[pll_kernel]
         flags |= FMD_FLAG_PLL_STREAM_ORDER if pll_stream_order else 0
+        flags |= FMD_FLAG_FAST_MATH if fast_math else 0
         cfg = Config(n_channels, block_size, fs_baseband, device, flags)
         rc = self.L.fmd_create(C.byref(cfg), C.byref(self.h))
         if rc != FMD_OK:
@@ -270,6 +284,26 @@ class BatchDemod:
             stream = stream.cuda_stream
         self._check(self.L.fmd_wait_outputs(self.h, C.c_void_p(stream)))
 
+    def release_outputs(self, stream=None):
+        """Tell the library that everything queued on `stream` so far reads the newest block's output views: their buffers are
+        not reused before that work has finished (fmd_release_outputs; device-side ordering, the host never blocks)."""
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        elif hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+        self._check(self.L.fmd_release_outputs(self.h, C.c_void_p(stream)))
+
+    # -- per-channel state snapshot / restore --
+    def get_state(self, channel: int) -> bytes:
+        n = self.L.fmd_state_size(self.h)
+        buf = C.create_string_buffer(n)
+        self._check(self.L.fmd_get_state(self.h, channel, buf, n))
+        return buf.raw
+
+    def set_state(self, channel: int, blob: bytes):
+        self._check(self.L.fmd_set_state(self.h, channel, blob, len(blob)))
+
     # -- outputs --
     def audio(self) -> np.ndarray:
         out = np.empty((self.n_channels, self.rates.n_audio, 2), np.float32)
@@ -335,7 +369,8 @@ class BatchDemod:
     def audio_tensor(self):
         """Zero-copy torch view of the newest block's device audio buffer [C, n_audio, 2] (the library alternates
         between its pipeline slots: call again after each process(); contents are complete after wait_outputs/synchronize and stay
-        valid until five more blocks have been submitted)."""
+        valid while at most FMD_OUTPUT_LIFETIME_BLOCKS = 5 further blocks have been submitted — or longer for a consumer that
+        calls release_outputs())."""
         import torch
         p = C.c_void_p()
         self._check(self.L.fmd_audio_dev(self.h, C.byref(p)))

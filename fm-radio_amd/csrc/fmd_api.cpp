@@ -16,6 +16,7 @@
 #include "fmd_design.h"
 #include "fmd_kernels.h"
 #include "fmdemod.h"
+#include "fmdemod_debug.h"
 
 using namespace fmd;
 
@@ -46,7 +47,10 @@ struct fmd_handle_s {
     bool pll_chained = false;
     int pll_waves = 0;
     hipEvent_t ev_in = nullptr, ev_P[kSlots] = {}, ev_F[kSlots] = {}, ev_A[kSlots] = {}, ev_B[kSlots] = {}, ev_E[kSlots] = {}, ev_X[kSlots] = {};
+    hipEvent_t ev_C[kSlots] = {};            // fmd_release_outputs: the consumer of a slot's outputs has finished with them
+    bool consumer_pending[kSlots] = {};
     bool slot_used[kSlots] = {};
+    bool poisoned = false;                   // a block failed part-way: state is not the state after a whole number of blocks
     bool pipelined = true;
     long n_blocks = 0;                       // blocks submitted since create/reset; slot = n_blocks % kSlots
     int out_slot = 0;                        // slot holding the newest block's outputs
@@ -60,10 +64,22 @@ struct fmd_handle_s {
 
 namespace {
 
-// The pipeline keeps five streams busy beside the caller's; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default
-// 4) and dependent stages sharing a queue block each other.  Ask for 8 when the library is loaded, unless the process already
-// chose (only effective before the HIP runtime initialises).
-__attribute__((constructor)) void fmd_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// The pipeline keeps six streams busy beside the caller's; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default
+// 4) and dependent stages sharing a queue block each other.  The library does not touch the process environment: the host
+// application sets GPU_MAX_HW_QUEUES >= 8 before the HIP runtime initialises, and fmd_create warns once on
+// stderr (and in fmd_last_error(NULL)) when it finds less.  FMD_QUIET=1 silences the warning.
+void warn_hw_queues_once() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const char* v = getenv("GPU_MAX_HW_QUEUES");
+    const int n = v ? atoi(v) : 4;
+    if (n >= 7) return;
+    const char* q = getenv("FMD_QUIET");
+    if (q && *q && *q != '0') return;
+    fprintf(stderr, "libfmdemod: GPU_MAX_HW_QUEUES=%s: the pipelined demodulator uses 7 streams and loses its overlap on fewer hardware "
+                    "queues; set GPU_MAX_HW_QUEUES=8 in the environment before the HIP runtime initialises (see INTEGRATION.md)\n", v ? v : "(unset, default 4)");
+}
 
 thread_local std::string g_create_error;
 
@@ -96,8 +112,12 @@ int dev_alloc(fmd_handle h, T** p, size_t count) {
     return FMD_OK;
 }
 
+constexpr unsigned kKnownFlags = FMD_FLAG_KEEP_TAPS | FMD_FLAG_NO_PIPELINE | FMD_FLAG_PLL_TIME_PARALLEL | FMD_FLAG_PLL_LOW_WORK | FMD_FLAG_PLL_K8 |
+                                 FMD_FLAG_PLL_STREAM_ORDER;
+
 bool config_ok(const fmd_config* c, int* m) {
     if (!c || c->n_channels <= 0) return false;
+    if (c->flags & ~kKnownFlags) return false;        // a flag this build does not implement must not be silently ignored
     if (c->fs_baseband != 256000 && c->fs_baseband != 1024000 && c->fs_baseband != 2048000) return false;
     *m = c->fs_baseband / 256000;
     if (c->block_size <= 0 || (c->block_size % (1024 * *m)) != 0) return false;
@@ -176,9 +196,14 @@ int zero_history(fmd_handle h, hipStream_t s) {
         HIP_TRY(h, hipMemsetAsync(b.rds_bytes_count[p], 0, sizeof(int) * (size_t)d.C, s));
     }
     HIP_TRY(h, launch_reset_state(h->ctx, s));
+    // everything is idle here (callers synchronise first): restart the per-wavefront PLL hand-over chain, watchdog flag included
+    if (b.pll_chain) HIP_TRY(h, hipMemsetAsync(b.pll_chain, 0, sizeof(unsigned) * ((size_t)h->pll_waves + 1), s));
+    h->pll_seq = 0;
     h->n_blocks = 0;
     h->out_slot = 0;
     for (bool& u : h->slot_used) u = false;
+    for (bool& u : h->consumer_pending) u = false;
+    h->poisoned = false;
     return FMD_OK;
 }
 
@@ -189,7 +214,12 @@ int sync_all(fmd_handle h) {
     if (h->pll_chained && h->pll_seq) {   // the hand-over watchdog of k_pilot_pll
         unsigned timed_out = 0;
         HIP_TRY(h, hipMemcpy(&timed_out, h->ctx.b.pll_chain + h->pll_waves, sizeof(unsigned), hipMemcpyDeviceToHost));
-        if (timed_out) return fail(h, FMD_ERR_DEVICE, "k_pilot_pll: a wavefront's predecessor never published its state");
+        if (timed_out) {
+            // reported once; the flag is cleared so that later calls do not fail for good, and the handle asks for a reset
+            (void)hipMemset(h->ctx.b.pll_chain + h->pll_waves, 0, sizeof(unsigned));
+            h->poisoned = true;
+            return fail(h, FMD_ERR_DEVICE, "k_pilot_pll: a wavefront's predecessor never published its state (call fmd_reset)");
+        }
     }
     return FMD_OK;
 }
@@ -200,6 +230,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     if (!d_iq) return fail(h, FMD_ERR_ARG, "null input pointer");
     if (n_channels != h->cfg.n_channels || n_samples != h->cfg.block_size)
         return fail(h, FMD_ERR_SIZE, "block dropped: got %d x %d, handle is %d x %d", n_channels, n_samples, h->cfg.n_channels, h->cfg.block_size);
+    if (h->poisoned) return fail(h, FMD_ERR_STATE, "an earlier block failed part-way: call fmd_reset");
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->controls_dirty) {
@@ -240,6 +271,14 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         return fn(h->ctx, r, on);
     };
     hipError_t e = hipSuccess;
+    // from here on kernels are queued and host-side counters advance: a failure leaves the state between two blocks
+    struct Poison { fmd_handle h; bool armed = true; ~Poison() { if (armed) h->poisoned = true; } } poison{h};
+    // fmd_release_outputs: the writers of this slot's output views wait for the consumer that still reads the old contents
+    if (h->consumer_pending[slot]) {
+        HIP_TRY(h, hipStreamWaitEvent(sX, h->ev_C[slot], 0));
+        if (sR != sX) HIP_TRY(h, hipStreamWaitEvent(sR, h->ev_C[slot], 0));
+        h->consumer_pending[slot] = false;
+    }
     // The first decimator (1.024 / 2.048 MSa/s) gets a stream of its own when the PLL launches do not need own_stream: it then
     // works on block b+1 while k_front works on block b (back to back on one stream the two were the longest stage)
     const bool predecim = h->ctx.d.m > 1;
@@ -294,6 +333,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     h->n_blocks++;
     if (h->deemph_linger) { h->deemph_linger = false; h->ctx.any_deemph = 0; }
     h->last_stream = s;
+    poison.armed = false;
     return FMD_OK;
 }
 
@@ -330,6 +370,7 @@ void free_marks(fmd_handle h) {
 extern "C" {
 
 int fmd_api_version(void) { return FMD_API_VERSION; }
+int fmd_output_lifetime_blocks(void) { static_assert(FMD_OUTPUT_LIFETIME_BLOCKS == kSlots - 1, "one contract"); return kSlots - 1; }
 
 const char* fmd_status_string(int s) {
     switch (s) {
@@ -339,6 +380,7 @@ const char* fmd_status_string(int s) {
         case FMD_ERR_DEVICE: return "HIP runtime error";
         case FMD_ERR_NO_DEVICE: return "no gfx950 device (no CPU fallback)";
         case FMD_ERR_NAME: return "unknown stream name";
+        case FMD_ERR_STATE: return "a block failed part-way: call fmd_reset";
         default: return "unknown status";
     }
 }
@@ -390,6 +432,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     { hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking); if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e))); }
 
     h->pipelined = (cfg->flags & FMD_FLAG_NO_PIPELINE) == 0;
+    if (h->pipelined) warn_hw_queues_once();
 
     // (A CU-mask split between the serial and the FIR streams was measured: it shields the PLL wave from FIR waves
     //  sharing its SIMD — 3.06 -> 2.75 ms — but CU-masked streams did not overlap with each other on this runtime, so
@@ -403,7 +446,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     }
     {
         std::vector<hipEvent_t*> evs = {&h->ev_in};
-        for (int i = 0; i < kSlots; i++) { evs.push_back(&h->ev_P[i]); evs.push_back(&h->ev_F[i]); evs.push_back(&h->ev_A[i]); evs.push_back(&h->ev_B[i]); evs.push_back(&h->ev_E[i]); evs.push_back(&h->ev_X[i]); }
+        for (int i = 0; i < kSlots; i++) { evs.push_back(&h->ev_P[i]); evs.push_back(&h->ev_F[i]); evs.push_back(&h->ev_A[i]); evs.push_back(&h->ev_B[i]); evs.push_back(&h->ev_E[i]); evs.push_back(&h->ev_X[i]); evs.push_back(&h->ev_C[i]); }
         for (hipEvent_t* ev : evs) {
             hipError_t e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
             if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "event: %s", hipGetErrorString(e)));
@@ -465,7 +508,9 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     if (!rc) rc = dev_alloc(h, &b.state, (size_t)S_NUM_FIELDS * C);
     if (!rc) rc = dev_alloc(h, &b.spec_stats, 8);
     // per-wavefront hand-over between consecutive k_pilot_pll launches: the time-parallel kernel only, pipelined mode only
-    h->pll_chained = h->pipelined && effective_channels(d) <= 3328 && !(cfg->flags & FMD_FLAG_PLL_STREAM_ORDER);
+    // (the low-work kernel k_pilot_pll_pairs has no chain argument: its launches must stay ordered by the stream)
+    const bool time_parallel = d.C <= h->ctx.pll_time_parallel_max_channels;
+    h->pll_chained = h->pipelined && time_parallel && effective_channels(d) <= 3328 && !(cfg->flags & (FMD_FLAG_PLL_STREAM_ORDER | FMD_FLAG_PLL_LOW_WORK));
     h->pll_waves = (effective_channels(d) <= h->ctx.pll_k16_max_channels) ? (d.C + 3) / 4 : (d.C + 7) / 8;
     if (!rc) rc = dev_alloc(h, &b.pll_chain, (size_t)h->pll_waves + 1);
     if (rc) return bail(rc);
@@ -485,7 +530,7 @@ int fmd_destroy(fmd_handle h) {
     for (hipStream_t st : {h->sF, h->sA, h->sB, h->sX, h->sR}) if (st) (void)hipStreamDestroy(st);
     {
         std::vector<hipEvent_t> evs = {h->ev_in};
-        for (int i = 0; i < kSlots; i++) { evs.push_back(h->ev_P[i]); evs.push_back(h->ev_F[i]); evs.push_back(h->ev_A[i]); evs.push_back(h->ev_B[i]); evs.push_back(h->ev_E[i]); evs.push_back(h->ev_X[i]); }
+        for (int i = 0; i < kSlots; i++) { evs.push_back(h->ev_P[i]); evs.push_back(h->ev_F[i]); evs.push_back(h->ev_A[i]); evs.push_back(h->ev_B[i]); evs.push_back(h->ev_E[i]); evs.push_back(h->ev_X[i]); evs.push_back(h->ev_C[i]); }
         for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     }
     for (void* p : h->allocs) (void)hipFree(p);
@@ -498,7 +543,7 @@ int fmd_destroy(fmd_handle h) {
 int fmd_reset(fmd_handle h) {
     if (!h) return FMD_ERR_ARG;
     HIP_TRY(h, hipSetDevice(h->device));
-    { int rc0 = sync_all(h); if (rc0) return rc0; }
+    { int rc0 = sync_all(h); if (rc0 && !h->poisoned) return rc0; }   // a poisoned handle is reset whatever the last error was
     int rc = zero_history(h, h->own_stream);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->own_stream));
@@ -564,6 +609,15 @@ int fmd_wait_outputs(fmd_handle h, void* stream) {
     if (!h->pipelined || h->n_blocks == 0) return FMD_OK;   // unpipelined: the outputs are already ordered on the caller's stream
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->ev_X[h->out_slot], 0));
+    return FMD_OK;
+}
+
+int fmd_release_outputs(fmd_handle h, void* stream) {
+    if (!h) return FMD_ERR_ARG;
+    if (h->n_blocks == 0) return FMD_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventRecord(h->ev_C[h->out_slot], static_cast<hipStream_t>(stream)));
+    h->consumer_pending[h->out_slot] = true;
     return FMD_OK;
 }
 
@@ -657,6 +711,80 @@ int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats
     int rc = fmd_synchronize(h);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpy(out, p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return FMD_OK;
+}
+
+// ---- per-channel state snapshot (include/fmdemod.h: fmd_state_size / fmd_get_state / fmd_set_state) ----
+extern "C++" {
+namespace {
+struct StateHeader { uint32_t magic, version; int32_t fs_baseband, m, n_fields, tail_base; uint32_t reserved[2]; };
+constexpr uint32_t kStateMagic = 0x53444d46u;   // "FMDS"
+struct StatePart { void* base[2]; size_t floats; bool by_parity; };   // per-channel row of `floats` floats at base[par] + channel * floats
+
+std::vector<StatePart> state_parts(fmd_handle h) {
+    const Dims& d = h->ctx.d;
+    Buffers& b = h->ctx.b;
+    std::vector<StatePart> v;
+    v.push_back({{b.base_tail[0], b.base_tail[1]}, (size_t)d.tail_base * 2, true});
+    if (d.m > 1) v.push_back({{b.pre_tail[0], b.pre_tail[1]}, 64 * 2, true});
+    v.push_back({{b.iq_tail[0], b.iq_tail[1]}, 128 * 2, true});
+    v.push_back({{b.dt_tail[0], b.dt_tail[1]}, 128, true});
+    v.push_back({{b.fo_tail[0], b.fo_tail[1]}, 64, true});
+    return v;
+}
+size_t state_floats(fmd_handle h) {
+    size_t n = S_NUM_FIELDS;
+    for (const StatePart& p : state_parts(h)) n += p.floats;
+    return n;
+}
+}  // namespace
+}  // extern "C++"
+
+size_t fmd_state_size(fmd_handle h) { return h ? sizeof(StateHeader) + sizeof(float) * state_floats(h) : 0; }
+
+int fmd_get_state(fmd_handle h, int channel, void* blob, size_t cap_bytes) {
+    if (!h || !blob) return FMD_ERR_ARG;
+    if (channel < 0 || channel >= h->cfg.n_channels) return fail(h, FMD_ERR_ARG, "channel %d out of range", channel);
+    if (cap_bytes < fmd_state_size(h)) return fail(h, FMD_ERR_ARG, "state blob needs %zu bytes", fmd_state_size(h));
+    if (h->poisoned) return fail(h, FMD_ERR_STATE, "an earlier block failed part-way: call fmd_reset");
+    int rc = sync_all(h);
+    if (rc) return rc;
+    const Dims& d = h->ctx.d;
+    StateHeader hd{kStateMagic, 1u, h->cfg.fs_baseband, d.m, (int32_t)S_NUM_FIELDS, d.tail_base, {0u, 0u}};
+    std::memcpy(blob, &hd, sizeof(hd));
+    float* out = reinterpret_cast<float*>(static_cast<char*>(blob) + sizeof(hd));
+    // SoA fields [field][C] -> one float per field
+    HIP_TRY(h, hipMemcpy2D(out, sizeof(float), h->ctx.b.state + channel, sizeof(float) * (size_t)d.C, sizeof(float), S_NUM_FIELDS, hipMemcpyDeviceToHost));
+    out += S_NUM_FIELDS;
+    const int par = (int)(h->n_blocks & 1);   // the histories the NEXT block reads
+    for (const StatePart& p : state_parts(h)) {
+        HIP_TRY(h, hipMemcpy(out, static_cast<float*>(p.base[par]) + (size_t)channel * p.floats, sizeof(float) * p.floats, hipMemcpyDeviceToHost));
+        out += p.floats;
+    }
+    return FMD_OK;
+}
+
+int fmd_set_state(fmd_handle h, int channel, const void* blob, size_t n_bytes) {
+    if (!h || !blob) return FMD_ERR_ARG;
+    if (channel < 0 || channel >= h->cfg.n_channels) return fail(h, FMD_ERR_ARG, "channel %d out of range", channel);
+    if (h->poisoned) return fail(h, FMD_ERR_STATE, "an earlier block failed part-way: call fmd_reset");
+    const Dims& d = h->ctx.d;
+    StateHeader hd;
+    if (n_bytes < sizeof(hd)) return fail(h, FMD_ERR_ARG, "state blob too short");
+    std::memcpy(&hd, blob, sizeof(hd));
+    if (hd.magic != kStateMagic || hd.version != 1u || hd.fs_baseband != h->cfg.fs_baseband || hd.m != d.m || hd.n_fields != (int32_t)S_NUM_FIELDS ||
+        hd.tail_base != d.tail_base || n_bytes != fmd_state_size(h))
+        return fail(h, FMD_ERR_ARG, "state blob does not match this handle (rate %d vs %d, %zu vs %zu bytes)", hd.fs_baseband, h->cfg.fs_baseband, n_bytes, fmd_state_size(h));
+    int rc = sync_all(h);
+    if (rc) return rc;
+    const float* in = reinterpret_cast<const float*>(static_cast<const char*>(blob) + sizeof(hd));
+    HIP_TRY(h, hipMemcpy2D(h->ctx.b.state + channel, sizeof(float) * (size_t)d.C, in, sizeof(float), sizeof(float), S_NUM_FIELDS, hipMemcpyHostToDevice));
+    in += S_NUM_FIELDS;
+    const int par = (int)(h->n_blocks & 1);
+    for (const StatePart& p : state_parts(h)) {
+        HIP_TRY(h, hipMemcpy(static_cast<float*>(p.base[par]) + (size_t)channel * p.floats, in, sizeof(float) * p.floats, hipMemcpyHostToDevice));
+        in += p.floats;
+    }
     return FMD_OK;
 }
 

@@ -35,6 +35,7 @@ struct ChanDims {
     int L, M, T;            // interpolation, decimation, taps per phase
     int n_stations;
     long long n_out;        // outputs per station this call
+    long long out_stride;   // row stride of the caller's output buffer (its capacity per station)
     unsigned long long o0;  // absolute index of the first output of this call
     unsigned long long n_base;  // absolute input index of win[0]
 };
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void k_channelize(ChanDims d, const float2* __
                 ar[u] = fmaf(h, x.x, ar[u]); ai[u] = fmaf(h, x.y, ai[u]);
             }
         }
-        out[(size_t)k * d.n_out + tile0 + oo] = make_float2((ar[0] + ar[2]) + (ar[1] + ar[3]), (ai[0] + ai[2]) + (ai[1] + ai[3]));
+        out[(size_t)k * d.out_stride + tile0 + oo] = make_float2((ar[0] + ar[2]) + (ar[1] + ar[3]), (ai[0] + ai[2]) + (ai[1] + ai[3]));
     }
 }
 
@@ -98,7 +99,10 @@ struct fmd_channelizer_s {
     size_t max_in = 0;
     unsigned long long n_abs = 0;     // absolute index of the next input sample
     unsigned long long o_abs = 0;     // absolute index of the next output sample
-    float2* win = nullptr;            // [T-1 + max_in]
+    float2* win[2] = {nullptr, nullptr};   // [T-1 + max_in] each, ping-pong: the history hand-over copies between DIFFERENT buffers
+    int cur = 0;                      // window the next call stages into (its first T-1 samples hold the history)
+    hipEvent_t done = nullptr;        // end of the previous call's work, for callers that change streams between calls
+    bool have_done = false;
     float* taps = nullptr;            // [T][L]
     unsigned long long* inc = nullptr;
     std::vector<float> h_taps;
@@ -167,10 +171,11 @@ int fmd_chan_create(const fmd_chan_config* cfg, fmd_channelizer* out) {
         inc[k] = (unsigned long long)std::llround(std::ldexp(fr, 63)) << 1;   // fr * 2^64, even
     }
     bool ok = hipSetDevice(dev) == hipSuccess;
-    ok = ok && hipMalloc(&h->win, sizeof(float2) * (h->max_in + (size_t)T)) == hipSuccess;
+    for (int i = 0; i < 2; i++) ok = ok && hipMalloc(&h->win[i], sizeof(float2) * (h->max_in + (size_t)T)) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->done, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(&h->taps, sizeof(float) * h->h_taps.size()) == hipSuccess;
     ok = ok && hipMalloc(&h->inc, sizeof(unsigned long long) * h->C) == hipSuccess;
-    ok = ok && hipMemset(h->win, 0, sizeof(float2) * (h->max_in + (size_t)T)) == hipSuccess;
+    for (int i = 0; i < 2; i++) ok = ok && hipMemset(h->win[i], 0, sizeof(float2) * (h->max_in + (size_t)T)) == hipSuccess;
     ok = ok && hipMemcpy(h->taps, h->h_taps.data(), sizeof(float) * h->h_taps.size(), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(h->inc, inc.data(), sizeof(unsigned long long) * h->C, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { fmd_chan_destroy(h); return chan_fail(nullptr, FMD_ERR_DEVICE, "device allocation failed"); }
@@ -181,7 +186,8 @@ int fmd_chan_create(const fmd_chan_config* cfg, fmd_channelizer* out) {
 int fmd_chan_destroy(fmd_channelizer h) {
     if (!h) return FMD_ERR_ARG;
     (void)hipSetDevice(h->device);
-    if (h->win) (void)hipFree(h->win);
+    for (int i = 0; i < 2; i++) if (h->win[i]) (void)hipFree(h->win[i]);
+    if (h->done) (void)hipEventDestroy(h->done);
     if (h->taps) (void)hipFree(h->taps);
     if (h->inc) (void)hipFree(h->inc);
     delete h;
@@ -206,8 +212,9 @@ int fmd_chan_get_taps(fmd_channelizer h, float* taps, size_t cap_floats) {
 int fmd_chan_reset(fmd_channelizer h) {
     if (!h) return FMD_ERR_ARG;
     if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "synchronise failed");
-    if (hipMemset(h->win, 0, sizeof(float2) * (h->max_in + (size_t)h->T)) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "memset failed");
-    h->n_abs = 0; h->o_abs = 0;
+    for (int i = 0; i < 2; i++)
+        if (hipMemset(h->win[i], 0, sizeof(float2) * (h->max_in + (size_t)h->T)) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "memset failed");
+    h->n_abs = 0; h->o_abs = 0; h->cur = 0; h->have_done = false;
     return FMD_OK;
 }
 
@@ -220,15 +227,23 @@ int fmd_chan_process_cf32_dev(fmd_channelizer h, const float* d_wide, size_t n_i
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipSetDevice(h->device) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "hipSetDevice failed");
     const int T = h->T;
+    // the windows carry state from call to call: a caller that switches streams is ordered behind the previous call's work
+    if (h->have_done && hipStreamWaitEvent(s, h->done, 0) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "stream wait failed");
     // window = [T-1 history samples][this block]; win[0] has absolute input index n_abs - (T-1)
-    if (hipMemcpyAsync(h->win + (T - 1), d_wide, sizeof(float2) * n_in, hipMemcpyDeviceToDevice, s) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "staging copy failed");
-    ChanDims d{h->L, h->M, T, h->C, (long long)no, h->o_abs, h->n_abs - (unsigned long long)(T - 1)};
+    float2* win = h->win[h->cur];
+    float2* next = h->win[h->cur ^ 1];
+    if (hipMemcpyAsync(win + (T - 1), d_wide, sizeof(float2) * n_in, hipMemcpyDeviceToDevice, s) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "staging copy failed");
+    ChanDims d{h->L, h->M, T, h->C, (long long)no, (long long)out_capacity_per_station, h->o_abs, h->n_abs - (unsigned long long)(T - 1)};
     // outputs o0 .. o0+no-1 need inputs up to floor((o0+no-1) M / L) <= n_abs + n_in - 1 by construction
-    hipLaunchKernelGGL(k_channelize, dim3((unsigned)((no + kTile - 1) / kTile), (unsigned)h->C), dim3(256), 0, s, d, h->win, h->taps, h->inc,
+    hipLaunchKernelGGL(k_channelize, dim3((unsigned)((no + kTile - 1) / kTile), (unsigned)h->C), dim3(256), 0, s, d, win, h->taps, h->inc,
                        reinterpret_cast<float2*>(d_out));
     if (hipGetLastError() != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "k_channelize launch failed");
-    // keep the last T-1 input samples as the next call's history
-    if (hipMemcpyAsync(h->win, h->win + n_in, sizeof(float2) * (size_t)(T - 1), hipMemcpyDeviceToDevice, s) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "history copy failed");
+    // the last T-1 samples of [history ++ block] are the next call's history: copied into the OTHER window, so source and
+    // destination never overlap however short the block is (n_in = 625 < T - 1 = 639 is a legal call)
+    if (hipMemcpyAsync(next, win + n_in, sizeof(float2) * (size_t)(T - 1), hipMemcpyDeviceToDevice, s) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "history copy failed");
+    if (hipEventRecord(h->done, s) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "event record failed");
+    h->have_done = true;
+    h->cur ^= 1;
     h->n_abs += n_in; h->o_abs += no;
     *n_out = no;
     return FMD_OK;

@@ -10,13 +10,19 @@ from __future__ import annotations
 
 
 def channel_range(total_channels: int, world_size: int, rank: int) -> tuple[int, int]:
-    """Contiguous range [lo, hi) of global channel indices owned by `rank` (remainder spread over the first ranks)."""
+    """Contiguous range [lo, hi) of global channel indices owned by `rank` (remainder spread over the first ranks).
+    AudioGather needs equal shards: use padded_shard() for the per-rank batch size when total % world != 0."""
     if not (0 <= rank < world_size):
         raise ValueError("rank out of range")
     base, rem = divmod(total_channels, world_size)
     lo = rank * base + min(rank, rem)
     hi = lo + base + (1 if rank < rem else 0)
     return lo, hi
+
+
+def padded_shard(total_channels: int, world_size: int) -> int:
+    """Per-rank batch size that covers `total_channels` with EQUAL shards (the last ranks carry idle padding channels)."""
+    return -(-total_channels // world_size)
 
 
 def pcm16_frames(audio):
@@ -40,6 +46,14 @@ class AudioGather:
                  dtype=None, dst: int = 0):
         if mode not in ("root", "all"):
             raise ValueError("mode must be 'root' or 'all'")
+        if not (0 <= dst < world_size):
+            raise ValueError("dst out of range")
+        # every rank contributes the same number of channels (the gathered block is a plain concatenation in rank order):
+        # checked once, collectively, so that an uneven shard fails on every rank alike instead of corrupting the gather
+        sizes = [None] * world_size
+        dist.all_gather_object(sizes, int(c_local))
+        if len(set(sizes)) != 1:
+            raise ValueError(f"AudioGather needs equal shards on every rank, got {sizes}: pad the last shard with idle channels")
         self.dist, self.torch, self.mode, self.dst = dist, torch, mode, dst
         self.dtype = dtype if dtype is not None else torch.float32
         self.rank = dist.get_rank()
@@ -63,17 +77,10 @@ class AudioGather:
         """Start the gather of staging slot s (already filled on the current stream)."""
         # the collectives move bytes: neither RCCL nor gloo has a 16-bit integer type
         as_bytes = (lambda t: t.view(self.torch.uint8)) if self.dtype == self.torch.int16 else (lambda t: t)
-        if self.mode == "root":
+        if self.mode == "root":   # the mode is fixed at construction: no per-rank fallback that could desynchronise the collective
             parts = [as_bytes(t) for t in self.out[s].chunk(self.world, dim=0)] if self.rank == self.dst else None
-            try:
-                self.handles[s] = self.dist.gather(as_bytes(self.stage[s]), parts, dst=self.dst, async_op=True)
-                return s
-            except (RuntimeError, NotImplementedError) as e:   # a backend without gather: raised before anything is sent, on every rank alike
-                import sys
-                print(f"AudioGather: dist.gather unavailable ({e}); falling back to all_gather", file=sys.stderr)
-                self.mode = "all"
-                self.out = [o if o is not None else self.torch.empty((self.world * self.stage[0].shape[0],) + tuple(self.stage[0].shape[1:]),
-                                                                       dtype=self.dtype, device=self.stage[0].device) for o in self.out]
+            self.handles[s] = self.dist.gather(as_bytes(self.stage[s]), parts, dst=self.dst, async_op=True)
+            return s
         self.handles[s] = self.dist.all_gather_into_tensor(as_bytes(self.out[s]), as_bytes(self.stage[s]), async_op=True)
         return s
 

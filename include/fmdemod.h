@@ -5,8 +5,13 @@
  * src/fm_demod/broadcast_fm_demod.h:91-299) advanced in lock-step on one GPU.  Every entry point
  * names the reference member it replaces.  Plain pointers and sizes only; no C++ / torch types.
  *
- * Threading (same contract as the reference): one caller thread per handle; outputs are views
- * that stay valid until the next fmd_process_* call on that handle.
+ * Threading (same contract as the reference): one caller thread per handle.
+ *
+ * Output lifetime — ONE rule for every output view and getter (fmd_audio_dev, fmd_rds_dev, fmd_get_*): the outputs of a
+ * block stay valid while at most FMD_OUTPUT_LIFETIME_BLOCKS (= 5) further fmd_process_* calls have been made on the handle;
+ * the call after that reuses the block's buffers.  (The reference keeps one block: "valid until the next Process",
+ * broadcast_fm_demod.h:242-256.)  A consumer that may fall further behind tells the library so with
+ * fmd_release_outputs(): the library then orders the reuse behind the consumer's stream.
  *
  * Data layouts (channel-major, time contiguous per channel):
  *   IQ in      cf32 [C][N][2] float  (or u8 [C][N][2], RTL-SDR style, converted as `(float)u8 - 127`,
@@ -24,7 +29,9 @@
 extern "C" {
 #endif
 
-#define FMD_API_VERSION 1
+#define FMD_API_VERSION 2
+/* further fmd_process_* calls during which a block's outputs stay valid (see the lifetime rule above) */
+#define FMD_OUTPUT_LIFETIME_BLOCKS 5
 
 typedef struct fmd_handle_s* fmd_handle;
 
@@ -35,7 +42,9 @@ enum {
                                 (reference Process(): silent return, broadcast_fm_demod.cpp:311-313) */
     FMD_ERR_DEVICE = -3,     /* HIP runtime error, see fmd_last_error */
     FMD_ERR_NO_DEVICE = -4,  /* no usable MI355X: the library has NO CPU fallback */
-    FMD_ERR_NAME = -5        /* unknown stream name */
+    FMD_ERR_NAME = -5,       /* unknown stream name */
+    FMD_ERR_STATE = -6       /* an earlier fmd_process_* call failed part-way (or the pilot-PLL hand-over watchdog fired): the
+                                per-channel state is no longer the state after a whole number of blocks; call fmd_reset */
 };
 
 /* reference Broadcast_FM_Demod_Controls::AudioOut (broadcast_fm_demod.h:80) */
@@ -90,6 +99,8 @@ typedef struct {
 } fmd_coeffs;
 
 int         fmd_api_version(void);
+/* == FMD_OUTPUT_LIFETIME_BLOCKS of the library that was loaded */
+int         fmd_output_lifetime_blocks(void);
 const char* fmd_status_string(int status);
 /* number of usable gfx950 devices; <= 0 means every other call fails with FMD_ERR_NO_DEVICE */
 int         fmd_device_count(void);
@@ -114,9 +125,10 @@ int fmd_get_coeffs(fmd_handle h, int channel, fmd_coeffs* k);
  * *_dev: `d_iq` is a DEVICE pointer.  The call returns without synchronising.  The block is read after everything
  * already queued on `stream` (hipStream_t, NULL = default stream), and work queued on `stream` AFTER the call is
  * ordered behind the library's last read of `d_iq`, so the buffer may be refilled in stream order.  The stages of
- * the block run on the library's own streams and overlap with the neighbouring blocks' stages (up to three blocks in
- * flight); outputs become readable after fmd_synchronize / fmd_wait_outputs and stay valid until the second
- * next fmd_process_* call.  *_host: `iq` is a host pointer; copies, runs, synchronises. */
+ * the block run on the library's own streams and overlap with the neighbouring blocks' stages (up to six blocks in
+ * flight); outputs become readable after fmd_synchronize / fmd_wait_outputs and stay valid as the lifetime rule at the
+ * top of this header says.  *_host: `iq` is a host pointer; copies, runs, synchronises.
+ * A call that fails with FMD_ERR_DEVICE after some of its kernels were queued leaves the handle in FMD_ERR_STATE. */
 int fmd_process_cf32_dev(fmd_handle h, const float* d_iq, int n_channels, int n_samples, void* stream);
 int fmd_process_u8_dev(fmd_handle h, const uint8_t* d_iq, int n_channels, int n_samples, void* stream);
 int fmd_process_cf32_host(fmd_handle h, const float* iq, int n_channels, int n_samples);
@@ -124,6 +136,10 @@ int fmd_process_u8_host(fmd_handle h, const uint8_t* iq, int n_channels, int n_s
 int fmd_synchronize(fmd_handle h);
 /* make `stream` wait (on the device, no host block) until the newest block's outputs are complete */
 int fmd_wait_outputs(fmd_handle h, void* stream);
+/* The consumer's side of the lifetime rule: everything queued on `stream` so far (the kernels / copies that read the newest
+ * block's output views) must finish before the library overwrites those views, however many blocks are submitted meanwhile.
+ * Records an event on `stream`; the library's writers of that buffer slot wait for it on the device.  Never blocks the host. */
+int fmd_release_outputs(fmd_handle h, void* stream);
 
 /* OnAudioOut() / GetAudioOut() (broadcast_fm_demod.h:256,297): device views of the current block */
 int fmd_audio_dev(fmd_handle h, const float** d_audio /* [C][n_audio][2] */);
@@ -149,45 +165,21 @@ int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats
 
 const char* fmd_last_error(fmd_handle h);
 
+/* Per-channel state snapshot / restore (SURVEY.md §5 "checkpoint / resume"; what moving a station between handles or GPUs
+ * needs): every filter history, AGC gain, loop integrator, NCO phase, BPSK synchroniser and Manchester decoder variable of ONE
+ * channel — the member variables of one reference Broadcast_FM_Demod (broadcast_fm_demod.h:94-227) — as an opaque,
+ * self-describing blob of fmd_state_size() bytes.  Both calls synchronise the handle first.  A blob can be restored into any
+ * channel of any handle with the same fs_baseband; the restored channel then continues bit-identically.  Controls are not
+ * part of the blob (fmd_get_controls / fmd_set_controls). */
+size_t fmd_state_size(fmd_handle h);
+int    fmd_get_state(fmd_handle h, int channel, void* blob, size_t cap_bytes);
+int    fmd_set_state(fmd_handle h, int channel, const void* blob, size_t n_bytes);
+
 /* Differential Manchester decode of the RDS symbol stream on the GPU, one decoder per channel
  * (reference src/rds_decoder/differential_manchester_decoder.h:25-60; the 16-byte buffer size is the
  * one src/app.cpp:13-20 uses).  bytes: [C][cap_bytes]; counts[c] = bytes appended for channel c this
  * block (multiples of 16). */
 int fmd_get_rds_bytes(fmd_handle h, uint8_t* bytes, int cap_bytes_per_channel, int* counts);
-
-/* Per-kernel timing with HIP events recorded on the processing stream (for bench.py's roofline figures).
- * on = 1: every fmd_process_* call brackets each kernel of the sequence with events; on = 2: k_pilot_pll (the dominant
- * kernel) of every block, the other kernels of every 4th block — the brackets are extra queue packets between dependent
- * kernels and cost the pipelined step a few percent; fmd_profile_read synchronises, accumulates and clears them. */
-typedef struct {
-    char   name[32];     /* kernel name as it appears in rocprofv3 kernel traces (prefix match) */
-    double total_ms;     /* sum of launch durations since the last read */
-    int    launches;
-} fmd_kernel_time;
-/* Self-test hook: evaluates the kernels' atan2f on the device for n host-side (y, x) pairs, so tests can compare
- * the device math bit-for-bit with the host libm the reference links (std::atan2, reference fm_demod.cpp:40). */
-int fmd_selftest_atan2(const float* y, const float* x, float* out, size_t n);
-/* Same for the table-driven form the discriminator (k_front) uses: identical values, fewer issued instructions. */
-int fmd_selftest_atan2_table(const float* y, const float* x, float* out, size_t n);
-/* ... and its variant for u8 IQ at 256 kSa/s, whose operands are the integers -127..128 (only 0/0 is special there). */
-int fmd_selftest_atan2_table_u8(const float* y, const float* x, float* out, size_t n);
-/* Same for the short form k_pilot_pll's phase detector uses on a locked loop: out[i] is only meaningful where ok[i] != 0, and
- * there it must equal atan2f(y[i], x[i]) bit-for-bit (DESIGN.md "Pilot PLL"). */
-int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t* ok, size_t n);
-
-/* Counters of k_pilot_pll's frequency speculation since creation / the last reset (DESIGN.md "Pilot PLL"):
- * out8[0] = 128-sample chunks, summed over wavefronts (4 channels each); out8[1] = of those, chunks run with the plain serial
- * iteration (wavefront out of lock); out8[2] = spans redone with the reference forms (a short form outside its domain);
- * out8[3] = spans, out8[4] = samples committed, both summed over channels (ratio = samples per 16-sample span);
- * out8[6], out8[7] = shader-clock cycles and 100 MHz real-time ticks of one wavefront per launch (ratio x 100 = core MHz).
- * Results never depend on any of them; they explain k_pilot_pll's duration. */
-int fmd_get_spec_stats(fmd_handle h, uint64_t* out8, int reset);
-
-/* on = 0: off; 1: timing events on every kernel of every block; 2: the dominant kernel every block, the others every 4th;
- * 3: every kernel of every 4th block plus the dominant kernel of the block behind it (what bench.py uses: ~1 % of the step) */
-int fmd_profile_enable(fmd_handle h, int on);
-int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out);
-
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Wideband channeliser (SURVEY.md §8f row 3 / BASELINE configs[4]; NOT part of the reference, which tunes one station in
@@ -215,7 +207,9 @@ int fmd_chan_reset(fmd_channelizer h);
 int fmd_chan_info(fmd_channelizer h, int* L, int* M, int* taps_per_phase, int* n_stations);
 int fmd_chan_get_taps(fmd_channelizer h, float* taps, size_t cap_floats);
 /* d_wide: [n_in][2] cf32 on the device; n_in * L must be a multiple of M (625 input samples per 16 outputs at 10 M -> 256 k).
- * d_out: [n_stations][*n_out][2] cf32 on the device.  Asynchronous on `stream`. */
+ * d_out: [n_stations][out_capacity_per_station][2] cf32 on the device — station k's *n_out samples start at row k (row
+ * stride = out_capacity_per_station; pass the exact n_out to get the dense [C][n_out] layout fmd_process_cf32_dev takes).
+ * Asynchronous on `stream`; consecutive calls may use different streams (the library orders them). */
 int fmd_chan_process_cf32_dev(fmd_channelizer h, const float* d_wide, size_t n_in, float* d_out, size_t out_capacity_per_station,
                               size_t* n_out, void* stream);
 const char* fmd_chan_last_error(fmd_channelizer h);

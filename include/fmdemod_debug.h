@@ -1,0 +1,52 @@
+/* fmdemod_debug.h — test, self-check and profiling hooks of libfmdemod.so.
+ *
+ * NOT part of the drop-in boundary (include/fmdemod.h): nothing here has a counterpart in the reference's demodulator API.
+ * tests/ use the self-tests to compare the device math with the host libm the reference links; bench.py uses the profiling
+ * hooks for its roofline figures.  Results of the demodulator never depend on any of these calls.
+ */
+#ifndef FMDEMOD_DEBUG_H
+#define FMDEMOD_DEBUG_H
+
+#include "fmdemod.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Per-kernel timing with HIP events recorded on the processing stream (for bench.py's roofline figures).
+ * on = 1: every fmd_process_* call brackets each kernel of the sequence with events; on = 2: k_pilot_pll (the dominant
+ * kernel) of every block, the other kernels of every 4th block — the brackets are extra queue packets between dependent
+ * kernels and cost the pipelined step a few percent; fmd_profile_read synchronises, accumulates and clears them. */
+typedef struct {
+    char   name[32];     /* kernel name as it appears in rocprofv3 kernel traces (prefix match) */
+    double total_ms;     /* sum of launch durations since the last read */
+    int    launches;
+} fmd_kernel_time;
+/* Self-test hook: evaluates the kernels' atan2f on the device for n host-side (y, x) pairs, so tests can compare
+ * the device math bit-for-bit with the host libm the reference links (std::atan2, reference fm_demod.cpp:40). */
+int fmd_selftest_atan2(const float* y, const float* x, float* out, size_t n);
+/* Same for the table-driven form the discriminator (k_front) uses: identical values, fewer issued instructions. */
+int fmd_selftest_atan2_table(const float* y, const float* x, float* out, size_t n);
+/* ... and its variant for u8 IQ at 256 kSa/s, whose operands are the integers -127..128 (only 0/0 is special there). */
+int fmd_selftest_atan2_table_u8(const float* y, const float* x, float* out, size_t n);
+/* Same for the short form k_pilot_pll's phase detector uses on a locked loop: out[i] is only meaningful where ok[i] != 0, and
+ * there it must equal atan2f(y[i], x[i]) bit-for-bit (DESIGN.md "Pilot PLL"). */
+int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t* ok, size_t n);
+
+/* Counters of k_pilot_pll's frequency speculation since creation / the last reset (DESIGN.md "Pilot PLL"):
+ * out8[0] = 128-sample chunks, summed over wavefronts (4 channels each); out8[1] = of those, chunks run with the plain serial
+ * iteration (wavefront out of lock); out8[2] = spans redone with the reference forms (a short form outside its domain);
+ * out8[3] = spans, out8[4] = samples committed, both summed over channels (ratio = samples per 16-sample span);
+ * out8[6], out8[7] = shader-clock cycles and 100 MHz real-time ticks of one wavefront per launch (ratio x 100 = core MHz).
+ * Results never depend on any of them; they explain k_pilot_pll's duration. */
+int fmd_get_spec_stats(fmd_handle h, uint64_t* out8, int reset);
+
+/* on = 0: off; 1: timing events on every kernel of every block; 2: the dominant kernel every block, the others every 4th;
+ * 3: every kernel of every 4th block plus the dominant kernel of the block behind it (what bench.py uses: ~1 % of the step) */
+int fmd_profile_enable(fmd_handle h, int on);
+int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

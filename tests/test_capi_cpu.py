@@ -27,8 +27,50 @@ def test_library_exports_declared_abi(pkg):
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/fmdemod.h but not exported"
-    assert lib.fmd_api_version() == 1
+    assert lib.fmd_api_version() == 2
     assert lib.fmd_status_string(-4).decode().startswith("no gfx950")
+    assert "fmd_reset" in lib.fmd_status_string(-6).decode()
+
+
+def test_debug_hooks_live_in_their_own_header(pkg):
+    """The drop-in boundary (include/fmdemod.h) holds only entry points with a counterpart in the reference's demodulator
+    API; self-tests and profiling hooks are declared in include/fmdemod_debug.h."""
+    product = set(pkg.declared_symbols(debug=False))
+    everything = set(pkg.declared_symbols())
+    hooks = everything - product
+    assert hooks == {"fmd_selftest_atan2", "fmd_selftest_atan2_table", "fmd_selftest_atan2_table_u8", "fmd_selftest_atan2_small",
+                     "fmd_get_spec_stats", "fmd_profile_enable", "fmd_profile_read"}
+    assert {"fmd_release_outputs", "fmd_get_state", "fmd_set_state", "fmd_state_size", "fmd_output_lifetime_blocks"} <= product
+    # both headers compile as plain C
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src = Path(td) / "c.c"
+        src.write_text('#include "fmdemod.h"\n#include "fmdemod_debug.h"\nint main(void) { return FMD_OUTPUT_LIFETIME_BLOCKS == 5 ? 0 : 1; }\n')
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(Path(td) / "c")], check=True)
+        subprocess.run([str(Path(td) / "c")], check=True)
+
+
+def test_one_output_lifetime_contract(pkg):
+    """The number of further blocks an output view survives is stated once (FMD_OUTPUT_LIFETIME_BLOCKS) and the header, the
+    library, the Python binding and INTEGRATION.md agree on it."""
+    lib = pkg.load_library()
+    n = lib.fmd_output_lifetime_blocks()
+    from fm_radio_amd import capi
+    assert n == capi.FMD_OUTPUT_LIFETIME_BLOCKS == 5
+    hdr = (ROOT / "include" / "fmdemod.h").read_text()
+    assert f"#define FMD_OUTPUT_LIFETIME_BLOCKS {n}" in hdr
+    assert "second\n * next" not in hdr and "three blocks in" not in hdr      # the stale round-1 wordings
+    integ = (ROOT / "INTEGRATION.md").read_text()
+    assert "FMD_OUTPUT_LIFETIME_BLOCKS" in integ and "five more blocks" not in integ
+
+
+def test_library_does_not_touch_the_environment(pkg):
+    """Loading libfmdemod.so must not mutate the host process's environment (round 1 had a constructor calling setenv)."""
+    code = ("import ctypes, os; os.environ.pop('GPU_MAX_HW_QUEUES', None); "
+            f"ctypes.CDLL(r'{pkg.lib_path()}'); print(os.environ.get('GPU_MAX_HW_QUEUES'), ctypes.CDLL(None).getenv(b'GPU_MAX_HW_QUEUES'))")
+    import sys
+    out = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True).stdout.split()
+    assert out == ["None", "0"], out
 
 
 def test_no_gpu_means_loud_failure(pkg):
@@ -45,7 +87,7 @@ def test_bad_configs_rejected(pkg):
     lib = pkg.load_library()
     h = C.c_void_p()
     for cfg in (pkg.Config(0, 8192, 1_024_000, -1, 0), pkg.Config(1, 1000, 1_024_000, -1, 0), pkg.Config(1, 8192, 48000, -1, 0),
-                pkg.Config(1, 4096, 2_048_000, -1, 0)):
+                pkg.Config(1, 4096, 2_048_000, -1, 0), pkg.Config(1, 8192, 1_024_000, -1, 1 << 20)):   # last: an unknown flag bit
         assert lib.fmd_create(C.byref(cfg), C.byref(h)) == -1
         assert not h.value
 

@@ -23,6 +23,51 @@ def test_channel_range_partitions():
         assert seen == list(range(total))
     with pytest.raises(ValueError):
         pkg.channel_range(8, 2, 2)
+    assert pkg.padded_shard(65536, 8) == 8192 and pkg.padded_shard(10, 4) == 3 and pkg.padded_shard(7, 8) == 1
+
+
+def _uneven_worker(rank: int, world: int, port: int, tmp: str):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import fmradio_loader as fl
+    pkg = fl.load()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = pkg.channel_range(7, world, rank)          # 4 + 3 channels: not a legal gather layout
+    try:
+        pkg.AudioGather(dist, torch, hi - lo, 16, world, torch.device("cpu"))
+        outcome = "constructed"
+    except ValueError as e:
+        outcome = "ValueError" if "equal shards" in str(e) else f"other: {e}"
+    # equal, padded shards are accepted on every rank
+    pkg.AudioGather(dist, torch, pkg.padded_shard(7, world), 16, world, torch.device("cpu"))
+    with open(os.path.join(tmp, f"uneven{rank}.txt"), "w") as f:
+        f.write(outcome)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_fail_on_every_rank_alike(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_uneven_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert [(tmp_path / f"uneven{r}.txt").read_text() for r in range(2)] == ["ValueError", "ValueError"]
+
+
+def test_bench_refuses_a_world_size_mismatch_and_launches_its_own_ranks():
+    """bench.py --gpus N: under a launcher WORLD_SIZE must equal N (a mismatch is an error, not silently ignored); without a
+    launcher it starts `torch.distributed.run` as a child process itself and returns the child's exit code (here, without a
+    GPU, the ranks fail: the parent must report that with a non-zero code and no result line)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+    if torch.cuda.is_available():
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--preroll", "0", "--channels", "8",
+                        "--backend", "gloo", "--share-gpu", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and '"metric"' not in r.stdout
 
 
 def _worker(rank: int, world: int, port: int, tmp: str, mode: str, pcm16: bool):
