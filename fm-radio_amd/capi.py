@@ -148,6 +148,7 @@ def load_library():
     L.fmd_selftest_atan2_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.fmd_selftest_atan2_table_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.fmd_selftest_atan2_small.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.fmd_selftest_fast_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.fmd_get_spec_stats.argtypes = [H, C.c_void_p, C.c_int]
     L.fmd_profile_enable.argtypes = [H, C.c_int]
     L.fmd_profile_read.argtypes = [H, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]
@@ -175,6 +176,18 @@ def selftest_atan2(y: np.ndarray, x: np.ndarray, table_form: bool = False) -> np
     L = load_library()
     fn = L.fmd_selftest_atan2_table_u8 if table_form == "u8" else (L.fmd_selftest_atan2_table if table_form else L.fmd_selftest_atan2)
     rc = fn(y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), y.size)
+    if rc != FMD_OK:
+        raise FmdError(rc, load_library().fmd_last_error(None).decode())
+    return out
+
+
+def selftest_fast_math(kind: str, a: np.ndarray, b: np.ndarray | None = None) -> np.ndarray:
+    """The tolerance mode's primitives on the device: kind in {"atan2", "sin_turns", "cos_turns"}."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = a if b is None else np.ascontiguousarray(b, np.float32)
+    out = np.empty_like(a)
+    rc = load_library().fmd_selftest_fast_math({"atan2": 0, "sin_turns": 1, "cos_turns": 2}[kind], a.ctypes.data_as(C.c_void_p),
+                                               b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), a.size)
     if rc != FMD_OK:
         raise FmdError(rc, load_library().fmd_last_error(None).decode())
     return out

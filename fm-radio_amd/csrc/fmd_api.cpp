@@ -113,7 +113,7 @@ int dev_alloc(fmd_handle h, T** p, size_t count) {
 }
 
 constexpr unsigned kKnownFlags = FMD_FLAG_KEEP_TAPS | FMD_FLAG_NO_PIPELINE | FMD_FLAG_PLL_TIME_PARALLEL | FMD_FLAG_PLL_LOW_WORK | FMD_FLAG_PLL_K8 |
-                                 FMD_FLAG_PLL_STREAM_ORDER;
+                                 FMD_FLAG_PLL_STREAM_ORDER | FMD_FLAG_FAST_MATH;
 
 bool config_ok(const fmd_config* c, int* m) {
     if (!c || c->n_channels <= 0) return false;
@@ -165,6 +165,21 @@ int upload_controls(fmd_handle h, hipStream_t s) {
     h->deemph_on = any != 0;
     h->controls_dirty = false;
     return FMD_OK;
+}
+
+// Tables of the parallel form of the pilot peak filter (fmd_kernels.h PilotFastTab), in double precision.
+void design_pilot_fast(const fmd_coeffs& k, PilotFastTab* t) {
+    const double a0 = k.pilot_a[0], a1 = k.pilot_a[1];
+    struct M2 { double a, b, c, d; };
+    auto mul = [](const M2& x, const M2& y) { return M2{x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d}; };
+    const M2 A{a1, a0, 1.0, 0.0};
+    M2 P = A;                                   // A^(k+1)
+    for (int i = 0; i < kPilotSeg; i++) { t->h1[i] = (float)P.a; t->h2[i] = (float)P.b; if (i + 1 < kPilotSeg) P = mul(A, P); }
+    M2 S = P;                                   // M = A^kPilotSeg
+    for (int s = 0; s < 6; s++) { t->m[s][0] = (float)S.a; t->m[s][1] = (float)S.b; t->m[s][2] = (float)S.c; t->m[s][3] = (float)S.d; S = mul(S, S); }
+    M2 L{1.0, 0.0, 0.0, 1.0};
+    for (int l = 0; l < 64; l++) { t->mlane[l][0] = (float)L.a; t->mlane[l][1] = (float)L.b; t->mlane[l][2] = (float)L.c; t->mlane[l][3] = (float)L.d; L = mul(P, L); }
+    t->k = k.pilot_b[0]; t->a0 = k.pilot_a[0]; t->a1 = k.pilot_a[1];
 }
 
 void fill_ctx_coeffs(fmd_handle h) {
@@ -467,6 +482,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     h->bytes_cap = 16 * (d.n_rds / 256 + 1);
     h->ctx.bytes_cap = h->bytes_cap;
     h->ctx.keep_taps = (cfg->flags & FMD_FLAG_KEEP_TAPS) ? 1 : 0;
+    h->ctx.fast = (cfg->flags & FMD_FLAG_FAST_MATH) ? 1 : 0;
 
     fmd_controls def;
     fmd_default_controls(&def);
@@ -507,10 +523,19 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     if (!rc) rc = dev_alloc(h, &b.mix, C * 2);
     if (!rc) rc = dev_alloc(h, &b.state, (size_t)S_NUM_FIELDS * C);
     if (!rc) rc = dev_alloc(h, &b.spec_stats, 8);
+    if (!rc && h->ctx.fast) {
+        rc = dev_alloc(h, &b.pilot_tab, 1);
+        if (!rc) {
+            PilotFastTab tab;
+            design_pilot_fast(h->base, &tab);
+            if (hipMemcpyAsync(b.pilot_tab, &tab, sizeof(tab), hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
+                hipStreamSynchronize(h->own_stream) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "pilot table upload failed");
+        }
+    }
     // per-wavefront hand-over between consecutive k_pilot_pll launches: the time-parallel kernel only, pipelined mode only
     // (the low-work kernel k_pilot_pll_pairs has no chain argument: its launches must stay ordered by the stream)
     const bool time_parallel = d.C <= h->ctx.pll_time_parallel_max_channels;
-    h->pll_chained = h->pipelined && time_parallel && effective_channels(d) <= 3328 && !(cfg->flags & (FMD_FLAG_PLL_STREAM_ORDER | FMD_FLAG_PLL_LOW_WORK));
+    h->pll_chained = h->pipelined && !h->ctx.fast && time_parallel && effective_channels(d) <= 3328 && !(cfg->flags & (FMD_FLAG_PLL_STREAM_ORDER | FMD_FLAG_PLL_LOW_WORK));
     h->pll_waves = (effective_channels(d) <= h->ctx.pll_k16_max_channels) ? (d.C + 3) / 4 : (d.C + 7) / 8;
     if (!rc) rc = dev_alloc(h, &b.pll_chain, (size_t)h->pll_waves + 1);
     if (rc) return bail(rc);
@@ -813,6 +838,11 @@ int fmd_selftest_atan2(const float* y, const float* x, float* out, size_t n) { r
 int fmd_selftest_atan2_table(const float* y, const float* x, float* out, size_t n) { return selftest_atan2_host(y, x, out, nullptr, n, 1); }
 int fmd_selftest_atan2_table_u8(const float* y, const float* x, float* out, size_t n) { return selftest_atan2_host(y, x, out, nullptr, n, 2); }
 
+int fmd_selftest_fast_math(int kind, const float* a, const float* b, float* out, size_t n) {
+    if (kind < 0 || kind > 2) return FMD_ERR_ARG;
+    return selftest_atan2_host(a, b ? b : a, out, nullptr, n, 10 + kind);
+}
+
 int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t* ok, size_t n) {
     if (!ok) return FMD_ERR_ARG;
     return selftest_atan2_host(y, x, out, ok, n);
@@ -844,12 +874,13 @@ int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out) {
             float ms = 0.0f;
             HIP_TRY(h, hipEventElapsedTime(&ms, pm->t0[i], pm->t1[i]));
             int slot = -1;
-            for (int j = 0; j < n; j++) if (std::strncmp(out[j].name, kStageName[i], sizeof(out[j].name)) == 0) { slot = j; break; }
+            const char* nm = (h->ctx.fast && i == ST_POWER) ? "k_pilot_fast" : (h->ctx.fast && i == ST_PLL) ? "k_pll_fast" : kStageName[i];
+            for (int j = 0; j < n; j++) if (std::strncmp(out[j].name, nm, sizeof(out[j].name)) == 0) { slot = j; break; }
             if (slot < 0) {
                 if (n >= cap) continue;
                 slot = n++;
                 std::memset(&out[slot], 0, sizeof(out[slot]));
-                std::strncpy(out[slot].name, kStageName[i], sizeof(out[slot].name) - 1);
+                std::strncpy(out[slot].name, nm, sizeof(out[slot].name) - 1);
             }
             out[slot].total_ms += ms;
             out[slot].launches += 1;

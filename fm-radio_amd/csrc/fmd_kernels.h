@@ -47,6 +47,18 @@ enum StateField : int {
     S_NUM_FIELDS
 };
 
+// FMD_FLAG_FAST_MATH: the pilot peak filter y[n] = K x[n-2] + a1 y[n-1] + a0 y[n-2] evaluated as a parallel scan (k_pilot_fast):
+// each lane runs kPilotSeg samples from a zero state, the segment end states are combined across the wavefront with powers of
+// the transition matrix A = [[a1, a0], [1, 0]], and the homogeneous solution is added back.  Designed on the host in double
+// precision (fmd_api.cpp design_pilot_fast).
+static constexpr int kPilotSeg = 16;
+struct PilotFastTab {
+    float h1[kPilotSeg], h2[kPilotSeg];   // y[k] += h1[k] y[-1] + h2[k] y[-2]: first row of A^(k+1)
+    float m[6][4];                        // M^(2^s), M = A^kPilotSeg, as (m00, m01, m10, m11): steps of the cross-lane scan
+    float mlane[64][4];                   // M^l: what the chunk's initial state contributes to the start state of lane l
+    float k, a0, a1;
+};
+
 struct Dims {
     int C;          // channels
     int N;          // baseband samples per block
@@ -99,6 +111,7 @@ struct Buffers {
     float*  deemph;         // [C][4]  b0,b1,a0,flag
     float*  mix;            // [C][2]  audio mode (as float), stereo mix factor
     float*  state;          // [S_NUM_FIELDS][C]
+    PilotFastTab* pilot_tab;         // FMD_FLAG_FAST_MATH only
     unsigned int* pll_chain;         // [wavefronts of k_pilot_pll + 1] last block number each wavefront completed; [last] = watchdog flag
     unsigned long long* spec_stats;  // [8] speculation counters: pll {chunks, general, replayed, -}, rds {chunks, general, replayed, -}
 };
@@ -114,6 +127,7 @@ struct LaunchCtx {
     RdsTaps rds_taps;
     LoopCoeffs loops;
     int keep_taps;
+    int fast;                             // FMD_FLAG_FAST_MATH: the tolerance-mode kernels
     int any_deemph;
     int bytes_cap;
     int pll_time_parallel_max_channels;   // batches up to this size use the time-parallel PLL kernel, larger ones the low-work one

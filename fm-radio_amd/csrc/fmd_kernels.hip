@@ -76,7 +76,7 @@ __device__ __forceinline__ float4 load_iq2(const uchar2* p, size_t i) {
     return make_float4((float)v.x - 127.0f, (float)v.y - 127.0f, (float)v.z - 127.0f, (float)v.w - 127.0f);
 }
 
-template <typename InT, int TT = 512>
+template <typename InT, int TT = 512, bool FAST = false>
 __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
                                                float2* __restrict__ tail_out, float2* __restrict__ fm_out_iq,
                                                float* __restrict__ fm_out_plain, float* __restrict__ fo_tail_out, FrontTaps taps,
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
     float* dem = smem + G::OFF_DEM;                               // [NW-1]
     float* fo = smem + G::OFF_FO;                                 // [T+64]
     AtanTable* atab = reinterpret_cast<AtanTable*>(smem + G::OFF_ATAN);
-    atan_table_fill(atab, threadIdx.x, 256);                      // visible after the first barrier below
+    if constexpr (!FAST) atan_table_fill(atab, threadIdx.x, 256);   // visible after the first barrier below
 
     const int tiles = d.n_fm_out / T;
     const int c = blockIdx.x / tiles;
@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
 #pragma unroll
         for (int r = 0; r < PER; r++) {
             const int i = tid + 256 * r;
-            if (i < NW) theta[i] = fmd_atan2f_table<sizeof(InT) == 2>(buf[r].y, buf[r].x, atab);   // u8 IQ: small integers
+            if (i < NW) {
+                if constexpr (FAST) theta[i] = fast_atan2f(buf[r].y, buf[r].x);      // FMD_FLAG_FAST_MATH: ~21 instructions instead of ~60
+                else theta[i] = fmd_atan2f_table<sizeof(InT) == 2>(buf[r].y, buf[r].x, atab);   // u8 IQ: small integers
+            }
         }
     }
     __syncthreads();
@@ -1098,7 +1101,7 @@ __device__ __forceinline__ void fir8_quad(const float* __restrict__ ph, int P, i
     for (int v = 0; v < 4; v++) out[v] = (acc[v][0] + acc[v][2]) + (acc[v][1] + acc[v][3]);
 }
 
-template <int TA>
+template <int TA, bool FAST = false>
 __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict__ fm_out_iq, const float* __restrict__ pll_dt,
                                                 const float2* __restrict__ iq_tail_in, const float* __restrict__ dt_tail_in,
                                                 float2* __restrict__ iq_tail_out, float* __restrict__ dt_tail_out,
@@ -1149,18 +1152,37 @@ __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict
                 }
             }
         }
+        // FMD_FLAG_FAST_MATH: one hardware sine / cosine of the pilot phase per sample, the x2 and x3 harmonics by angle
+        // multiplication, the L-R phase offset as a rotation by a per-block constant
+        float co_cur = 1.f, so_cur = 0.f, co_prev = 1.f, so_prev = 0.f;
+        if constexpr (FAST) {
+            co_cur = fast_cos_turns(off_cur); so_cur = fast_sin_turns(off_cur);
+            co_prev = fast_cos_turns(off_prev); so_prev = fast_sin_turns(off_prev);
+        }
 #pragma unroll
         for (int r = 0; r < PER; r++) {
             const int e = tid + TA * r;
             if (e < XS) {
-                const float off = (s_lo + e < 0) ? off_prev : off_cur;   // history samples were mixed with last block's offset
-                const float2 m2 = harmonic_mix(xv[r], dv[r], 2.0f, off, off + 0.25f);
+                const bool hist = s_lo + e < 0;                          // history samples were mixed with last block's offset
+                float2 m2, m3;
+                if constexpr (FAST) {
+                    const float c1 = fast_cos_turns(dv[r]), s1 = fast_sin_turns(dv[r]);
+                    const float c2 = fmaf(c1, c1, -(s1 * s1)), s2 = (c1 + c1) * s1;
+                    const float co = hist ? co_prev : co_cur, so = hist ? so_prev : so_cur;
+                    const float c2o = fmaf(c2, co, -(s2 * so)), s2o = fmaf(s2, co, c2 * so);
+                    m2 = make_float2(fmaf(c2o, xv[r].x, -(xv[r].y * s2o)), fmaf(c2o, xv[r].y, xv[r].x * s2o));
+                    const float c3 = fmaf(c2, c1, -(s2 * s1)), s3 = fmaf(s2, c1, c2 * s1);
+                    m3 = make_float2(fmaf(c3, xv[r].x, -(xv[r].y * s3)), fmaf(c3, xv[r].y, xv[r].x * s3));
+                } else {
+                    const float off = hist ? off_prev : off_cur;
+                    m2 = harmonic_mix(xv[r], dv[r], 2.0f, off, off + 0.25f);
+                    m3 = harmonic_mix(xv[r], dv[r], 3.0f, 0.0f, 0.25f);
+                }
                 const int a4 = (e & 3) * P4 + (e >> 2);
                 lpr_ph[a4] = xv[r].x;
                 lmr_re_ph[a4] = m2.x;
                 lmr_im_ph[a4] = m2.y;
                 if (e >= 4) {
-                    const float2 m3 = harmonic_mix(xv[r], dv[r], 3.0f, 0.0f, 0.25f);
                     const int e8 = e - 4, a8 = (e8 & 7) * P8 + (e8 >> 3);
                     rds_re_ph[a8] = m3.x;
                     rds_im_ph[a8] = m3.y;
@@ -1219,7 +1241,7 @@ __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict
         // reference :500-510: estimate against the +-pi/2 constellation, every 10th output of the block
         const int ii = est_first + 10 * tid;
         if (ii < TA) {
-            const float ph = fmd_atan2f(res_lmr[ii], res_est_re[tid]);
+            const float ph = FAST ? fast_atan2f(res_lmr[ii], res_est_re[tid]) : fmd_atan2f(res_lmr[ii], res_est_re[tid]);
             const float half_pi = bits_f32(kHalfPiBits);
             lmr_est[(size_t)c * d.n_est + (i0 + ii) / 10] = (ph > 0.0f) ? (half_pi - ph) : (-half_pi - ph);
         }
@@ -1264,6 +1286,7 @@ __global__ __launch_bounds__(kWave) void k_lmr_phase(Dims d, const float* __rest
 // (ted_clock.cpp:18-44), Zero_Crossing_Detector, Trigger_Cooldown, and the differential Manchester
 // decoder (rds_decoder/differential_manchester_decoder.h:32-60).  Lane per channel.
 // =============================================================================================
+template <bool FAST>
 __global__ __launch_bounds__(kWave) void k_rds_sync(Dims d, float2* __restrict__ rds,
                                                     float* __restrict__ state, LoopCoeffs k, float* __restrict__ rds_sym,
                                                     float2* __restrict__ rds_raw_sym, int* __restrict__ rds_count,
@@ -1335,10 +1358,16 @@ __global__ __launch_bounds__(kWave) void k_rds_sync(Dims d, float2* __restrict__
             const float control = clampf(PI_pll * 1.0f, -1.0f, 1.0f);
             const float freq = fmaf(control, 10.0f, 0.0f);
             const float yy = fmaf(freq, Ts, mix_t);
-            mix_t = yy - round_half_away(yy);
-            float dt_cos = mix_t + 0.25f;
-            dt_cos = dt_cos - round_half_away(dt_cos);
-            const float ps = cheb_sine_scalar(mix_t), pc = cheb_sine_scalar(dt_cos);
+            float ps, pc;
+            if constexpr (FAST) {
+                mix_t = yy - rintf(yy);
+                ps = fast_sin_turns(mix_t); pc = fast_cos_turns(mix_t);
+            } else {
+                mix_t = yy - round_half_away(yy);
+                float dt_cos = mix_t + 0.25f;
+                dt_cos = dt_cos - round_half_away(dt_cos);
+                ps = cheb_sine_scalar(mix_t); pc = cheb_sine_scalar(dt_cos);
+            }
             const float iq_r = fmaf(pc, p, -(q * ps));
             const float iq_i = fmaf(p, ps, q * pc);
             // zero crossing on Q with hold-off
@@ -1368,7 +1397,7 @@ __global__ __launch_bounds__(kWave) void k_rds_sync(Dims d, float2* __restrict__
                 clock = 0.0f;
                 const float sr = dump_r, si = dump_i;
                 dump_r = 0.0f; dump_i = 0.0f;
-                const float phs = fmd_atan2f(si, sr);
+                const float phs = FAST ? fast_atan2f(si, sr) : fmd_atan2f(si, sr);
                 const float est = (phs > 0.0f) ? (half_pi - phs) : (-half_pi - phs);
                 pll_err = est * two_over_pi;
                 if (live) {
@@ -1476,6 +1505,8 @@ __global__ __launch_bounds__(256) void k_hilbert(Dims d, const float* __restrict
     if (tile == tiles - 1 && tid < 64) fo_tail_out[(size_t)c * 64 + tid] = row[d.n_fm_out - 64 + tid];
 }
 
+#include "fmd_kernels_fast.inc"
+
 __global__ void k_selftest_atan2(const float* __restrict__ y, const float* __restrict__ x, float* __restrict__ out,
                                  unsigned char* __restrict__ ok_out, size_t n, int table_form) {
     __shared__ AtanTable atab;
@@ -1483,7 +1514,10 @@ __global__ void k_selftest_atan2(const float* __restrict__ y, const float* __res
     __syncthreads();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (table_form == 2) {   // k_front's discriminator on u8 IQ (operands are small integers)
+    if (table_form == 10) { out[i] = fast_atan2f(y[i], x[i]); }                  // FMD_FLAG_FAST_MATH primitives
+    else if (table_form == 11) { out[i] = fast_sin_turns(y[i]); }
+    else if (table_form == 12) { out[i] = fast_cos_turns(y[i]); }
+    else if (table_form == 2) {   // k_front's discriminator on u8 IQ (operands are small integers)
         out[i] = fmd_atan2f_table<true>(y[i], x[i], &atab);
     } else if (table_form) {   // k_front's discriminator
         out[i] = fmd_atan2f_table(y[i], x[i], &atab);
@@ -1533,16 +1567,19 @@ __global__ void k_reset(Dims d, float* __restrict__ state) {
 // ---------------------------------------------------------------------------------------------
 // host-side stage launchers
 // ---------------------------------------------------------------------------------------------
-template <typename InT, int TT = 512>
+template <typename InT, int TT = 512, bool FAST = false>
 static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq, hipStream_t s) {
     using G = FrontGeom<TT>;
     const Dims& d = ctx.d;
+    if constexpr (!FAST) {
+        if (ctx.fast) return launch_front<InT, TT, true>(ctx, r, d_iq, s);
+    }
     if constexpr (TT == 512) {
-        if (d.n_fm_out % 1024 == 0) return launch_front<InT, 1024>(ctx, r, d_iq, s);
+        if (d.n_fm_out % 1024 == 0) return launch_front<InT, 1024, FAST>(ctx, r, d_iq, s);
     }
     const int tiles = d.n_fm_out / G::T;
     const size_t lds = sizeof(float) * G::LDS_FLOATS;
-    auto kern = k_front<InT, TT>;
+    auto kern = k_front<InT, TT, FAST>;
     FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), lds, s, d, d_iq, ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1],
                        ctx.b.fm_out_iq[r.buf], ctx.b.fm_out[r.buf], ctx.b.fo_tail[r.par ^ 1], ctx.front, ctx.any_deemph);
     return hipGetLastError();
@@ -1592,6 +1629,11 @@ hipError_t launch_stage_deemph(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
 
 hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
+    if (ctx.fast) {   // one wavefront per channel, the recurrence as a scan
+        FMD_LAUNCH(r, true, true, k_pilot_fast, dim3((unsigned)d.C), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[r.buf], ctx.b.pilot[r.buf], ctx.b.state,
+                   ctx.b.pilot_tab, (int)S_PILOT_POWER0 + r.buf);
+        return hipGetLastError();
+    }
     if (effective_channels(d) <= 2816) {   // the batches whose step is this kernel's latency (and whose PLL launches hand over per wavefront)
         FMD_LAUNCH(r, true, true, k_pilot_power<true>, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[r.buf], ctx.b.pilot[r.buf], ctx.b.state,
                    ctx.loops, (int)S_PILOT_POWER0 + r.buf);
@@ -1604,6 +1646,11 @@ hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
 
 hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
+    if (ctx.fast) {
+        FMD_LAUNCH(r, true, true, k_pll_fast, dim3((unsigned)((d.C + 3) / 4)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
+                   ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
+        return hipGetLastError();
+    }
     if (d.C > ctx.pll_time_parallel_max_channels) {
         FMD_LAUNCH(r, true, true, k_pilot_pll_pairs, dim3((unsigned)((d.C + kPllCh - 1) / kPllCh)), dim3(2 * kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf],
                    ctx.b.state, ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
@@ -1620,11 +1667,14 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int TA>
+template <int TA, bool FAST = false>
 static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
-    FMD_LAUNCH(r, true, true, k_extract<TA>, dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fm_out_iq[r.buf], b.pll_dt[r.buf],
+    if constexpr (!FAST) {
+        if (ctx.fast) return launch_extract_ta<TA, true>(ctx, r, s);
+    }
+    FMD_LAUNCH(r, true, true, (k_extract<TA, FAST>), dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fm_out_iq[r.buf], b.pll_dt[r.buf],
                        b.iq_tail[r.par], b.dt_tail[r.par], b.iq_tail[r.par ^ 1], b.dt_tail[r.par ^ 1], b.b_lpr, b.b_lmr, ctx.rds_taps, b.mix,
                        b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est, b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps);
 }
@@ -1639,14 +1689,22 @@ hipError_t launch_stage_extract(const LaunchCtx& ctx, SlotRef r, hipStream_t s) 
 hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
-    FMD_LAUNCH(r, true, true, k_rds_sync, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
-                       b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps);
+    if (ctx.fast) {
+        FMD_LAUNCH(r, true, true, k_rds_sync<true>, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
+                   b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps);
+    } else {
+        FMD_LAUNCH(r, true, true, k_rds_sync<false>, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
+                   b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps);
+    }
     return hipGetLastError();
 }
 
 template <typename InT, int TT = 512>
 static hipError_t prepare_front() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_front<InT, TT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front<InT, TT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(float) * FrontGeom<TT>::LDS_FLOATS));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_front<InT, TT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(sizeof(float) * FrontGeom<TT>::LDS_FLOATS));
 }
 

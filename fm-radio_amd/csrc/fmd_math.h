@@ -371,4 +371,56 @@ FMD_HD float cheb_sine_vector(float x) {
     return (x * cheb_poly(z)) * (z + -0.25f);
 }
 
+// ---------------------------------------------------------------------------------------------
+// FMD_FLAG_FAST_MATH — the tolerance mode (BASELINE north star: audio / L-R / RDS symbols within 1e-4 RMS of the
+// reference, RDS bits identical).  Same signal flow as the reference, cheaper arithmetic: a minimax arctangent instead of
+// libm's, the hardware sine/cosine (input in turns — the unit the reference's NCO phases already have) instead of the
+// chebyshev polynomial, free summation order.  Measured accuracies: tests/test_gpu_fast.py::test_fast_math_primitives.
+// ---------------------------------------------------------------------------------------------
+
+// atan(a) for a in [0, 1]: a * P(a^2), degree-15 odd minimax (8 terms), max error 1.3e-7 rad in float arithmetic
+FMD_HD float fast_atan_unit(float a) {
+    const float z = a * a;
+    float p = fmaf(-0.00405453285202384f, z, 0.021862823516130447f);
+    p = fmaf(p, z, -0.055912118405103683f);
+    p = fmaf(p, z, 0.09642180055379868f);
+    p = fmaf(p, z, -0.13908621668815613f);
+    p = fmaf(p, z, 0.19946563243865967f);
+    p = fmaf(p, z, -0.33329859375953674f);
+    p = fmaf(p, z, 0.9999993443489075f);
+    return p * a;
+}
+
+// atan2(y, x), every quadrant, max error ~3e-7 rad; atan2(+0, +0) = 0 like libm's (the u8 path produces exact zeros).
+// ~21 instructions, no division (one reciprocal), no table, no divergent special cases: NaN in -> NaN out.
+FMD_HD float fast_atan2f(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(fmaxf(ax, ay), 1.0e-37f), mn = fminf(ax, ay);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float a = mn * __builtin_amdgcn_rcpf(mx);
+#else
+    const float a = mn / mx;
+#endif
+    float r = fast_atan_unit(a);
+    r = (ay > ax) ? (bits_f32(kHalfPiBits) - r) : r;
+    r = (f32_bits(x) >> 31) ? (bits_f32(kPiBits) - r) : r;
+    return bits_f32((f32_bits(r) & 0x7fffffffu) | (f32_bits(y) & 0x80000000u));
+}
+
+// sin(2 pi t), cos(2 pi t) for t in turns (|t| <= 256: no range reduction needed for the phases of this chain)
+FMD_HD float fast_sin_turns(float t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sinf(t);
+#else
+    return (float)sin(6.283185307179586 * (double)t);
+#endif
+}
+FMD_HD float fast_cos_turns(float t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_cosf(t);
+#else
+    return (float)cos(6.283185307179586 * (double)t);
+#endif
+}
+
 }  // namespace fmd

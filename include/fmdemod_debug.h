@@ -33,6 +33,10 @@ int fmd_selftest_atan2_table_u8(const float* y, const float* x, float* out, size
  * there it must equal atan2f(y[i], x[i]) bit-for-bit (DESIGN.md "Pilot PLL"). */
 int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t* ok, size_t n);
 
+/* The FMD_FLAG_FAST_MATH primitives evaluated on the device, for accuracy checks against float64 on the host:
+ * kind 0: out = fast atan2(a, b); kind 1: out = sin(2 pi a) (hardware, argument in turns); kind 2: out = cos(2 pi a). */
+int fmd_selftest_fast_math(int kind, const float* a, const float* b, float* out, size_t n);
+
 /* Counters of k_pilot_pll's frequency speculation since creation / the last reset (DESIGN.md "Pilot PLL"):
  * out8[0] = 128-sample chunks, summed over wavefronts (4 channels each); out8[1] = of those, chunks run with the plain serial
  * iteration (wavefront out of lock); out8[2] = spans redone with the reference forms (a short form outside its domain);

@@ -26,11 +26,11 @@ def oracle_controls(ctl) -> O.Controls:
 
 
 def run_gpu(pkg, caps: np.ndarray, block_size: int, fs: int, use_torch: bool = False, controls=None, per_channel_controls=None,
-            pll_kernel: str = "auto"):
+            pll_kernel: str = "auto", fast_math: bool = False):
     """caps: [C, n, 2] float32 or uint8.  Returns dict of per-block concatenated streams [C, ...]."""
     n_ch = caps.shape[0]
     nb = caps.shape[1] // block_size
-    dm = pkg.BatchDemod(n_ch, block_size, fs, keep_taps=True, pll_kernel=pll_kernel)
+    dm = pkg.BatchDemod(n_ch, block_size, fs, keep_taps=True, pll_kernel=pll_kernel, fast_math=fast_math)
     if controls is not None:
         dm.set_controls(controls)
     if per_channel_controls:

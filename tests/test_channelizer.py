@@ -82,6 +82,26 @@ def test_kernel_matches_float64_definition_and_streams(pkg):
     assert np.abs(y2 - y).max() <= 1e-6 * np.abs(y).max()
     with pytest.raises(Exception):
         ch.process(xt[:1000].contiguous())               # 1000 inputs is not a whole number of outputs
+    # the shortest legal calls, 625 inputs -> 16 outputs: shorter than the 639-sample history (the history hand-over
+    # used to be an overlapping device memcpy here), alternating between two streams, into an output buffer with spare capacity
+    # (row stride = capacity, not n_out)
+    ch.reset()
+    bigs = [torch.full((6, 40, 2), 7.0, device="cuda") for _ in range(2)]   # one per stream: the library orders its own work, not the test's reads
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for i in range(96):
+        st = streams[i & 1]
+        with torch.cuda.stream(st):
+            big = bigs[i & 1]
+            got = ch.process(xt[i * 625:(i + 1) * 625].contiguous(), out=big, stream=st.cuda_stream)
+            assert tuple(got.shape) == (6, 16, 2)
+            outs.append(got.clone())
+            assert float(big[:, 16:].min()) == 7.0       # nothing written beyond n_out in any row
+    torch.cuda.synchronize()
+    y3 = torch.cat(outs, dim=1).cpu().numpy()
+    y3 = y3[..., 0] + 1j * y3[..., 1]
+    assert np.abs(y3 - y).max() <= 1e-6 * np.abs(y).max()
     ch.close()
 
 
