@@ -176,9 +176,9 @@ void design_pilot_fast(const fmd_coeffs& k, PilotFastTab* t) {
     M2 P = A;                                   // A^(k+1)
     for (int i = 0; i < kPilotSeg; i++) { t->h1[i] = (float)P.a; t->h2[i] = (float)P.b; if (i + 1 < kPilotSeg) P = mul(A, P); }
     M2 S = P;                                   // M = A^kPilotSeg
-    for (int s = 0; s < 6; s++) { t->m[s][0] = (float)S.a; t->m[s][1] = (float)S.b; t->m[s][2] = (float)S.c; t->m[s][3] = (float)S.d; S = mul(S, S); }
+    for (int s = 0; s < 4; s++) { t->m[s][0] = (float)S.a; t->m[s][1] = (float)S.b; t->m[s][2] = (float)S.c; t->m[s][3] = (float)S.d; S = mul(S, S); }
     M2 L{1.0, 0.0, 0.0, 1.0};
-    for (int l = 0; l < 64; l++) { t->mlane[l][0] = (float)L.a; t->mlane[l][1] = (float)L.b; t->mlane[l][2] = (float)L.c; t->mlane[l][3] = (float)L.d; L = mul(P, L); }
+    for (int l = 0; l < 16; l++) { t->mlane[l][0] = (float)L.a; t->mlane[l][1] = (float)L.b; t->mlane[l][2] = (float)L.c; t->mlane[l][3] = (float)L.d; L = mul(P, L); }
     t->k = k.pilot_b[0]; t->a0 = k.pilot_a[0]; t->a1 = k.pilot_a[1];
 }
 
@@ -329,11 +329,11 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     if (e != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_front launch: %s", hipGetErrorString(e));
     if (h->ctx.any_deemph && (e = run(ST_DEEMPH, sF, launch_stage_deemph, h->ev_F[slot])) != hipSuccess)
         return fail(h, FMD_ERR_DEVICE, "de-emphasis launch: %s", hipGetErrorString(e));
-    if (pipe) {
-        HIP_TRY(h, hipStreamWaitEvent(s, input_done ? input_done : dep, 0));   // the caller may reuse `iq` in stream order after this call
-        HIP_TRY(h, hipStreamWaitEvent(sA, dep, 0));
+    if (pipe) HIP_TRY(h, hipStreamWaitEvent(s, input_done ? input_done : dep, 0));   // the caller may reuse `iq` in stream order after this call
+    if (!h->ctx.fast) {   // (FMD_FLAG_FAST_MATH: the pilot peak filter runs inside the PLL kernel, there is no power pass)
+        if (pipe) HIP_TRY(h, hipStreamWaitEvent(sA, dep, 0));
+        if ((e = run(ST_POWER, sA, launch_stage_power, h->ev_A[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_pilot_power launch: %s", hipGetErrorString(e));
     }
-    if ((e = run(ST_POWER, sA, launch_stage_power, h->ev_A[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_pilot_power launch: %s", hipGetErrorString(e));
     if (pipe) HIP_TRY(h, hipStreamWaitEvent(sB, dep, 0));
     if ((e = run(ST_PLL, sB, launch_stage_pll, h->ev_B[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_pilot_pll launch: %s", hipGetErrorString(e));
     if (pipe) HIP_TRY(h, hipStreamWaitEvent(sX, dep, 0));
@@ -504,7 +504,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
         rc = dev_alloc(h, &b.fm_out_iq[p], C * d.n_fm_out);
         if (!rc && m > 1) rc = dev_alloc(h, &b.fm_in[p], C * d.n_fm_in);
         if (!rc) rc = dev_alloc(h, &b.fm_out[p], C * d.n_fm_out);
-        if (!rc) rc = dev_alloc(h, &b.pilot[p], C * d.n_fm_out);
+        if (!rc && !h->ctx.fast) rc = dev_alloc(h, &b.pilot[p], C * d.n_fm_out);   // (fast mode never materialises the pilot stream)
         if (!rc) rc = dev_alloc(h, &b.pll_dt[p], C * d.n_fm_out);
         if (!rc) rc = dev_alloc(h, &b.audio[p], C * d.n_audio * 2);
         if (!rc) rc = dev_alloc(h, &b.rds_sym[p], C * d.n_rds);
@@ -874,7 +874,7 @@ int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out) {
             float ms = 0.0f;
             HIP_TRY(h, hipEventElapsedTime(&ms, pm->t0[i], pm->t1[i]));
             int slot = -1;
-            const char* nm = (h->ctx.fast && i == ST_POWER) ? "k_pilot_fast" : (h->ctx.fast && i == ST_PLL) ? "k_pll_fast" : kStageName[i];
+            const char* nm = (h->ctx.fast && i == ST_PLL) ? "k_pll_fast" : kStageName[i];
             for (int j = 0; j < n; j++) if (std::strncmp(out[j].name, nm, sizeof(out[j].name)) == 0) { slot = j; break; }
             if (slot < 0) {
                 if (n >= cap) continue;

@@ -1629,11 +1629,6 @@ hipError_t launch_stage_deemph(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
 
 hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
-    if (ctx.fast) {   // one wavefront per channel, the recurrence as a scan
-        FMD_LAUNCH(r, true, true, k_pilot_fast, dim3((unsigned)d.C), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[r.buf], ctx.b.pilot[r.buf], ctx.b.state,
-                   ctx.b.pilot_tab, (int)S_PILOT_POWER0 + r.buf);
-        return hipGetLastError();
-    }
     if (effective_channels(d) <= 2816) {   // the batches whose step is this kernel's latency (and whose PLL launches hand over per wavefront)
         FMD_LAUNCH(r, true, true, k_pilot_power<true>, dim3(serial_waves(d)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[r.buf], ctx.b.pilot[r.buf], ctx.b.state,
                    ctx.loops, (int)S_PILOT_POWER0 + r.buf);
@@ -1647,8 +1642,8 @@ hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
 hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     if (ctx.fast) {
-        FMD_LAUNCH(r, true, true, k_pll_fast, dim3((unsigned)((d.C + 3) / 4)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
-                   ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
+        FMD_LAUNCH(r, true, true, k_pll_fast, dim3((unsigned)((d.C + 3) / 4)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
+                   ctx.loops, ctx.b.pilot_tab, ctx.b.spec_stats);
         return hipGetLastError();
     }
     if (d.C > ctx.pll_time_parallel_max_channels) {
