@@ -178,7 +178,7 @@ void design_pilot_fast(const fmd_coeffs& k, PilotFastTab* t) {
     M2 S = P;                                   // M = A^kPilotSeg
     for (int s = 0; s < 4; s++) { t->m[s][0] = (float)S.a; t->m[s][1] = (float)S.b; t->m[s][2] = (float)S.c; t->m[s][3] = (float)S.d; S = mul(S, S); }
     M2 L{1.0, 0.0, 0.0, 1.0};
-    for (int l = 0; l < 16; l++) { t->mlane[l][0] = (float)L.a; t->mlane[l][1] = (float)L.b; t->mlane[l][2] = (float)L.c; t->mlane[l][3] = (float)L.d; L = mul(P, L); }
+    for (int l = 0; l <= 32; l++) { t->mlane[l][0] = (float)L.a; t->mlane[l][1] = (float)L.b; t->mlane[l][2] = (float)L.c; t->mlane[l][3] = (float)L.d; L = mul(P, L); }
     t->k = k.pilot_b[0]; t->a0 = k.pilot_a[0]; t->a1 = k.pilot_a[1];
 }
 
@@ -483,6 +483,8 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     h->ctx.bytes_cap = h->bytes_cap;
     h->ctx.keep_taps = (cfg->flags & FMD_FLAG_KEEP_TAPS) ? 1 : 0;
     h->ctx.fast = (cfg->flags & FMD_FLAG_FAST_MATH) ? 1 : 0;
+    h->ctx.pll_hold_hz = 2.0f;
+    if (const char* e = getenv("FMD_DEBUG_PLL_HOLD_HZ")) h->ctx.pll_hold_hz = (float)atof(e);   // development knob (tools/dbg): 0 = one sample per span
 
     fmd_controls def;
     fmd_default_controls(&def);

@@ -1642,8 +1642,8 @@ hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
 hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     if (ctx.fast) {
-        FMD_LAUNCH(r, true, true, k_pll_fast, dim3((unsigned)((d.C + 3) / 4)), dim3(kWave), 0, s, d, ctx.b.fm_out_iq[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
-                   ctx.loops, ctx.b.pilot_tab, ctx.b.spec_stats);
+        FMD_LAUNCH(r, true, true, k_pll_fast, dim3((unsigned)((d.C + 1) / 2)), dim3(2 * kWave), 0, s, d, ctx.b.fm_out_iq[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
+                   ctx.loops, ctx.b.pilot_tab, ctx.b.spec_stats, ctx.pll_hold_hz);
         return hipGetLastError();
     }
     if (d.C > ctx.pll_time_parallel_max_channels) {
