@@ -42,14 +42,16 @@ struct fmd_handle_s {
     size_t d_in_bytes = 0;
     hipStream_t own_stream = nullptr;        // host-pointer entry points, uploads, resets
     hipStream_t last_stream = nullptr;
-    hipStream_t sF = nullptr, sA = nullptr, sB = nullptr, sB2 = nullptr, sX = nullptr, sR = nullptr;
+    hipStream_t sF = nullptr, sA = nullptr, sB = nullptr, sB2 = nullptr, sX = nullptr, sR = nullptr, sD = nullptr;   // sD: the optional de-emphasis stage
     unsigned pll_seq = 0;                    // k_pilot_pll launches handed over per wavefront so far (0: hand-over by stream order)
     bool pll_chained = false;
     int pll_waves = 0;
     hipEvent_t ev_in = nullptr, ev_P[kSlots] = {}, ev_F[kSlots] = {}, ev_A[kSlots] = {}, ev_B[kSlots] = {}, ev_E[kSlots] = {}, ev_X[kSlots] = {};
+    hipEvent_t ev_D[kSlots] = {};            // k_front done, de-emphasis stage may start
     hipEvent_t ev_C[kSlots] = {};            // fmd_release_outputs: the consumer of a slot's outputs has finished with them
     bool consumer_pending[kSlots] = {};
     bool slot_used[kSlots] = {};
+    bool last_block_deemph = false;          // the previous block went through the de-emphasis stage (stream sD)
     bool poisoned = false;                   // a block failed part-way: state is not the state after a whole number of blocks
     bool pipelined = true;
     long n_blocks = 0;                       // blocks submitted since create/reset; slot = n_blocks % kSlots
@@ -224,7 +226,7 @@ int zero_history(fmd_handle h, hipStream_t s) {
 
 int sync_all(fmd_handle h) {
     HIP_TRY(h, hipSetDevice(h->device));
-    for (hipStream_t st : {h->sF, h->sA, h->sB, h->sB2, h->sX, h->sR, h->own_stream}) if (st) HIP_TRY(h, hipStreamSynchronize(st));
+    for (hipStream_t st : {h->sF, h->sD, h->sA, h->sB, h->sB2, h->sX, h->sR, h->own_stream}) if (st) HIP_TRY(h, hipStreamSynchronize(st));
     if (!h->pipelined && h->n_blocks > 0) HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     if (h->pll_chained && h->pll_seq) {   // the hand-over watchdog of k_pilot_pll
         unsigned timed_out = 0;
@@ -309,6 +311,9 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
             if (sP != sF) HIP_TRY(h, hipStreamWaitEvent(sP, h->ev_X[slot], 0));
         }
     }
+    // the block after the last de-emphasised one: k_front maintains the Hilbert history (fo_tail) again and must not overwrite
+    // what the previous block's k_hilbert, on its own stream, is still reading
+    if (pipe && !h->ctx.any_deemph && h->last_block_deemph) HIP_TRY(h, hipStreamWaitEvent(sF, h->ev_F[h->out_slot], 0));
     hipEvent_t input_done = nullptr;               // fires when the caller's buffer has been consumed
     if (predecim) {
         SlotRef r = ref;
@@ -322,14 +327,22 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     {
         SlotRef r = ref;
         if (pm && prof_stage(ST_FRONT)) { r.t0 = pm->t0[ST_FRONT]; r.t1 = pm->t1[ST_FRONT]; pm->used[ST_FRONT] = true; }
-        if (pipe && !r.t1 && !h->ctx.any_deemph) r.done = h->ev_F[slot];
-        dep = r.t1 ? r.t1 : h->ev_F[slot];
+        hipEvent_t front_done = h->ctx.any_deemph ? h->ev_D[slot] : h->ev_F[slot];
+        if (pipe && !r.t1) r.done = front_done;
+        dep = r.t1 ? r.t1 : front_done;
         e = launch_stage_front(h->ctx, r, d_iq, u8, sF);
     }
     if (e != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_front launch: %s", hipGetErrorString(e));
-    if (h->ctx.any_deemph && (e = run(ST_DEEMPH, sF, launch_stage_deemph, h->ev_F[slot])) != hipSuccess)
-        return fail(h, FMD_ERR_DEVICE, "de-emphasis launch: %s", hipGetErrorString(e));
-    if (pipe) HIP_TRY(h, hipStreamWaitEvent(s, input_done ? input_done : dep, 0));   // the caller may reuse `iq` in stream order after this call
+    hipEvent_t front_dep = dep;                    // k_front itself: the caller's buffer (256 kSa/s captures) has been consumed
+    if (h->ctx.any_deemph) {
+        // the optional de-emphasis IIR + Hilbert FIR: a pipeline stage of its own (stream sD), so that k_front of the next block
+        // runs beside it — in k_front's stream the two made the front end the longest stage (+25 % on the step)
+        hipStream_t sDe = pipe ? h->sD : s;
+        if (pipe) HIP_TRY(h, hipStreamWaitEvent(sDe, dep, 0));
+        if ((e = run(ST_DEEMPH, sDe, launch_stage_deemph, h->ev_F[slot])) != hipSuccess)
+            return fail(h, FMD_ERR_DEVICE, "de-emphasis launch: %s", hipGetErrorString(e));
+    }
+    if (pipe) HIP_TRY(h, hipStreamWaitEvent(s, input_done ? input_done : front_dep, 0));   // the caller may reuse `iq` in stream order after this call
     if (!h->ctx.fast) {   // (FMD_FLAG_FAST_MATH: the pilot peak filter runs inside the PLL kernel, there is no power pass)
         if (pipe) HIP_TRY(h, hipStreamWaitEvent(sA, dep, 0));
         if ((e = run(ST_POWER, sA, launch_stage_power, h->ev_A[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_pilot_power launch: %s", hipGetErrorString(e));
@@ -343,6 +356,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     if ((e = run(ST_RDS, sR, launch_stage_rds, h->ev_X[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_rds_sync launch: %s", hipGetErrorString(e));
     // ev_X outlives this call (slot reuse, fmd_wait_outputs): when the dispatch carried a timing event instead, record it
     if (pipe && dep != h->ev_X[slot]) HIP_TRY(h, hipEventRecord(h->ev_X[slot], sR));
+    h->last_block_deemph = h->ctx.any_deemph != 0;
     h->slot_used[slot] = true;
     h->out_slot = slot;
     h->n_blocks++;
@@ -455,13 +469,13 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     // (the second PLL stream is own_stream: one more stream would be the ninth on the device with the caller's and would share a
     //  hardware queue with another stage; everything else own_stream does is preceded by a full synchronisation)
     h->sB2 = h->own_stream;
-    for (hipStream_t* st : {&h->sF, &h->sA, &h->sB, &h->sX, &h->sR}) {
+    for (hipStream_t* st : {&h->sF, &h->sD, &h->sA, &h->sB, &h->sX, &h->sR}) {
         hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
         if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e)));
     }
     {
         std::vector<hipEvent_t*> evs = {&h->ev_in};
-        for (int i = 0; i < kSlots; i++) { evs.push_back(&h->ev_P[i]); evs.push_back(&h->ev_F[i]); evs.push_back(&h->ev_A[i]); evs.push_back(&h->ev_B[i]); evs.push_back(&h->ev_E[i]); evs.push_back(&h->ev_X[i]); evs.push_back(&h->ev_C[i]); }
+        for (int i = 0; i < kSlots; i++) { evs.push_back(&h->ev_P[i]); evs.push_back(&h->ev_F[i]); evs.push_back(&h->ev_A[i]); evs.push_back(&h->ev_B[i]); evs.push_back(&h->ev_E[i]); evs.push_back(&h->ev_X[i]); evs.push_back(&h->ev_C[i]); evs.push_back(&h->ev_D[i]); }
         for (hipEvent_t* ev : evs) {
             hipError_t e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
             if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "event: %s", hipGetErrorString(e)));
@@ -554,10 +568,10 @@ int fmd_destroy(fmd_handle h) {
     (void)hipSetDevice(h->device);
     (void)sync_all(h);
     free_marks(h);
-    for (hipStream_t st : {h->sF, h->sA, h->sB, h->sX, h->sR}) if (st) (void)hipStreamDestroy(st);
+    for (hipStream_t st : {h->sF, h->sD, h->sA, h->sB, h->sX, h->sR}) if (st) (void)hipStreamDestroy(st);
     {
         std::vector<hipEvent_t> evs = {h->ev_in};
-        for (int i = 0; i < kSlots; i++) { evs.push_back(h->ev_P[i]); evs.push_back(h->ev_F[i]); evs.push_back(h->ev_A[i]); evs.push_back(h->ev_B[i]); evs.push_back(h->ev_E[i]); evs.push_back(h->ev_X[i]); evs.push_back(h->ev_C[i]); }
+        for (int i = 0; i < kSlots; i++) { evs.push_back(h->ev_P[i]); evs.push_back(h->ev_F[i]); evs.push_back(h->ev_A[i]); evs.push_back(h->ev_B[i]); evs.push_back(h->ev_E[i]); evs.push_back(h->ev_X[i]); evs.push_back(h->ev_C[i]); evs.push_back(h->ev_D[i]); }
         for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     }
     for (void* p : h->allocs) (void)hipFree(p);

@@ -1462,21 +1462,91 @@ __global__ __launch_bounds__(kWave) void k_rds_sync(Dims d, float2* __restrict__
 // optional de-emphasis path — reference Run_FM_Demodulate :403-410: IIR_Filter<float> K=2 in place on
 // fm_out (serial per channel), then the Hilbert FIR.  k_front writes fm_out when any channel asks for it.
 // =============================================================================================
-__global__ __launch_bounds__(kWave) void k_deemphasis(Dims d, float* __restrict__ fm_out, const float* __restrict__ deemph, float* __restrict__ state) {
-    const int c = blockIdx.x * kWave + threadIdx.x;
-    if (c >= d.C) return;
-    const float b0 = deemph[4 * c + 0], b1 = deemph[4 * c + 1], a0 = deemph[4 * c + 2];
-    if (deemph[4 * c + 3] == 0.0f) return;
-    float x1 = st(state, S_DE_X1, d.C, c), y1 = st(state, S_DE_Y1, d.C, c);
-    float* row = fm_out + (size_t)c * d.n_fm_out;
-    for (int i = 0; i < d.n_fm_out; i++) {
-        const float x = row[i];
-        const float t0 = fmaf(x1, b0, y1 * a0);
-        const float y = (0.0f + t0) + fmaf(x, b1, 0.0f);
-        x1 = x; y1 = y;
-        row[i] = y;
+// Lane per channel, 32-sample chunks moved row-wise (coalesced, 16 B per lane) and transposed through LDS, the next chunk in
+// flight while the current one is filtered — the form of the other serial kernels.  (Round 1 walked each channel's row straight
+// in global memory: 64 lanes, 64 different rows per load.)  The recurrence is 4 dependent operations per sample.
+struct ChunkRegsF { float4 v0, v1, v2, v3, v4, v5, v6, v7; };
+#define FMD_FOR8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+__device__ __forceinline__ ChunkRegsF chunk_load_f(const float* __restrict__ base, int n, int c0, int C, int t0) {
+    const int lane = threadIdx.x & (kWave - 1), row = lane >> 3, col = lane & 7;
+    ChunkRegsF r;
+#define FMD_LDF(k) { int ch = c0 + 8 * k + row; ch = ch < C ? ch : C - 1; r.v##k = *reinterpret_cast<const float4*>(base + (size_t)ch * n + t0 + 4 * col); }
+    FMD_FOR8(FMD_LDF)
+#undef FMD_LDF
+    return r;
+}
+__device__ __forceinline__ void chunk_store_f(const ChunkRegsF& r, float* lds) {
+    const int lane = threadIdx.x & (kWave - 1), row = lane >> 3, col = lane & 7;
+#define FMD_STF(k) *reinterpret_cast<float4*>(lds + (8 * k + row) * kRowF + 4 * col) = r.v##k;
+    FMD_FOR8(FMD_STF)
+#undef FMD_STF
+}
+
+// Workgroup = two wavefronts for 64 channels: wave 1 only LOADS (HBM -> registers -> LDS ring, two chunks ahead), wave 0 filters
+// (lane per channel) and only STORES.  On gfx9 loads and stores share one in-order counter and complete out of order with
+// respect to each other, so a wave that has both in flight waits for "everything": with the chunk prefetch and the result
+// stores in one wave this kernel paid an HBM round trip per 32-sample chunk (4100 cycles per chunk for 770 cycles of work).
+__global__ __launch_bounds__(2 * kWave) void k_deemphasis(Dims d, float* __restrict__ fm_out, const float* __restrict__ deemph, float* __restrict__ state) {
+    constexpr int kRingSlots = 4;
+    __shared__ __attribute__((aligned(16))) float ring[kRingSlots][kWave * kRowF];
+    const bool loader = threadIdx.x >= kWave;              // wave-uniform
+    const int lane = threadIdx.x & (kWave - 1), c0 = blockIdx.x * kWave, c = c0 + lane;
+    const bool live = c < d.C;
+    const int cs = live ? c : d.C - 1;
+    const bool on = deemph[4 * cs + 3] != 0.0f;
+    const int n = d.n_fm_out, chunks = n / kChunk;
+    // a workgroup none of whose channels filters has nothing to do (both waves see the same 64 channels)
+    if (__builtin_amdgcn_ballot_w64(on && live) == 0ull) return;
+    if (loader) {
+        ChunkRegsF ra = chunk_load_f(fm_out, n, c0, d.C, 0);
+        ChunkRegsF rb = chunk_load_f(fm_out, n, c0, d.C, kChunk);
+        chunk_store_f(ra, ring[0]);
+        ra = chunk_load_f(fm_out, n, c0, d.C, (2 < chunks ? 2 : chunks - 1) * kChunk);
+        chunk_store_f(rb, ring[1]);
+        rb = chunk_load_f(fm_out, n, c0, d.C, (3 < chunks ? 3 : chunks - 1) * kChunk);
+        __syncthreads();                                   // chunks 0 and 1 are in the ring
+        for (int ch = 0; ch < chunks; ch += 2) {           // while wave 0 filters chunk ch: chunk ch + 2 into its slot
+            chunk_store_f(ra, ring[(ch + 2) & (kRingSlots - 1)]);
+            ra = chunk_load_f(fm_out, n, c0, d.C, (ch + 4 < chunks ? ch + 4 : chunks - 1) * kChunk);
+            __syncthreads();
+            chunk_store_f(rb, ring[(ch + 3) & (kRingSlots - 1)]);
+            rb = chunk_load_f(fm_out, n, c0, d.C, (ch + 5 < chunks ? ch + 5 : chunks - 1) * kChunk);
+            __syncthreads();
+        }
+        return;
     }
-    st(state, S_DE_X1, d.C, c) = x1; st(state, S_DE_Y1, d.C, c) = y1;
+    __builtin_amdgcn_s_setprio(3);
+    const float b0 = deemph[4 * cs + 0], b1 = deemph[4 * cs + 1], a0 = deemph[4 * cs + 2];
+    float x1 = st(state, S_DE_X1, d.C, cs), y1 = st(state, S_DE_Y1, d.C, cs);
+    __syncthreads();
+    for (int ch = 0; ch < chunks; ch++) {
+        float* buf = ring[ch & (kRingSlots - 1)];
+        float4* row_ = reinterpret_cast<float4*>(buf + lane * kRowF);
+        float4 w_[kChunk / 4];
+#pragma unroll
+        for (int t = 0; t < kChunk / 4; t++) w_[t] = row_[t];
+        if (on) {
+#pragma unroll
+            for (int t = 0; t < kChunk / 4; t++) {
+                float xs_[4] = {w_[t].x, w_[t].y, w_[t].z, w_[t].w}, ys_[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    // reference IIR_Filter<float> K=2 (iir_filter.h:62-69): t_i = fma(xn[i], b[i], yn[i] a[i]); y = (0 + t_0) + t_1
+                    const float t0 = fmaf(x1, b0, y1 * a0);
+                    const float y = (0.0f + t0) + fmaf(xs_[u], b1, 0.0f);
+                    x1 = xs_[u]; y1 = y; ys_[u] = y;
+                }
+                w_[t] = make_float4(ys_[0], ys_[1], ys_[2], ys_[3]);
+            }
+#pragma unroll
+            for (int t = 0; t < kChunk / 4; t++) row_[t] = w_[t];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        chunk_flush_f(buf, fm_out, n, c0, d.C, ch * kChunk);     // stores only: nothing in this wave ever waits for them
+        __syncthreads();
+    }
+    if (live && on) { st(state, S_DE_X1, d.C, c) = x1; st(state, S_DE_Y1, d.C, c) = y1; }
 }
 
 __global__ __launch_bounds__(256) void k_hilbert(Dims d, const float* __restrict__ fm_out, const float* __restrict__ fo_tail_in,
@@ -1621,7 +1691,7 @@ static unsigned serial_waves(const Dims& d) { return (unsigned)((d.C + kWave - 1
 hipError_t launch_stage_deemph(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
-    FMD_LAUNCH(r, true, false, k_deemphasis, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.fm_out[r.buf], b.deemph, b.state);
+    FMD_LAUNCH(r, true, false, k_deemphasis, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.fm_out[r.buf], b.deemph, b.state);
     FMD_LAUNCH(r, false, true, k_hilbert, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, b.fm_out[r.buf], b.fo_tail[r.par],
                        b.fo_tail[r.par ^ 1], b.fm_out_iq[r.buf], ctx.front);
     return hipGetLastError();

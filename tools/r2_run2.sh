@@ -6,7 +6,7 @@ export GPU_MAX_HW_QUEUES=8
 timeout 900 python -m pytest tests/test_gpu_fast.py -m gpu -q -s 2>&1 | tail -60 > gpurun_out/r2_2/pytest_fast.log
 for extra in "" "--unlocked-frac 0.1" "--unlocked-frac 1.0" "--no-pipeline" "--channels 8192" "--channels 16384" "--fs 1024000" "--u8"; do
   tag=$(echo "$extra" | tr -d ' -.')
-  timeout 300 python bench.py --fast-math --steps 20 --warmup 5 --no-cpu-baseline $extra > gpurun_out/r2_2/bench_fast_$tag.json 2> gpurun_out/r2_2/bench_fast_$tag.err
+  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline $extra > gpurun_out/r2_2/bench_fast_$tag.json 2> gpurun_out/r2_2/bench_fast_$tag.err
 done
 cat gpurun_out/r2_2/pytest_fast.log
 for f in gpurun_out/r2_2/bench_*.json; do echo $f; python - "$f" <<'PY'
