@@ -234,6 +234,29 @@ def cpu_reference(budget_s: float = 10.0) -> dict | None:
             "sample": f"{n_proc} processes x {n} u8 samples @ 1.024 MSa/s (20.5 s of signal each) in {el:.1f} s, reference fm_demod_benchmark incl. RDS decode"}
 
 
+def host_fed_line(C: int, block: int, fs: int, fast: bool, threads: int = 4, blocks: int = 40) -> dict | None:
+    """The PCIe-inclusive rate (never `value`): fm-radio_amd/host/station_ring.hpp — producer threads push u8 IQ into pinned staging
+    blocks, H2D copies, the demodulator and the D2H copies of audio + RDS bytes overlap — driven by tests/cpp/station_ring_main.cpp
+    (compiled here with g++ against the C ABI and the HIP runtime API).  None when the toolchain or the run fails."""
+    import subprocess
+    import tempfile
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            exe = Path(td) / "station_ring_main"
+            subprocess.run(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{ROOT / 'include'}", f"-I{ROOT / 'fm-radio_amd' / 'host'}",
+                            str(ROOT / "tests" / "cpp" / "station_ring_main.cpp"), f"-L{ROOT / 'fm-radio_amd' / 'csrc'}", "-lfmdemod", "-L/opt/rocm/lib", "-lamdhip64",
+                            "-lpthread", f"-Wl,-rpath,{ROOT / 'fm-radio_amd' / 'csrc'}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True, capture_output=True, timeout=300)
+            r = subprocess.run([str(exe), "bench", str(C), str(block), str(fs), str(blocks), str(threads)] + (["fast"] if fast else []),
+                               check=True, capture_output=True, text=True, timeout=300)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            d["pcie_bound_msa_per_s"] = 63e9 / 2.0 / 1e6     # 63 GB/s (PCIe Gen5 x16 spec) / 2 B per u8 IQ sample
+            d["frac_of_pcie_bound"] = d["host_fed_msa_per_s"] / d["pcie_bound_msa_per_s"]
+            d["note"] = "u8 IQ pushed by host threads into pinned staging, H2D + demodulation + D2H of audio and RDS bytes overlapped; PCIe-inclusive, not the headline"
+            return d
+    except Exception as e:   # noqa: BLE001 - an optional extra line
+        return {"error": str(e)[:300]}
+
+
 def launch_ranks(n: int) -> int:
     """Start `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child process, pass its
     stderr through, print exactly one JSON line (rank 0's) on stdout and return the child's exit code."""
@@ -302,6 +325,7 @@ def main() -> None:
                     "the reference, RDS bits identical: tests/test_gpu_fast.py); the other mode is then timed briefly as `other_mode`")
     ap.add_argument("--fast-math", action="store_true", help="(default) the tolerance mode as the primary result")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the short run of the other arithmetic mode")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (PCIe-inclusive) extra line")
     args = ap.parse_args()
     if args.exact and args.fast_math:
         raise SystemExit("bench.py: --exact and --fast-math exclude each other")
@@ -521,6 +545,8 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del x
         torch.cuda.empty_cache()
+        if not args.no_host_fed:
+            out["host_fed_u8"] = host_fed_line(C, block, fs, args.fast_math)
         out["cpu_baseline"] = cpu_baseline(fs, block)
         ref = cpu_reference()
         if ref is not None:

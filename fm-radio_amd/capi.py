@@ -143,6 +143,7 @@ def load_library():
     L.fmd_get_audio.argtypes = [H, C.c_void_p]
     L.fmd_get_rds_symbols.argtypes = [H, C.c_void_p, C.c_void_p]
     L.fmd_get_rds_bytes.argtypes = [H, C.c_void_p, C.c_int, C.c_void_p]
+    L.fmd_rds_bytes_dev.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
     L.fmd_get_stream.argtypes = [H, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.fmd_selftest_atan2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.fmd_selftest_atan2_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]

@@ -720,6 +720,14 @@ int fmd_get_rds_bytes(fmd_handle h, uint8_t* bytes, int cap_bytes_per_channel, i
     return FMD_OK;
 }
 
+int fmd_rds_bytes_dev(fmd_handle h, const uint8_t** d_bytes, const int** d_counts, int* cap_bytes_per_channel) {
+    if (!h || !d_bytes || !d_counts || !cap_bytes_per_channel) return FMD_ERR_ARG;
+    *d_bytes = h->ctx.b.rds_bytes[h->out_slot];
+    *d_counts = h->ctx.b.rds_bytes_count[h->out_slot];
+    *cap_bytes_per_channel = h->bytes_cap;
+    return FMD_OK;
+}
+
 int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats, size_t* n_floats) {
     if (!h || !name) return FMD_ERR_ARG;
     const Dims& d = h->ctx.d;

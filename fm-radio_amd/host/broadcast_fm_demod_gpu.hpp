@@ -27,7 +27,10 @@
 
 namespace fmd_host {
 
+#ifndef FMD_HOST_FRAME_DEFINED
+#define FMD_HOST_FRAME_DEFINED
 struct Frame { float channels[2]; };  // reference src/audio/frame.h:6-8
+#endif
 
 template <typename... T>
 class Observable {  // reference src/utility/observable.h:7-22

@@ -187,6 +187,9 @@ int    fmd_set_state(fmd_handle h, int channel, const void* blob, size_t n_bytes
  * one src/app.cpp:13-20 uses).  bytes: [C][cap_bytes]; counts[c] = bytes appended for channel c this
  * block (multiples of 16). */
 int fmd_get_rds_bytes(fmd_handle h, uint8_t* bytes, int cap_bytes_per_channel, int* counts);
+/* ... and as device views of the newest block (same lifetime rule as fmd_audio_dev): d_bytes [C][*cap_bytes_per_channel],
+ * d_counts [C] — for hosts that fetch the outputs with their own asynchronous copies (fm-radio_amd/host/station_ring.hpp). */
+int fmd_rds_bytes_dev(fmd_handle h, const uint8_t** d_bytes, const int** d_counts, int* cap_bytes_per_channel);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Wideband channeliser (SURVEY.md §8f row 3 / BASELINE configs[4]; NOT part of the reference, which tunes one station in
