@@ -137,7 +137,7 @@ def bench_wideband(args, torch, pkg, device) -> dict:
     centers = (np.arange(C) - (C - 1) / 2.0) * 250e3
     wide = synth_wideband_device(torch, centers, n_res * n_in, fs_in, 1234, device).view(n_res, n_in, 2)
     ch = pkg.Channelizer(fs_in, centers, float(fs), max_input_samples=n_in)
-    dm = pkg.BatchDemod(C, block, fs, device=device.index)
+    dm = pkg.BatchDemod(C, block, fs, device=device.index, fast_math=args.fast_math)
     outs = [torch.empty((C, block, 2), dtype=torch.float32, device=device) for _ in range(4)]
 
     def step(k):
@@ -164,7 +164,8 @@ def bench_wideband(args, torch, pkg, device) -> dict:
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[4]: one {fs_in / 1e6:g} MSa/s cf32 capture resident in HBM, {C} FM stations on a 250 kHz raster, "
                                f"on-GPU polyphase channeliser (16/625, 640 taps/phase) -> {fs} Sa/s per station -> full stereo + pilot PLL + RDS",
-                   "stations": C, "fs_wideband": fs_in, "fs_baseband": fs, "block_size": block, "preroll_blocks": P},
+                   "stations": C, "fs_wideband": fs_in, "fs_baseband": fs, "block_size": block, "preroll_blocks": P,
+                   "mode": "fast_math (tolerance)" if args.fast_math else "exact"},
         "wideband_msa_per_s": n_in * K / el / 1e6,
         "realtime_factor": (n_in * K / el) / fs_in,
         "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in ktimes.items()},

@@ -11,9 +11,16 @@
 // the L phases of one Kaiser-windowed prototype (cut-off fs_out/2, length L*T), shared by all stations.  Per output
 // sample that is T complex-by-real MACs; 40 stations x 256 kSa/s x 640 taps = 13 GFMA/s — noise next to the demodulator.
 //
-// Kernel: workgroup = (station, 128 consecutive outputs).  The input window those outputs need (128 M/L + T samples) is
-// mixed once while it is staged into LDS; every thread then walks its own T taps.  Taps are stored [t][p] so the 64 lanes
-// of a wavefront (consecutive outputs = consecutive phases when M mod L == 1) read contiguous rows.
+// Kernel (round 2): workgroup = (station, 128 consecutive outputs), 256 threads, all of them on the FIR.
+//   * The input window those outputs need (128 M/L + T samples) is mixed to baseband while it is staged into LDS.  The mixer's
+//     phasor is computed exactly (64-bit modular phase, sincospi) for a thread's first sample and advanced by a complex
+//     multiplication for its following ones (stride 256 samples, ~22 steps: drift < 2e-6), instead of one sincospi per sample.
+//   * Outputs o and o + L share their polyphase branch p = (o M) mod L.  Thread (p, s) owns branch p and the tap slice
+//     [s T/16, (s+1) T/16) of it — its taps live in registers — and accumulates that slice for the tile's 128 / L outputs of
+//     the branch: one tap load per (128 / L) x 2 FMAs instead of one per 2.  The 16 slices of an output are summed through LDS
+//     in a fixed order.
+// Requires L == 16 (10 MSa/s -> 256 kSa/s and every other pair of rates with fs_out / gcd = 16) for this mapping; other ratios
+// take the general kernel below (one output per thread), which is what round 1 had.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -30,6 +37,7 @@ namespace {
 
 constexpr int kTile = 128;          // outputs per workgroup
 constexpr int kMaxWindow = 7168;    // staged input samples per workgroup (56 KB of LDS)
+constexpr int kSlices = 16;         // tap slices per branch in the L == 16 kernel
 
 struct ChanDims {
     int L, M, T;            // interpolation, decimation, taps per phase
@@ -40,9 +48,80 @@ struct ChanDims {
     unsigned long long n_base;  // absolute input index of win[0]
 };
 
+// window staging shared by both kernels: xs[i] = win[n_lo + i] * exp(-j 2 pi f n / fs)
+__device__ __forceinline__ void stage_mixed(const ChanDims& d, const float2* __restrict__ win, unsigned long long n_lo, int n_win,
+                                            unsigned long long inc, float2* xs) {
+    // phase in turns = frac(n_abs * f_k / fs_in), exact in 64-bit modular arithmetic, then one rounding to float
+    const unsigned long long n_first = n_lo + (unsigned long long)threadIdx.x;
+    const unsigned int ph0 = (unsigned int)((n_first * inc) >> 32);
+    float s, c;
+    sincospif((float)ph0 * 4.656612873077393e-10f /* 2^-31: argument in units of pi */, &s, &c);
+    const unsigned int phs = (unsigned int)((256ull * inc) >> 32);          // phase advance between a thread's consecutive samples
+    float ss, cs;
+    sincospif((float)phs * 4.656612873077393e-10f, &ss, &cs);
+    for (int i = threadIdx.x; i < n_win; i += 256) {
+        const float2 x = win[(n_lo + (unsigned long long)i) - d.n_base];
+        xs[i] = make_float2(fmaf(x.x, c, x.y * s), fmaf(x.y, c, -(x.x * s)));   // x * (cos - j sin)
+        const float cn = fmaf(c, cs, -(s * ss)), sn = fmaf(s, cs, c * ss);
+        c = cn; s = sn;
+    }
+}
+
+// L == 16: see the header comment
+__global__ __launch_bounds__(256) void k_channelize16(ChanDims d, const float2* __restrict__ win, const float* __restrict__ taps /* [T][16] */,
+                                                      const unsigned long long* __restrict__ phase_inc, float2* __restrict__ out) {
+    constexpr int L = 16, PER = kTile / L;                    // 8 outputs of a branch per tile
+    constexpr int kMaxSlice = 64;                             // taps per slice held in registers (T <= 1024)
+    __shared__ float2 xs[kMaxWindow];
+    __shared__ float2 part[kSlices][kTile + 1];
+    const int k = blockIdx.y;
+    const long long tile0 = (long long)blockIdx.x * kTile;
+    const int n_tile = (int)((d.n_out - tile0) < kTile ? (d.n_out - tile0) : kTile);
+    const unsigned long long o_first = d.o0 + (unsigned long long)tile0, o_last = o_first + (unsigned long long)(n_tile - 1);
+    const unsigned long long n_hi = (o_last * (unsigned long long)d.M) / (unsigned long long)L;
+    const unsigned long long n_lo = (o_first * (unsigned long long)d.M) / (unsigned long long)L - (unsigned long long)(d.T - 1);
+    stage_mixed(d, win, n_lo, (int)(n_hi - n_lo + 1), phase_inc[k], xs);
+    // this thread's branch and slice: outputs oo = j0 + 16 q (q < 8) where j0 is the tile-relative output with branch p
+    const int p = threadIdx.x & (L - 1), sl = threadIdx.x >> 4;
+    const int tps = d.T / kSlices, t0 = sl * tps;             // T is a multiple of 64
+    // tile-relative output whose branch is p: (o_first + j) M mod 16 == p.  M mod 16 is odd for coprime L, M: solve by search
+    int j0 = 0;
+    for (int j = 0; j < L; j++) if ((int)(((o_first + (unsigned long long)j) * (unsigned long long)d.M) % L) == p) j0 = j;
+    float h[kMaxSlice];
+#pragma unroll
+    for (int t = 0; t < kMaxSlice; t++) h[t] = (t < tps) ? taps[(size_t)(t0 + t) * L + p] : 0.0f;
+    __syncthreads();
+#pragma unroll 1
+    for (int q = 0; q < PER; q++) {
+        const int oo = j0 + L * q;
+        float ar = 0.f, ai = 0.f, br = 0.f, bi = 0.f;
+        if (oo < n_tile) {
+            const unsigned long long om = (o_first + (unsigned long long)oo) * (unsigned long long)d.M;
+            const int n0 = (int)(om / (unsigned long long)L - n_lo) - t0;
+#pragma unroll
+            for (int t = 0; t < kMaxSlice; t += 2) {
+                if (t < tps) {
+                    const float2 x0 = xs[n0 - t], x1 = xs[n0 - t - 1];
+                    ar = fmaf(h[t], x0.x, ar); ai = fmaf(h[t], x0.y, ai);
+                    br = fmaf(h[t + 1], x1.x, br); bi = fmaf(h[t + 1], x1.y, bi);
+                }
+            }
+        }
+        if (oo < kTile) part[sl][oo] = make_float2(ar + br, ai + bi);
+    }
+    __syncthreads();
+    if (threadIdx.x < n_tile) {
+        float sr = 0.f, si = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < kSlices; s2++) { const float2 v = part[s2][threadIdx.x]; sr += v.x; si += v.y; }
+        out[(size_t)k * d.out_stride + tile0 + threadIdx.x] = make_float2(sr, si);
+    }
+}
+
+// any L <= 64: one output per thread (the first 128 threads), taps read from global memory
 __global__ __launch_bounds__(256) void k_channelize(ChanDims d, const float2* __restrict__ win, const float* __restrict__ taps /* [T][L] */,
                                                     const unsigned long long* __restrict__ phase_inc /* [C], turns * 2^64 per input sample */,
-                                                    float2* __restrict__ out /* [C][n_out] */) {
+                                                    float2* __restrict__ out /* [C][out_stride] */) {
     __shared__ float2 xs[kMaxWindow];
     const int k = blockIdx.y;
     const long long tile0 = (long long)blockIdx.x * kTile;
@@ -51,17 +130,7 @@ __global__ __launch_bounds__(256) void k_channelize(ChanDims d, const float2* __
     const unsigned long long o_first = d.o0 + (unsigned long long)tile0, o_last = o_first + (unsigned long long)(n_tile - 1);
     const unsigned long long n_hi = (o_last * (unsigned long long)d.M) / (unsigned long long)d.L;
     const unsigned long long n_lo = (o_first * (unsigned long long)d.M) / (unsigned long long)d.L - (unsigned long long)(d.T - 1);
-    const int n_win = (int)(n_hi - n_lo + 1);
-    const unsigned long long inc = phase_inc[k];
-    for (int i = threadIdx.x; i < n_win; i += 256) {
-        const unsigned long long n_abs = n_lo + (unsigned long long)i;
-        const float2 x = win[n_abs - d.n_base];
-        // phase in turns = frac(n_abs * f_k / fs_in), exact in 64-bit modular arithmetic, then one rounding to float
-        const unsigned int ph = (unsigned int)((n_abs * inc) >> 32);
-        float s, c;
-        sincospif((float)ph * 4.656612873077393e-10f /* 2^-31: argument in units of pi */, &s, &c);
-        xs[i] = make_float2(fmaf(x.x, c, x.y * s), fmaf(x.y, c, -(x.x * s)));   // x * (cos - j sin)
-    }
+    stage_mixed(d, win, n_lo, (int)(n_hi - n_lo + 1), phase_inc[k], xs);
     __syncthreads();
     for (int oo = threadIdx.x; oo < n_tile; oo += 256) {
         const unsigned long long o = o_first + (unsigned long long)oo;
@@ -235,8 +304,12 @@ int fmd_chan_process_cf32_dev(fmd_channelizer h, const float* d_wide, size_t n_i
     if (hipMemcpyAsync(win + (T - 1), d_wide, sizeof(float2) * n_in, hipMemcpyDeviceToDevice, s) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "staging copy failed");
     ChanDims d{h->L, h->M, T, h->C, (long long)no, (long long)out_capacity_per_station, h->o_abs, h->n_abs - (unsigned long long)(T - 1)};
     // outputs o0 .. o0+no-1 need inputs up to floor((o0+no-1) M / L) <= n_abs + n_in - 1 by construction
-    hipLaunchKernelGGL(k_channelize, dim3((unsigned)((no + kTile - 1) / kTile), (unsigned)h->C), dim3(256), 0, s, d, win, h->taps, h->inc,
-                       reinterpret_cast<float2*>(d_out));
+    if (h->L == 16 && T % 64 == 0 && T <= 1024)
+        hipLaunchKernelGGL(k_channelize16, dim3((unsigned)((no + kTile - 1) / kTile), (unsigned)h->C), dim3(256), 0, s, d, win, h->taps, h->inc,
+                           reinterpret_cast<float2*>(d_out));
+    else
+        hipLaunchKernelGGL(k_channelize, dim3((unsigned)((no + kTile - 1) / kTile), (unsigned)h->C), dim3(256), 0, s, d, win, h->taps, h->inc,
+                           reinterpret_cast<float2*>(d_out));
     if (hipGetLastError() != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "k_channelize launch failed");
     // the last T-1 samples of [history ++ block] are the next call's history: copied into the OTHER window, so source and
     // destination never overlap however short the block is (n_in = 625 < T - 1 = 639 is a legal call)
