@@ -457,8 +457,9 @@ def main() -> None:
     value = samples_per_step * K / el / 1e6
     bps = algorithmic_bytes_per_sample(fs, args.u8)
 
-    # dominant kernel by accumulated HIP-event time on this rank
-    dom = max(ktimes.items(), key=lambda kv: kv[1][0]) if ktimes else (None, (0.0, 0))
+    # dominant kernel: the longest average launch (HIP events on the kernel's own stream); not the largest accumulated time — the
+    # timing events sample the PLL kernel twice as often as the others
+    dom = max(ktimes.items(), key=lambda kv: kv[1][0] / max(kv[1][1], 1)) if ktimes else (None, (0.0, 0))
     roofline = None
     if dom[0]:
         avg_ms = dom[1][0] / max(dom[1][1], 1)
@@ -469,7 +470,7 @@ def main() -> None:
         if tf.exists():
             try:
                 tj = json.loads(tf.read_text())
-                key = f"{dom[0]}|C={C}|fs={fs}|block={block}|{'u8' if args.u8 else 'cf32'}"
+                key = f"{dom[0]}|C={C}|fs={fs}|block={block}|{'u8' if args.u8 else 'cf32'}|{'fast' if args.fast_math else 'exact'}"
                 traffic = tj.get(key)
             except Exception:
                 traffic = None
@@ -479,10 +480,11 @@ def main() -> None:
         vf = ROOT / "profiles" / "valu_instructions.json"
         if vf.exists() and world == 1:
             try:
-                vt = json.loads(vf.read_text()).get(f"valu_total_per_block|C={C}|fs={fs}|block={block}|{'u8' if args.u8 else 'cf32'}")
+                vt = json.loads(vf.read_text()).get(f"valu_total_per_block|C={C}|fs={fs}|block={block}|{'u8' if args.u8 else 'cf32'}|{'fast' if args.fast_math else 'exact'}")
                 if vt:
                     clk = spec.get("pll_clock_mhz", 2400.0) * 1e6
-                    valu = {"wave_instructions_per_step": vt, "issue_capacity_per_s": 1024 * clk / 4.0, "issue_frac_of_step": vt / (1024 * clk / 4.0 * el / K)}
+                    cap = 1024 * clk / 2.35   # one plain wave64 VALU instruction per ~2.35 cycles and SIMD (tools/valu_rate_probe.hip; DPP ~6.2, v_sin ~8)
+                    valu = {"wave_instructions_per_step": vt, "issue_capacity_per_s": cap, "issue_frac_of_step": vt / (cap * el / K)}
             except Exception:
                 valu = None
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

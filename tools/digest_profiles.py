@@ -10,7 +10,7 @@ def newest(pattern):
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 src = ROOT / "gpurun_out" / "prof"
-rnd = sys.argv[1] if len(sys.argv) > 1 else "round1"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "round2"
 dst = ROOT / "profiles" / rnd
 dst.mkdir(parents=True, exist_ok=True)
 
@@ -53,8 +53,14 @@ def pmc(counter):
 
 fetch, write = pmc("fetch"), pmc("write")
 cfg = bench["config"]
-key_tail = f"|C={cfg['channels_per_gpu']}|fs={cfg['fs_baseband']}|block={cfg['block_size']}|{cfg['ingest']}"
-names = {"k_front": "k_front", "k_pilot_power": "k_pilot_power", "k_pilot_pll": "k_pilot_pll", "k_extract": "k_extract", "k_rds_sync": "k_rds_sync"}
+mode = "fast" if str(cfg.get("mode", "")).startswith("fast") else "exact"
+key_tail = f"|C={cfg['channels_per_gpu']}|fs={cfg['fs_baseband']}|block={cfg['block_size']}|{cfg['ingest']}|{mode}"
+names = {"k_front": "k_front", "k_pilot_power": "k_pilot_power", "k_pilot_pll": "k_pilot_pll", "k_pll_fast": "k_pll_fast", "k_extract": "k_extract",
+         "k_rds_sync": "k_rds_sync"}
+try:
+    old_traffic = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text())
+except Exception:
+    old_traffic = {}
 traffic, lines = {}, []
 for short in names:
     fk = [v for k, v in fetch.items() if short in k]
@@ -65,11 +71,12 @@ for short in names:
     total = (2.0 * fr + wr) * 1024.0     # KiB; gfx950 FETCH_SIZE counts half of a 16 B/lane stream (MI355X_MICROARCH.md, HBM section)
     traffic[short + key_tail] = total
     lines.append(f"| {short} | {fr:.0f} | {wr:.0f} | {total / 1e6:.1f} MB |")
-(ROOT / "profiles" / "hbm_traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")
+old_traffic.update(traffic)
+(ROOT / "profiles" / "hbm_traffic.json").write_text(json.dumps(old_traffic, indent=1) + "\n")
 algo = bench["roofline"]["algorithmic_bytes_per_launch"]
 (dst / "hbm_traffic_pmc.md").write_text(
     "# HBM traffic per launch, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)\n\n"
-    "Command: `rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 4 --warmup 1 --preroll 16 --no-cpu-baseline --no-pipeline`"
+    "Command: `rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 4 --warmup 1 --preroll 16 --no-cpu-baseline --no-other-mode --no-pipeline`"
     " (and WRITE_SIZE), " + cfg["workload"] + ".\nCounter unit KiB; reads doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE = 1/2 of a 16 B/lane coalesced stream)."
     " Averages over the steady-state launches.\n\n| kernel | FETCH_SIZE (KiB, raw) | WRITE_SIZE (KiB) | corrected HBM bytes / launch |\n|---|---|---|---|\n"
     + "\n".join(lines) + f"\n\nSum over the chain: {sum(traffic.values()) / 1e6:.0f} MB per block (algorithmic: {algo / 1e6:.1f} MB).\n")
@@ -91,12 +98,18 @@ try:
             insts[short] = {k: sum(x[len(x) // 2:]) / len(x[len(x) // 2:]) for k, x in v.items()}
     total_valu = sum(v.get("SQ_INSTS_VALU", 0.0) for v in insts.values())
     clock_mhz = bench.get("speculation", {}).get("pll_clock_mhz", 2400.0)
-    cap = 1024 * clock_mhz * 1e6 / 4.0          # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles each
+    cap = 1024 * clock_mhz * 1e6 / 2.35         # 256 CUs x 4 SIMDs; measured: one plain wave64 VALU instruction per 2.3-2.4 cycles and SIMD
+                                                # with >= 2 waves per SIMD (tools/valu_rate_probe.hip: 1.0 T wave-instructions/s); DPP ~6.2, v_sin ~8
     step_s = bench["ms_per_step"] * 1e-3
     summary = {"wave_instructions_per_block": insts, "valu_total_per_block": total_valu, "simd_issue_capacity_per_s": cap,
                "valu_issue_fraction_of_step": total_valu / (cap * step_s), "clock_mhz_used": clock_mhz, "ms_per_step": bench["ms_per_step"]}
     (dst / "valu_instructions_pmc.json").write_text(json.dumps(summary, indent=1) + "\n")
-    (ROOT / "profiles" / "valu_instructions.json").write_text(json.dumps({"valu_total_per_block" + key_tail: total_valu}, indent=1) + "\n")
+    try:
+        old_v = json.loads((ROOT / "profiles" / "valu_instructions.json").read_text())
+    except Exception:
+        old_v = {}
+    old_v["valu_total_per_block" + key_tail] = total_valu
+    (ROOT / "profiles" / "valu_instructions.json").write_text(json.dumps(old_v, indent=1) + "\n")
     print(json.dumps(summary, indent=1))
 except Exception as e:   # older gpurun_out without the pass
     print("no instruction-count pass:", e)
