@@ -56,7 +56,8 @@ struct FrontGeom {
     // aligned is replayed at ~64 cycles per wave instruction)
     static constexpr int NWP = (NW + 3) & ~3;
     static constexpr int OFF_THETA = 0;
-    static constexpr int OFF_DEM = OFF_THETA + NWP;
+    static constexpr int OFF_DEM = OFF_THETA;                            // the discriminator output replaces the phases in place: 9 KB less
+                                                                         // LDS per workgroup (13.7 KB), more workgroups beside the other stages' kernels
     static constexpr int OFF_FO = OFF_DEM + NWP;
     static constexpr int OFF_ATAN = (OFF_FO + (T + 64) + 7) & ~7;        // AtanTable (32-byte aligned rows)
     static constexpr int LDS_FLOATS = OFF_ATAN + kAtanTableWords;
@@ -123,14 +124,26 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
         }
     }
     __syncthreads();
-    // a2: phase difference, wrap, scale
+    // a2: phase difference, wrap, scale — in place (dem aliases theta): every thread reads its pairs, then all write
     {
         const float pi = bits_f32(kPiBits), two_pi = bits_f32(kTwoPiBits);
-        for (int j = tid; j < NW - 1; j += 256) {
-            float dlt = theta[j + 1] - theta[j];
-            if (dlt >= pi) dlt = dlt - two_pi;
-            else if (dlt <= -pi) dlt = dlt + two_pi;
-            dem[j] = dlt * taps.fm_gain;
+        constexpr int PERD = (NW - 1 + 255) / 256;
+        float dv[PERD];
+#pragma unroll
+        for (int r = 0; r < PERD; r++) {
+            const int j = tid + 256 * r;
+            if (j < NW - 1) {
+                float dlt = theta[j + 1] - theta[j];
+                if (dlt >= pi) dlt = dlt - two_pi;
+                else if (dlt <= -pi) dlt = dlt + two_pi;
+                dv[r] = dlt * taps.fm_gain;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PERD; r++) {
+            const int j = tid + 256 * r;
+            if (j < NW - 1) dem[j] = dv[r];
         }
     }
     __syncthreads();
@@ -1286,32 +1299,60 @@ __global__ __launch_bounds__(kWave) void k_lmr_phase(Dims d, const float* __rest
 // (ted_clock.cpp:18-44), Zero_Crossing_Detector, Trigger_Cooldown, and the differential Manchester
 // decoder (rds_decoder/differential_manchester_decoder.h:32-60).  Lane per channel.
 // =============================================================================================
+// Workgroup = two wavefronts for 64 channels (round 2): wave 1 only LOADS — the block's RDS baseband twice over (AGC power pass,
+// then the synchroniser pass), 32-sample chunks through a four-slot LDS ring, two chunks ahead — wave 0 runs the serial loops,
+// lane per channel, and only STORES (symbols; the post-AGC signal for FMD_FLAG_KEEP_TAPS).  See k_deemphasis for why the two
+// kinds of traffic must not share a wave on gfx9.  The differential Manchester decoder no longer runs inside the per-sample
+// loop: a symbol fires in some lane on almost every sample, so the wavefront walked the (masked) decoder ~1000 times a block for
+// ~150 symbols per lane; the loop now only packs the symbols' signs into a per-lane bit string (LDS), and the decoder runs once
+// per symbol behind it.  Same state machine, same bytes.
 template <bool FAST>
-__global__ __launch_bounds__(kWave) void k_rds_sync(Dims d, float2* __restrict__ rds,
-                                                    float* __restrict__ state, LoopCoeffs k, float* __restrict__ rds_sym,
-                                                    float2* __restrict__ rds_raw_sym, int* __restrict__ rds_count,
-                                                    uint8_t* __restrict__ rds_bytes, int* __restrict__ rds_bytes_count,
-                                                    int bytes_cap, int keep_taps) {
-    __shared__ __attribute__((aligned(16))) float2 xin[2][kWave * kRowC];
-    __builtin_amdgcn_s_setprio(3);
-    const int lane = threadIdx.x, c0 = blockIdx.x * kWave, c = c0 + lane;
+__global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restrict__ rds,
+                                                        float* __restrict__ state, LoopCoeffs k, float* __restrict__ rds_sym,
+                                                        float2* __restrict__ rds_raw_sym, int* __restrict__ rds_count,
+                                                        uint8_t* __restrict__ rds_bytes, int* __restrict__ rds_bytes_count,
+                                                        int bytes_cap, int keep_taps) {
+    constexpr int kRingSlots = 4;
+    constexpr int kSignWords = 33;                                       // up to 1024 symbols per block and lane (+1: odd stride, no bank conflicts)
+    __shared__ __attribute__((aligned(16))) float2 ring[kRingSlots][kWave * kRowC];
+    __shared__ unsigned sign_bits[kWave * kSignWords];
+    const bool loader = threadIdx.x >= kWave;                            // wave-uniform
+    const int lane = threadIdx.x & (kWave - 1), c0 = blockIdx.x * kWave, c = c0 + lane;
     const bool live = c < d.C;
     const int cs = live ? c : d.C - 1;
-    const int n = d.n_rds, chunks = n / kChunk;
-
-    // a13: AGC power pass
+    const int n = d.n_rds, chunks = n / kChunk, steps = 2 * chunks;      // step i handles chunk i mod chunks
+    if (loader) {
+        auto at = [&](int i) { return (i < steps ? i % chunks : chunks - 1) * kChunk; };
+        ChunkRegsC ra = chunk_load_c(rds, n, c0, d.C, at(0));
+        ChunkRegsC rb = chunk_load_c(rds, n, c0, d.C, at(1));
+        chunk_store_c(ra, ring[0]);
+        ra = chunk_load_c(rds, n, c0, d.C, at(2));
+        chunk_store_c(rb, ring[1]);
+        rb = chunk_load_c(rds, n, c0, d.C, at(3));
+        __syncthreads();                                                 // steps 0 and 1 are in the ring
+        for (int i = 0; i < steps; i += 2) {                             // while wave 0 works on step i: step i + 2 into its slot
+            chunk_store_c(ra, ring[(i + 2) & (kRingSlots - 1)]);
+            ra = chunk_load_c(rds, n, c0, d.C, at(i + 4));
+            __syncthreads();
+            chunk_store_c(rb, ring[(i + 3) & (kRingSlots - 1)]);
+            rb = chunk_load_c(rds, n, c0, d.C, at(i + 5));
+            __syncthreads();
+        }
+        return;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    __syncthreads();
+    // a13: AGC power pass (reference AGC_Filter::calculate_average_power, agc.h:21-30)
     float power = 0.0f;
-    ChunkRegsC regs = chunk_load_c(rds, n, c0, d.C, 0);
-    for (int ch = 0; ch < chunks; ch++) {
-        float2* buf = xin[ch & 1];
-        chunk_store_c(regs, buf);
-        __syncthreads();
-        regs = chunk_load_c(rds, n, c0, d.C, (ch + 1 < chunks ? ch + 1 : 0) * kChunk);
+    int step = 0;
+    for (; step < chunks; step++) {
+        const float2* buf = ring[step & (kRingSlots - 1)];
 #pragma unroll 8
         for (int t = 0; t < kChunk; t++) {
             const float2 x = buf[lane * kRowC + t];
             power = power + fmaf(x.x, x.x, x.y * x.y);
         }
+        __syncthreads();
     }
     float gain = st(state, S_AGC_RDS_GAIN, d.C, cs);
     {
@@ -1327,23 +1368,16 @@ __global__ __launch_bounds__(kWave) void k_rds_sync(Dims d, float2* __restrict__
     float ted_err = st(state, S_B_TED_ERR, d.C, cs), ted_x1 = st(state, S_B_TED_X1, d.C, cs), ted_y1 = st(state, S_B_TED_Y1, d.C, cs);
     float ted_int = st(state, S_B_TED_INT, d.C, cs), clock = st(state, S_B_CLOCK, d.C, cs);
     float dump_r = st(state, S_B_DUMP_R, d.C, cs), dump_i = st(state, S_B_DUMP_I, d.C, cs);
-    // Manchester decoder state: flags = is_read_bit | prev_bit<<1 | bit_index<<2 | byte_index<<5
-    unsigned mflags = __float_as_uint(st(state, S_M_FLAGS, d.C, cs));
-    unsigned mbuf[4] = {__float_as_uint(st(state, S_M_BUF0, d.C, cs)), __float_as_uint(st(state, S_M_BUF1, d.C, cs)),
-                        __float_as_uint(st(state, S_M_BUF2, d.C, cs)), __float_as_uint(st(state, S_M_BUF3, d.C, cs))};
-    int n_sym = 0, n_bytes = 0;
+    int n_sym = 0;
+    unsigned sign_word = 0u;
 
     const float Ts = 1.0f / 16e3f;
     const float KTs_pi = (10.0f * Ts) * (2e3f / 16e3f);
     const float half_pi = bits_f32(kHalfPiBits), two_over_pi = bits_f32(kTwoOverPiBits);
 
-    // (the power pass left chunk 0 in `regs` again)
-    for (int ch = 0; ch < chunks; ch++) {
-        float2* buf = xin[ch & 1];
-        __syncthreads();
-        chunk_store_c(regs, buf);
-        __syncthreads();
-        regs = chunk_load_c(rds, n, c0, d.C, (ch + 1 < chunks ? ch + 1 : ch) * kChunk);
+    for (; step < steps; step++) {
+        const int ch = step - chunks;
+        float2* buf = ring[step & (kRingSlots - 1)];
         for (int t = 0; t < kChunk; t++) {
             const float2 xr = buf[lane * kRowC + t];
             const float p = gain * xr.x, q = gain * xr.y;
@@ -1404,41 +1438,57 @@ __global__ __launch_bounds__(kWave) void k_rds_sync(Dims d, float2* __restrict__
                     rds_sym[(size_t)c * n + n_sym] = si;
                     if (keep_taps) rds_raw_sym[(size_t)c * n + n_sym] = make_float2(sr, si);
                 }
+                // the symbol's sign for the Manchester decoder behind the loop
+                sign_word |= ((si > 0.0f) ? 1u : 0u) << (n_sym & 31);
+                if ((n_sym & 31) == 31) { sign_bits[lane * kSignWords + (n_sym >> 5)] = sign_word; sign_word = 0u; }
                 n_sym++;
-                // differential Manchester: every second symbol, bit = sign(cur) xor sign(prev), MSB first
-                mflags ^= 1u;
-                if (mflags & 1u) {
-                    const unsigned cur = (si > 0.0f) ? 1u : 0u;
-                    const unsigned bit = cur ^ ((mflags >> 1) & 1u);
-                    mflags = (mflags & ~2u) | (cur << 1);
-                    unsigned bit_index = (mflags >> 2) & 7u, byte_index = (mflags >> 5) & 31u;
-                    const unsigned word = byte_index >> 2, shift = (byte_index & 3u) * 8u;
-                    if (bit_index == 0u) mbuf[word] &= ~(0xffu << shift);
-                    mbuf[word] |= (bit << (7u - bit_index)) << shift;
-                    bit_index++;
-                    byte_index += bit_index >> 3;
-                    bit_index &= 7u;
-                    if (byte_index == 16u) {
-                        byte_index = 0u;
-                        if (live && n_bytes + 16 <= bytes_cap) {
-                            uint32_t* o = reinterpret_cast<uint32_t*>(rds_bytes + (size_t)c * bytes_cap + n_bytes);
-                            o[0] = mbuf[0]; o[1] = mbuf[1]; o[2] = mbuf[2]; o[3] = mbuf[3];
-                        }
-                        n_bytes += 16;
-                    }
-                    mflags = (mflags & 3u) | (bit_index << 2) | (byte_index << 5);
-                }
             }
         }
         if (keep_taps) {
             // write the post-AGC RDS signal back (reference GetRDSOutput)
-            __syncthreads();
-            const int row = lane >> 4, col = lane & 15;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            chunk_flush_c(buf, rds, n, c0, d.C, ch * kChunk);
+        }
+        __syncthreads();
+    }
+    sign_bits[lane * kSignWords + (n_sym >> 5)] = sign_word;            // the last, partial word
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+
+    // differential Manchester (reference rds_decoder/differential_manchester_decoder.h:32-60): every second symbol,
+    // bit = sign(cur) xor sign(prev), MSB first, bytes handed on in buffers of 16.
+    // state: flags = is_read_bit | prev_bit<<1 | bit_index<<2 | byte_index<<5
+    unsigned mflags = __float_as_uint(st(state, S_M_FLAGS, d.C, cs));
+    unsigned mbuf[4] = {__float_as_uint(st(state, S_M_BUF0, d.C, cs)), __float_as_uint(st(state, S_M_BUF1, d.C, cs)),
+                        __float_as_uint(st(state, S_M_BUF2, d.C, cs)), __float_as_uint(st(state, S_M_BUF3, d.C, cs))};
+    int n_bytes = 0;
+    int max_sym = n_sym;
 #pragma unroll
-            for (int kk = 0; kk < 16; kk++) {
-                const int r = 4 * kk + row, chn = c0 + r;
-                if (chn < d.C) *reinterpret_cast<float4*>(rds + (size_t)chn * n + ch * kChunk + 2 * col) =
-                    *reinterpret_cast<const float4*>(buf + r * kRowC + 2 * col);
+    for (int dd = 32; dd >= 1; dd >>= 1) { const int o = __shfl_xor(max_sym, dd, kWave); max_sym = o > max_sym ? o : max_sym; }
+    for (int i = 0; i < max_sym; i++) {
+        if (i < n_sym) {
+            const unsigned cur = (sign_bits[lane * kSignWords + (i >> 5)] >> (i & 31)) & 1u;
+            mflags ^= 1u;
+            if (mflags & 1u) {
+                const unsigned bit = cur ^ ((mflags >> 1) & 1u);
+                mflags = (mflags & ~2u) | (cur << 1);
+                unsigned bit_index = (mflags >> 2) & 7u, byte_index = (mflags >> 5) & 31u;
+                const unsigned word = byte_index >> 2, shift = (byte_index & 3u) * 8u;
+                if (bit_index == 0u) mbuf[word] &= ~(0xffu << shift);
+                mbuf[word] |= (bit << (7u - bit_index)) << shift;
+                bit_index++;
+                byte_index += bit_index >> 3;
+                bit_index &= 7u;
+                if (byte_index == 16u) {
+                    byte_index = 0u;
+                    if (live && n_bytes + 16 <= bytes_cap) {
+                        uint32_t* o = reinterpret_cast<uint32_t*>(rds_bytes + (size_t)c * bytes_cap + n_bytes);
+                        o[0] = mbuf[0]; o[1] = mbuf[1]; o[2] = mbuf[2]; o[3] = mbuf[3];
+                    }
+                    n_bytes += 16;
+                }
+                mflags = (mflags & 3u) | (bit_index << 2) | (byte_index << 5);
             }
         }
     }
@@ -1755,10 +1805,10 @@ hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
     if (ctx.fast) {
-        FMD_LAUNCH(r, true, true, k_rds_sync<true>, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
+        FMD_LAUNCH(r, true, true, k_rds_sync<true>, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
                    b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps);
     } else {
-        FMD_LAUNCH(r, true, true, k_rds_sync<false>, dim3(serial_waves(d)), dim3(kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
+        FMD_LAUNCH(r, true, true, k_rds_sync<false>, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
                    b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps);
     }
     return hipGetLastError();
