@@ -207,6 +207,7 @@ int zero_history(fmd_handle h, hipStream_t s) {
         HIP_TRY(h, hipMemsetAsync(b.iq_tail[p], 0, sizeof(float2) * (size_t)d.C * 128, s));
         HIP_TRY(h, hipMemsetAsync(b.dt_tail[p], 0, sizeof(float) * (size_t)d.C * 128, s));
         HIP_TRY(h, hipMemsetAsync(b.fo_tail[p], 0, sizeof(float) * (size_t)d.C * 64, s));
+        HIP_TRY(h, hipMemsetAsync(b.lmr_est[p], 0, sizeof(float) * (size_t)d.C * d.n_est, s));
     }
     for (int p = 0; p < kSlots; p++) {
         HIP_TRY(h, hipMemsetAsync(b.rds_count[p], 0, sizeof(int) * (size_t)d.C, s));
@@ -532,7 +533,8 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
         if (!rc) rc = dev_alloc(h, &b.rds_bytes_count[p], C);
         if (!rc) rc = dev_alloc(h, &b.rds[p], C * d.n_rds);
     }
-    if (!rc) rc = dev_alloc(h, &b.lmr_est, C * d.n_est);
+    for (int p = 0; p < 2 && !rc; p++) rc = dev_alloc(h, &b.lmr_est[p], C * d.n_est);
+    if (!rc) rc = dev_alloc(h, &b.lmr_peek, C);
     if (!rc) rc = dev_alloc(h, &b.b_lpr, C * 128);
     if (!rc) rc = dev_alloc(h, &b.b_lmr, C * 128);
     if (!rc) rc = dev_alloc(h, &b.deemph, C * 4);
@@ -737,19 +739,19 @@ int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats
     const int o = h->out_slot;
     const void* p = nullptr;
     size_t n = 0;
-    bool from_state = false;
+    bool from_state = false, lmr_peek = false;
     int field = 0;
     const std::string s(name);
     if (s == "fm_out_iq") { p = b.fm_out_iq[o]; n = 2 * C * d.n_fm_out; }
     else if (s == "pll_dt") { p = b.pll_dt[o]; n = C * d.n_fm_out; }
     else if (s == "audio") { p = b.audio[o]; n = 2 * C * d.n_audio; }
     else if (s == "rds_sym") { p = b.rds_sym[o]; n = C * d.n_rds; }
-    else if (s == "lmr_est") { p = b.lmr_est; n = C * d.n_est; }
+    else if (s == "lmr_est") { p = b.lmr_est[(h->n_blocks + 1) & 1]; n = C * d.n_est; }
     else if (s == "rds" ) { p = b.rds[o]; n = 2 * C * d.n_rds; }
     else if (s == "lpr" && keep) { p = b.lpr[o]; n = C * d.n_audio; }
     else if (s == "lmr" && keep) { p = b.lmr[o]; n = C * d.n_audio; }
     else if (s == "rds_raw_sym" && keep) { p = b.rds_raw_sym[o]; n = 2 * C * d.n_rds; }
-    else if (s == "lmr_phase") { from_state = true; field = S_LMR_PHASE_CUR; }
+    else if (s == "lmr_phase") { lmr_peek = true; p = b.lmr_peek; n = C; }
     else if (s == "agc_pilot_gain") { from_state = true; field = S_AGC_PILOT_GAIN; }
     else if (s == "agc_rds_gain") { from_state = true; field = S_AGC_RDS_GAIN; }
     else if (s == "lpr" || s == "lmr" || s == "rds_raw_sym") return fail(h, FMD_ERR_NAME, "stream '%s' needs FMD_FLAG_KEEP_TAPS", name);
@@ -759,6 +761,10 @@ int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats
     if (!out || cap_floats < n) return fail(h, FMD_ERR_ARG, "stream '%s' needs %zu floats", name, n);  // size query: out may be NULL
     int rc = fmd_synchronize(h);
     if (rc) return rc;
+    if (lmr_peek) {   // reference GetAudioLMRPhaseError(): the offset after the newest block's update (the next block's k_extract computes it for itself)
+        HIP_TRY(h, launch_lmr_phase_peek(h->ctx, (int)((h->n_blocks + 1) & 1), b.lmr_peek, h->own_stream));
+        HIP_TRY(h, hipStreamSynchronize(h->own_stream));
+    }
     HIP_TRY(h, hipMemcpy(out, p, sizeof(float) * n, hipMemcpyDeviceToHost));
     return FMD_OK;
 }
@@ -768,17 +774,18 @@ extern "C++" {
 namespace {
 struct StateHeader { uint32_t magic, version; int32_t fs_baseband, m, n_fields, tail_base; uint32_t reserved[2]; };
 constexpr uint32_t kStateMagic = 0x53444d46u;   // "FMDS"
-struct StatePart { void* base[2]; size_t floats; bool by_parity; };   // per-channel row of `floats` floats at base[par] + channel * floats
+struct StatePart { void* base[2]; size_t floats; int par_flip; };   // per-channel row of `floats` floats at base[par ^ par_flip] + channel * floats
 
 std::vector<StatePart> state_parts(fmd_handle h) {
     const Dims& d = h->ctx.d;
     Buffers& b = h->ctx.b;
     std::vector<StatePart> v;
-    v.push_back({{b.base_tail[0], b.base_tail[1]}, (size_t)d.tail_base * 2, true});
-    if (d.m > 1) v.push_back({{b.pre_tail[0], b.pre_tail[1]}, 64 * 2, true});
-    v.push_back({{b.iq_tail[0], b.iq_tail[1]}, 128 * 2, true});
-    v.push_back({{b.dt_tail[0], b.dt_tail[1]}, 128, true});
-    v.push_back({{b.fo_tail[0], b.fo_tail[1]}, 64, true});
+    v.push_back({{b.base_tail[0], b.base_tail[1]}, (size_t)d.tail_base * 2, 0});
+    if (d.m > 1) v.push_back({{b.pre_tail[0], b.pre_tail[1]}, 64 * 2, 0});
+    v.push_back({{b.iq_tail[0], b.iq_tail[1]}, 128 * 2, 0});
+    v.push_back({{b.dt_tail[0], b.dt_tail[1]}, 128, 0});
+    v.push_back({{b.fo_tail[0], b.fo_tail[1]}, 64, 0});
+    v.push_back({{b.lmr_est[0], b.lmr_est[1]}, (size_t)d.n_est, 1});   // the newest block's L-R phase estimates (the next k_extract integrates them)
     return v;
 }
 size_t state_floats(fmd_handle h) {
@@ -799,15 +806,17 @@ int fmd_get_state(fmd_handle h, int channel, void* blob, size_t cap_bytes) {
     int rc = sync_all(h);
     if (rc) return rc;
     const Dims& d = h->ctx.d;
-    StateHeader hd{kStateMagic, 1u, h->cfg.fs_baseband, d.m, (int32_t)S_NUM_FIELDS, d.tail_base, {0u, 0u}};
+    StateHeader hd{kStateMagic, 2u, h->cfg.fs_baseband, d.m, (int32_t)S_NUM_FIELDS, d.tail_base, {0u, 0u}};
     std::memcpy(blob, &hd, sizeof(hd));
     float* out = reinterpret_cast<float*>(static_cast<char*>(blob) + sizeof(hd));
     // SoA fields [field][C] -> one float per field
     HIP_TRY(h, hipMemcpy2D(out, sizeof(float), h->ctx.b.state + channel, sizeof(float) * (size_t)d.C, sizeof(float), S_NUM_FIELDS, hipMemcpyDeviceToHost));
-    out += S_NUM_FIELDS;
     const int par = (int)(h->n_blocks & 1);   // the histories the NEXT block reads
+    // the two L-R phase fields hold P_k by k & 1 (fmd_kernels.hip: lmr_field); in the blob: PREV = the newest block's offset
+    if (par == 1) std::swap(out[S_LMR_PHASE_CUR], out[S_LMR_PHASE_PREV]);
+    out += S_NUM_FIELDS;
     for (const StatePart& p : state_parts(h)) {
-        HIP_TRY(h, hipMemcpy(out, static_cast<float*>(p.base[par]) + (size_t)channel * p.floats, sizeof(float) * p.floats, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(out, static_cast<float*>(p.base[par ^ p.par_flip]) + (size_t)channel * p.floats, sizeof(float) * p.floats, hipMemcpyDeviceToHost));
         out += p.floats;
     }
     return FMD_OK;
@@ -821,17 +830,19 @@ int fmd_set_state(fmd_handle h, int channel, const void* blob, size_t n_bytes) {
     StateHeader hd;
     if (n_bytes < sizeof(hd)) return fail(h, FMD_ERR_ARG, "state blob too short");
     std::memcpy(&hd, blob, sizeof(hd));
-    if (hd.magic != kStateMagic || hd.version != 1u || hd.fs_baseband != h->cfg.fs_baseband || hd.m != d.m || hd.n_fields != (int32_t)S_NUM_FIELDS ||
+    if (hd.magic != kStateMagic || hd.version != 2u || hd.fs_baseband != h->cfg.fs_baseband || hd.m != d.m || hd.n_fields != (int32_t)S_NUM_FIELDS ||
         hd.tail_base != d.tail_base || n_bytes != fmd_state_size(h))
         return fail(h, FMD_ERR_ARG, "state blob does not match this handle (rate %d vs %d, %zu vs %zu bytes)", hd.fs_baseband, h->cfg.fs_baseband, n_bytes, fmd_state_size(h));
     int rc = sync_all(h);
     if (rc) return rc;
     const float* in = reinterpret_cast<const float*>(static_cast<const char*>(blob) + sizeof(hd));
-    HIP_TRY(h, hipMemcpy2D(h->ctx.b.state + channel, sizeof(float) * (size_t)d.C, in, sizeof(float), sizeof(float), S_NUM_FIELDS, hipMemcpyHostToDevice));
-    in += S_NUM_FIELDS;
     const int par = (int)(h->n_blocks & 1);
+    std::vector<float> fields(in, in + S_NUM_FIELDS);
+    if (par == 1) std::swap(fields[S_LMR_PHASE_CUR], fields[S_LMR_PHASE_PREV]);   // see fmd_get_state
+    HIP_TRY(h, hipMemcpy2D(h->ctx.b.state + channel, sizeof(float) * (size_t)d.C, fields.data(), sizeof(float), sizeof(float), S_NUM_FIELDS, hipMemcpyHostToDevice));
+    in += S_NUM_FIELDS;
     for (const StatePart& p : state_parts(h)) {
-        HIP_TRY(h, hipMemcpy(static_cast<float*>(p.base[par]) + (size_t)channel * p.floats, in, sizeof(float) * p.floats, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(static_cast<float*>(p.base[par ^ p.par_flip]) + (size_t)channel * p.floats, in, sizeof(float) * p.floats, hipMemcpyHostToDevice));
         in += p.floats;
     }
     return FMD_OK;

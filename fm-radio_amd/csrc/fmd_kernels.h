@@ -51,7 +51,7 @@ enum StateField : int {
 // each of a channel's 32 lanes runs kPilotSeg samples from a zero state, the segment end states are combined across the lanes
 // with powers of the transition matrix A = [[a1, a0], [1, 0]], and the homogeneous solution is added back.  Designed on the
 // host in double precision (fmd_api.cpp design_pilot_fast).
-static constexpr int kPilotSeg = 4;
+static constexpr int kPilotSeg = 2;
 struct PilotFastTab {
     float h1[kPilotSeg], h2[kPilotSeg];   // y[k] += h1[k] y[-1] + h2[k] y[-2]: first row of A^(k+1)
     float m[4][4];                        // M^(2^s), M = A^kPilotSeg, as (m00, m01, m10, m11): steps of the cross-lane scan within a row of 16 lanes
@@ -95,7 +95,8 @@ struct Buffers {
     float2* pilot[kSlots];       // [C][n_fm_out]  pilot peak IIR output before AGC (k_pilot_power -> k_pilot_pll)
     float*  pll_dt[kSlots];      // [C][n_fm_out]
     float2* rds[kSlots];    // [C][n_rds]      (extract -> rds_sync, which runs on its own stream)
-    float*  lmr_est;        // [C][n_est]
+    float*  lmr_est[2];     // [C][n_est], by block parity (the next block's k_extract integrates them)
+    float*  lmr_peek;       // [C] scratch row of the "lmr_phase" getter
     // outputs
     float*  audio[kSlots];       // [C][n_audio][2]
     float*  rds_sym[kSlots];     // [C][n_rds]
@@ -144,6 +145,7 @@ hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s);  
 hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                               // k_pilot_pll
 hipError_t launch_stage_extract(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                           // k_extract
 hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                               // k_rds_sync
+hipError_t launch_lmr_phase_peek(const LaunchCtx& ctx, int par, float* out_row, hipStream_t s);            // k_lmr_phase into a scratch row
 hipError_t launch_reset_state(const LaunchCtx& ctx, hipStream_t stream);
 hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, unsigned char* d_ok, size_t n, int table_form, hipStream_t s);
 hipError_t launch_audio_pcm16(const float* d_audio, int16_t* d_pcm, size_t n_values, hipStream_t s);   // k_audio_pcm16

@@ -1114,6 +1114,26 @@ __device__ __forceinline__ void fir8_quad(const float* __restrict__ ph, int P, i
     for (int v = 0; v < 4; v++) out[v] = (acc[v][0] + acc[v][2]) + (acc[v][1] + acc[v][3]);
 }
 
+constexpr int kLmrInlineMax = 512;   // estimates per block (n_audio / 10) up to which k_extract integrates the L-R phase itself
+
+// reference ExtractComponents :511-516 — avg = sum / n; phase = fmod(phase + 0.1 avg, 2 pi)
+__device__ __forceinline__ float lmr_phase_finish(float sum, int n_est, float cur) {
+    const float avg = sum / (float)n_est;
+    const float acc = fmaf(avg, 0.1f, cur);
+    return fmodf(acc, bits_f32(kTwoPiBits));
+}
+// the block's estimates (LDS, padded with nothing: exactly n_est are read) summed in sample order, by every lane alike
+__device__ __forceinline__ float lmr_phase_update(const float* est_s, int n_est, float cur) {
+    float sum = 0.0f;
+    int i = 0;
+    for (; i + 4 <= n_est; i += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(est_s + i);
+        sum = sum + v.x; sum = sum + v.y; sum = sum + v.z; sum = sum + v.w;
+    }
+    for (; i < n_est; i++) sum = sum + est_s[i];
+    return lmr_phase_finish(sum, n_est, cur);
+}
+
 template <int TA, bool FAST = false>
 __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict__ fm_out_iq, const float* __restrict__ pll_dt,
                                                 const float2* __restrict__ iq_tail_in, const float* __restrict__ dt_tail_in,
@@ -1121,7 +1141,8 @@ __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict
                                                 const float* __restrict__ b_lpr, const float* __restrict__ b_lmr, RdsTaps rds_taps,
                                                 const float* __restrict__ mixctl, float* __restrict__ state,
                                                 float* __restrict__ audio, float2* __restrict__ rds, float* __restrict__ lmr_est,
-                                                float* __restrict__ lpr_out, float* __restrict__ lmr_out, int keep_taps) {
+                                                float* __restrict__ lpr_out, float* __restrict__ lmr_out, int keep_taps,
+                                                const float* __restrict__ lmr_est_prev, int field_cur, int field_prev) {
     using G = ExtractGeom<TA>;
     constexpr int XS = G::XS, P4 = G::P4, P8 = G::P8, NQ = G::NQ;
     __shared__ __attribute__((aligned(16))) float lpr_ph[4 * P4];     // Re fm_out_iq, 4 phases
@@ -1142,12 +1163,24 @@ __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict
     const int n = d.n_fm_out;
     const float2* x_c = fm_out_iq + (size_t)c * n;
     const float* dt_c = pll_dt + (size_t)c * n;
-    const float off_cur = st(state, S_LMR_PHASE_CUR, d.C, c), off_prev = st(state, S_LMR_PHASE_PREV, d.C, c);
+    // L-R phase offsets: state field (k & 1) holds P_k, the offset block k was mixed with.  lmr_est_prev != nullptr: this launch
+    // derives its own P_b from P_{b-1} and the previous block's estimates (lmr_phase_update below, done by the first wavefront
+    // while the tile's samples are in flight) and tile 0 publishes it; otherwise k_lmr_phase has written P_b behind block b-1.
+    const float off_prev = st(state, field_prev, d.C, c);
+    float off_cur = lmr_est_prev ? 0.0f : st(state, field_cur, d.C, c);
+    __shared__ __attribute__((aligned(16))) float est_s[kLmrInlineMax];
+    __shared__ float off_s;
 
     // stage + mix: all loads first, then the arithmetic
     {
         constexpr int PER = (XS + TA - 1) / TA;
         float2 xv[PER]; float dv[PER];
+        float ev[kLmrInlineMax / kWave];
+        if (lmr_est_prev && tid < kWave) {
+#pragma unroll
+            for (int k = 0; k < kLmrInlineMax / kWave; k++)
+                ev[k] = (tid + kWave * k < d.n_est) ? lmr_est_prev[(size_t)c * d.n_est + tid + kWave * k] : 0.0f;
+        }
         if (tile != 0) {
 #pragma unroll
             for (int r = 0; r < PER; r++) {
@@ -1164,6 +1197,18 @@ __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict
                     dv[r] = (s < 0) ? dt_tail_in[(size_t)c * 128 + 128 + s] : dt_c[s];
                 }
             }
+        }
+        if (lmr_est_prev) {
+            if (tid < kWave) {
+#pragma unroll
+                for (int k = 0; k < kLmrInlineMax / kWave; k++) est_s[tid + kWave * k] = ev[k];
+                __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wavefront's own LDS writes, read back below
+                __builtin_amdgcn_wave_barrier();
+                const float nxt = lmr_phase_update(est_s, d.n_est, off_prev);   // every lane the same value
+                if (tid == 0) { off_s = nxt; if (tile == 0) st(state, field_cur, d.C, c) = nxt; }
+            }
+            __syncthreads();
+            off_cur = off_s;
         }
         // FMD_FLAG_FAST_MATH: one hardware sine / cosine of the pilot phase per sample, the x2 and x3 harmonics by angle
         // multiplication, the L-R phase offset as a rotation by a per-block constant
@@ -1267,9 +1312,12 @@ __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict
 }
 
 // a11 — reference ExtractComponents :511-516: integrate the mean L-R phase error of the block (sequential sum in sample order).
-// Its own small kernel, right behind k_extract on the same stream: the next block's k_extract needs the updated offset, the
-// (long, serial) k_rds_sync of this block does not, so that one runs on a stream of its own.
-__global__ __launch_bounds__(kWave) void k_lmr_phase(Dims d, const float* __restrict__ lmr_est, float* __restrict__ state) {
+// Tolerance mode, blocks of up to 10 * kLmrInlineMax audio samples: the NEXT block's k_extract does it for itself
+// (lmr_phase_update in its prologue — a kernel of its own behind k_extract put two launch gaps per block on the one chain of that
+// pipeline that cannot overlap with itself).  Exact mode, longer blocks, and the "lmr_phase" getter: this kernel,
+// P_next = update(state[field_in], estimates) into out_row[c] (a state field, or a scratch row for the getter).
+__global__ __launch_bounds__(kWave) void k_lmr_phase(Dims d, const float* __restrict__ lmr_est, const float* __restrict__ state, int field_in,
+                                                     float* __restrict__ out_row) {
     constexpr int TILE = 128;                            // estimates per channel staged at a time
     __shared__ float est[kWave][TILE + 1];
     const int c0 = blockIdx.x * kWave, c = c0 + threadIdx.x;
@@ -1286,11 +1334,7 @@ __global__ __launch_bounds__(kWave) void k_lmr_phase(Dims d, const float* __rest
         for (int i = 0; i < w; i++) sum = sum + est[threadIdx.x][i];   // sequential, in sample order
     }
     if (c >= d.C) return;
-    const float avg = sum / (float)d.n_est;
-    const float cur = st(state, S_LMR_PHASE_CUR, d.C, c);
-    const float acc = fmaf(avg, 0.1f, cur);
-    const float nxt = fmodf(acc, bits_f32(kTwoPiBits));
-    st(state, S_LMR_PHASE_PREV, d.C, c) = cur; st(state, S_LMR_PHASE_CUR, d.C, c) = nxt;
+    out_row[c] = lmr_phase_finish(sum, d.n_est, state[(size_t)field_in * d.C + c]);
 }
 
 // =============================================================================================
@@ -1782,6 +1826,11 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Tolerance mode only: in the exact mode the pilot PLL's launch chain sets the step, and k_extract launches running back to back
+// (no k_lmr_phase and its two launch gaps between them) take more of the chip from it than the gaps cost (same-box A/B: -8 %)
+static inline bool lmr_inline(const LaunchCtx& ctx) { return ctx.fast && ctx.d.n_est <= kLmrInlineMax; }
+static inline int lmr_field(int par) { return par ? (int)S_LMR_PHASE_PREV : (int)S_LMR_PHASE_CUR; }   // state field holding P_k, k & 1 == par
+
 template <int TA, bool FAST = false>
 static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
@@ -1791,13 +1840,22 @@ static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     }
     FMD_LAUNCH(r, true, true, (k_extract<TA, FAST>), dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fm_out_iq[r.buf], b.pll_dt[r.buf],
                        b.iq_tail[r.par], b.dt_tail[r.par], b.iq_tail[r.par ^ 1], b.dt_tail[r.par ^ 1], b.b_lpr, b.b_lmr, ctx.rds_taps, b.mix,
-                       b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est, b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps);
+                       b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est[r.par], b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps,
+                       lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr, lmr_field(r.par), lmr_field(r.par ^ 1));
 }
 
 hipError_t launch_stage_extract(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     if (ctx.d.n_audio % 256 == 0) launch_extract_ta<256>(ctx, r, s);
     else launch_extract_ta<128>(ctx, r, s);
-    hipLaunchKernelGGL(k_lmr_phase, dim3(serial_waves(ctx.d)), dim3(kWave), 0, s, ctx.d, ctx.b.lmr_est, ctx.b.state);
+    if (!lmr_inline(ctx))   // P_{b+1} behind block b
+        hipLaunchKernelGGL(k_lmr_phase, dim3(serial_waves(ctx.d)), dim3(kWave), 0, s, ctx.d, ctx.b.lmr_est[r.par], ctx.b.state, lmr_field(r.par),
+                           ctx.b.state + (size_t)lmr_field(r.par ^ 1) * ctx.d.C);
+    return hipGetLastError();
+}
+
+// the value the reference's GetAudioLMRPhaseError() shows after the newest block (parity `par`): P_{b+1}, into out_row[C]
+hipError_t launch_lmr_phase_peek(const LaunchCtx& ctx, int par, float* out_row, hipStream_t s) {
+    hipLaunchKernelGGL(k_lmr_phase, dim3(serial_waves(ctx.d)), dim3(kWave), 0, s, ctx.d, ctx.b.lmr_est[par], ctx.b.state, lmr_field(par), out_row);
     return hipGetLastError();
 }
 

@@ -132,6 +132,36 @@ def test_fast_mode_is_within_the_north_star_tolerance_of_the_oracle(pkg, fs, u8)
     assert worst["pll_dt"] <= 5e-5          # turns
 
 
+def test_fast_mode_blocks_longer_than_the_inline_lmr_phase_limit(pkg):
+    """Up to 5120 audio samples per block the next block's k_extract integrates the L-R phase estimates itself; longer blocks
+    (here 65536 samples at 256 kSa/s = 8192 audio samples, 820 estimates) take the k_lmr_phase kernel behind k_extract.
+
+    Also shows the one discontinuity on the audio path (reference :500-510): each estimate is +-pi/2 - atan2(im, re) by the
+    SIGN of the L-R sample, so a sample within the arithmetic difference of zero (here ~1e-5) lands pi away in one of the two
+    evaluations and moves that block's offset by 0.1 pi / n_est.  The L-R of the next block is then rotated by that much (still
+    < 1e-3 RMS) until the loop has pulled the two back together; L+R is never affected."""
+    bs, nb, fs = 65536, 8, 256_000
+    caps = _caps(2, nb * bs, float(fs), seed=9300)
+    g = run_gpu(pkg, caps, bs, fs, fast_math=True)
+    n_a = bs // 8
+    flips = 0
+    for c in range(2):
+        o = O.run_chain(caps[c], bs, fs, u8=False, coeffs=lib_coeffs_to_oracle(g["coeffs"][c]), streams=["lpr", "lmr", "audio", "lmr_phase", "rds_sym"])
+        assert rms(np.asarray(g["lpr"][c], np.float64).reshape(-1) - o["lpr"].reshape(-1)) <= TOL_RMS
+        off_g, off_o = np.asarray(g["lmr_phase"][c], np.float64).reshape(-1)[:nb], o["lmr_phase"].reshape(-1)[:nb].astype(np.float64)
+        for k in ("lmr", "audio"):
+            w = n_a * (2 if k == "audio" else 1)
+            a = np.asarray(g[k][c], np.float64).reshape(nb, w)
+            b = o[k].reshape(nb, w).astype(np.float64)
+            for blk in range(nb):
+                # the offset a block is mixed with is the one the previous block left
+                moved = blk > 0 and abs(off_g[blk - 1] - off_o[blk - 1]) > 5e-5
+                flips += int(moved and k == "lmr")
+                assert rms(a[blk] - b[blk]) <= (1e-3 if moved else TOL_RMS), (c, k, blk, rms(a[blk] - b[blk]), off_g[blk - 1] - off_o[blk - 1])
+        assert same_bits_once_in_lock(g["rds_bytes"][c], o["rds_bytes"], skip_bits=5 * 76)
+    print("blocks mixed with an offset that one flipped estimate had moved:", flips)
+
+
 def test_fast_mode_golden_chain_fixture(pkg, golden):
     """Against vectors dumped from the compiled reference (tests/golden/chain_b16384.npz), the same bar the exact mode meets."""
     g = golden("chain_b16384.npz")

@@ -56,6 +56,11 @@ def test_block_65536_torch_device_pointer(pkg):
     _assert_exact(compare_with_oracle(pkg, _caps(2, 3 * 65536), 65536, 1_024_000, use_torch=True))
 
 
+def test_blocks_longer_than_the_inline_lmr_phase_limit(pkg):
+    """Long blocks (here 65536 samples at 256 kSa/s = 8192 audio samples, 820 L-R phase estimates per block)."""
+    _assert_exact(compare_with_oracle(pkg, _caps(2, 3 * 65536, fs=256_000.0, seed=41), 65536, 256_000))
+
+
 def test_more_than_one_wavefront_of_channels(pkg):
     # 70 channels -> two wavefronts, the second one mostly clamped
     caps = _caps(70, 2 * 4096, seed=300)
