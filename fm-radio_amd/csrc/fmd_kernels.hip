@@ -1122,16 +1122,11 @@ __device__ __forceinline__ float lmr_phase_finish(float sum, int n_est, float cu
     const float acc = fmaf(avg, 0.1f, cur);
     return fmodf(acc, bits_f32(kTwoPiBits));
 }
-// the block's estimates (LDS, padded with nothing: exactly n_est are read) summed in sample order, by every lane alike
-__device__ __forceinline__ float lmr_phase_update(const float* est_s, int n_est, float cur) {
-    float sum = 0.0f;
-    int i = 0;
-    for (; i + 4 <= n_est; i += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(est_s + i);
-        sum = sum + v.x; sum = sum + v.y; sum = sum + v.z; sum = sum + v.w;
-    }
-    for (; i < n_est; i++) sum = sum + est_s[i];
-    return lmr_phase_finish(sum, n_est, cur);
+// sum over the 64 lanes of a wavefront, the same value in every lane
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    return v;
 }
 
 template <int TA, bool FAST = false>
@@ -1164,11 +1159,10 @@ __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict
     const float2* x_c = fm_out_iq + (size_t)c * n;
     const float* dt_c = pll_dt + (size_t)c * n;
     // L-R phase offsets: state field (k & 1) holds P_k, the offset block k was mixed with.  lmr_est_prev != nullptr: this launch
-    // derives its own P_b from P_{b-1} and the previous block's estimates (lmr_phase_update below, done by the first wavefront
+    // derives its own P_b from P_{b-1} and the previous block's estimates (done by the first wavefront
     // while the tile's samples are in flight) and tile 0 publishes it; otherwise k_lmr_phase has written P_b behind block b-1.
     const float off_prev = st(state, field_prev, d.C, c);
     float off_cur = lmr_est_prev ? 0.0f : st(state, field_cur, d.C, c);
-    __shared__ __attribute__((aligned(16))) float est_s[kLmrInlineMax];
     __shared__ float off_s;
 
     // stage + mix: all loads first, then the arithmetic
@@ -1200,11 +1194,12 @@ __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict
         }
         if (lmr_est_prev) {
             if (tid < kWave) {
+                // (tolerance mode: the block's estimates summed as a tree, not in sample order — ~20 instructions in one wavefront
+                // of every tile instead of n_est dependent additions)
+                float part = 0.0f;
 #pragma unroll
-                for (int k = 0; k < kLmrInlineMax / kWave; k++) est_s[tid + kWave * k] = ev[k];
-                __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wavefront's own LDS writes, read back below
-                __builtin_amdgcn_wave_barrier();
-                const float nxt = lmr_phase_update(est_s, d.n_est, off_prev);   // every lane the same value
+                for (int k = 0; k < kLmrInlineMax / kWave; k++) part += ev[k];
+                const float nxt = lmr_phase_finish(wave_sum_f32(part), d.n_est, off_prev);   // every lane the same value
                 if (tid == 0) { off_s = nxt; if (tile == 0) st(state, field_cur, d.C, c) = nxt; }
             }
             __syncthreads();
@@ -1313,7 +1308,7 @@ __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict
 
 // a11 — reference ExtractComponents :511-516: integrate the mean L-R phase error of the block (sequential sum in sample order).
 // Tolerance mode, blocks of up to 10 * kLmrInlineMax audio samples: the NEXT block's k_extract does it for itself
-// (lmr_phase_update in its prologue — a kernel of its own behind k_extract put two launch gaps per block on the one chain of that
+// (in its prologue — a kernel of its own behind k_extract put two launch gaps per block on the one chain of that
 // pipeline that cannot overlap with itself).  Exact mode, longer blocks, and the "lmr_phase" getter: this kernel,
 // P_next = update(state[field_in], estimates) into out_row[c] (a state field, or a scratch row for the getter).
 __global__ __launch_bounds__(kWave) void k_lmr_phase(Dims d, const float* __restrict__ lmr_est, const float* __restrict__ state, int field_in,
@@ -1826,9 +1821,10 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     return hipGetLastError();
 }
 
-// Tolerance mode only: in the exact mode the pilot PLL's launch chain sets the step, and k_extract launches running back to back
-// (no k_lmr_phase and its two launch gaps between them) take more of the chip from it than the gaps cost (same-box A/B: -8 %)
-static inline bool lmr_inline(const LaunchCtx& ctx) { return ctx.fast && ctx.d.n_est <= kLmrInlineMax; }
+// Tolerance mode, batches up to 6144 stations: same-box A/B +3 % at 4096 stations, but -3 % at 8192 and -4 % at 16384 (there the
+// k_extract launches running back to back crowd k_front out: its launches take 1.7x as long); and in the exact mode the pilot
+// PLL's launch chain sets the step, which k_extract launches without gaps between them slow down (-8 %).
+static inline bool lmr_inline(const LaunchCtx& ctx) { return ctx.fast && ctx.d.n_est <= kLmrInlineMax && effective_channels(ctx.d) <= 6144; }
 static inline int lmr_field(int par) { return par ? (int)S_LMR_PHASE_PREV : (int)S_LMR_PHASE_CUR; }   // state field holding P_k, k & 1 == par
 
 template <int TA, bool FAST = false>
