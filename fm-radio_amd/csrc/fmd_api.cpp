@@ -142,6 +142,7 @@ int upload_controls(fmd_handle h, hipStream_t s) {
     const int C = h->cfg.n_channels;
     std::vector<float> lpr((size_t)C * 128), lmr((size_t)C * 128), de((size_t)C * 4), mix((size_t)C * 2);
     int any = 0;
+    bool slow_pole = false;   // a de-emphasis time constant beyond what k_front's in-tile form covers (fmd_kernels.hip kDeemphWarmup)
     for (int c = 0; c < C; c++) {
         const fmd_controls& k = h->controls[c];
         const auto& a = lpf_taps(h, k.lpr_cutoff_hz);
@@ -153,6 +154,7 @@ int upload_controls(fmd_handle h, hipStream_t s) {
         de[4 * c + 0] = kk.deemph_b[0]; de[4 * c + 1] = kk.deemph_b[1]; de[4 * c + 2] = kk.deemph_a[0];
         de[4 * c + 3] = k.use_deemphasis ? 1.0f : 0.0f;
         any |= k.use_deemphasis ? 1 : 0;
+        if (k.use_deemphasis && !(kk.deemph_a[0] >= 0.0f && kk.deemph_a[0] <= 0.905f)) slow_pole = true;
         mix[2 * c] = (float)k.audio_out; mix[2 * c + 1] = k.audio_stereo_mix_factor;
     }
     Buffers& b = h->ctx.b;
@@ -161,10 +163,17 @@ int upload_controls(fmd_handle h, hipStream_t s) {
     HIP_TRY(h, hipMemcpyAsync(b.deemph, de.data(), de.size() * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(b.mix, mix.data(), mix.size() * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipStreamSynchronize(s));  // the host vectors die here
-    if (any) { h->ctx.any_deemph = 1; h->deemph_linger = false; }
-    else if (h->deemph_on) { h->ctx.any_deemph = 1; h->deemph_linger = true; }
-    else if (!h->deemph_linger) h->ctx.any_deemph = 0;
-    h->deemph_on = any != 0;
+    // FMD_FLAG_FAST_MATH: the IIR runs inside k_front's tile (no state, no extra stage) unless a channel's time constant is too long
+    // for its warm-up; a switch between the two forms (controls changed across ~79 us) restarts the filter from the state the other
+    // form last left: a transient of a millisecond on those channels
+    h->ctx.deemph_in_tile = (h->ctx.fast && any && !slow_pole) ? 1 : 0;
+    if (h->ctx.deemph_in_tile) { h->ctx.any_deemph = 0; h->deemph_linger = false; h->deemph_on = false; }
+    else {
+        if (any) { h->ctx.any_deemph = 1; h->deemph_linger = false; }
+        else if (h->deemph_on) { h->ctx.any_deemph = 1; h->deemph_linger = true; }
+        else if (!h->deemph_linger) h->ctx.any_deemph = 0;
+        h->deemph_on = any != 0;
+    }
     h->controls_dirty = false;
     return FMD_OK;
 }
@@ -493,7 +502,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     h->ctx.pll_k16_max_channels = (cfg->flags & FMD_FLAG_PLL_K8) ? 0 : 3584;
     d.n_fm_in = d.N / m; d.n_fm_out = d.n_fm_in / 2; d.n_rds = d.n_fm_out / 8; d.n_audio = d.n_fm_out / 4;
     d.n_est = (d.n_audio + 9) / 10;
-    d.tail_base = front_tail_len(m);
+    d.tail_base = front_tail_len(m, (cfg->flags & FMD_FLAG_FAST_MATH) != 0);
     h->bytes_cap = 16 * (d.n_rds / 256 + 1);
     h->ctx.bytes_cap = h->bytes_cap;
     h->ctx.keep_taps = (cfg->flags & FMD_FLAG_KEEP_TAPS) ? 1 : 0;

@@ -131,6 +131,7 @@ struct LaunchCtx {
     int fast;                             // FMD_FLAG_FAST_MATH: the tolerance-mode kernels
     float pll_hold_hz;                    // k_pll_fast: a span ends where the NCO frequency has moved further than this from the held word
     int any_deemph;
+    int deemph_in_tile;     // FMD_FLAG_FAST_MATH: the de-emphasis IIR runs inside k_front's tile (every filtering channel's pole <= 0.905, i.e. up to ~79 us)
     int bytes_cap;
     int pll_time_parallel_max_channels;   // batches up to this size use the time-parallel PLL kernel, larger ones the low-work one
     int pll_k16_max_channels;             // (channels x m) up to this: 16 lanes per channel, above: 8
@@ -150,6 +151,6 @@ hipError_t launch_reset_state(const LaunchCtx& ctx, hipStream_t stream);
 hipError_t selftest_atan2(const float* d_y, const float* d_x, float* d_out, unsigned char* d_ok, size_t n, int table_form, hipStream_t s);
 hipError_t launch_audio_pcm16(const float* d_audio, int16_t* d_pcm, size_t n_values, hipStream_t s);   // k_audio_pcm16
 hipError_t prepare_kernels();          // one-time function attributes (dynamic LDS sizes)
-int front_tail_len(int m);             // input-history samples k_front needs per channel
+int front_tail_len(int m, bool fast);  // input-history samples k_front keeps per channel
 
 }  // namespace fmd

@@ -162,6 +162,62 @@ def test_fast_mode_blocks_longer_than_the_inline_lmr_phase_limit(pkg):
     print("blocks mixed with an offset that one flipped estimate had moved:", flips)
 
 
+@pytest.mark.parametrize("fs,bs", [(256_000, 16384), (1_024_000, 32768), (256_000, 10240)])
+def test_fast_mode_de_emphasis_inside_the_front_tile(pkg, fs, bs):
+    """Tolerance mode runs the de-emphasis IIR (reference :403-406) inside k_front's tile from a zero state 128 samples early
+    (time constants up to ~79 us) instead of as a serial stage of its own: 50 us, 75 us and unfiltered channels in one batch,
+    and a 150 us channel that makes the whole handle fall back to the serial k_deemphasis + k_hilbert stage."""
+    from fm_radio_amd.capi import default_controls
+    from gpu_parity import oracle_controls
+
+    def ctl(**kw):
+        c = default_controls()
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+    nb = -(-fs * 8 // 10 // bs)            # 0.8 s: enough RDS bits behind the synchroniser's acquisition
+    caps = _caps(4, nb * bs, float(fs), seed=9500)
+    for per in ({0: ctl(use_deemphasis=1, deemphasis_tus=50), 1: ctl(use_deemphasis=1, deemphasis_tus=75), 3: ctl(use_deemphasis=1, deemphasis_tus=50, audio_out=1)},
+                {0: ctl(use_deemphasis=1, deemphasis_tus=50), 2: ctl(use_deemphasis=1, deemphasis_tus=150)}):
+        g = run_gpu(pkg, caps, bs, fs, fast_math=True, per_channel_controls=per)
+        for c in range(4):
+            o = O.run_chain(caps[c], bs, fs, u8=False, controls=oracle_controls(per[c]) if c in per else None,
+                            coeffs=lib_coeffs_to_oracle(g["coeffs"][c]), streams=["fm_out_iq", "lpr", "lmr", "audio", "rds_sym"])
+            for k in ("fm_out_iq", "lpr", "lmr", "audio"):
+                e = rms(np.asarray(g[k][c], np.float64).reshape(-1) - o[k].reshape(-1))
+                assert e <= TOL_RMS, (sorted(per), c, k, e)
+            assert same_bits_once_in_lock(g["rds_bytes"][c], o["rds_bytes"], skip_bits=5 * 76)
+
+
+def test_fast_mode_de_emphasis_switched_on_and_off_between_blocks(pkg):
+    """Controls take effect at the next block boundary; the in-tile filter has no state of its own, so on L+R (no loop in its
+    path: the pilot PLL and the L-R phase offset, which see the filtered multiplex, take many blocks to move over) a channel that
+    switches it on (or off) mid-stream is, from that block on, what a run with the filter always on (off) gives."""
+    from fm_radio_amd.capi import default_controls
+    bs, fs, nb = 16384, 256_000, 6
+    caps = _caps(2, nb * bs, float(fs), seed=9600)
+    on = default_controls(); on.use_deemphasis = 1; on.deemphasis_tus = 50
+    off = default_controls()
+    mono = lambda a: a.reshape(a.shape[0], -1, 2).sum(axis=2)
+    always_on = mono(run_gpu(pkg, caps, bs, fs, fast_math=True, controls=on)["audio"]).reshape(2, nb, -1)
+    always_off = mono(run_gpu(pkg, caps, bs, fs, fast_math=True)["audio"]).reshape(2, nb, -1)
+    dm = pkg.BatchDemod(2, bs, fs, fast_math=True)
+    got = []
+    for b in range(nb):
+        if b == 2:
+            dm.set_controls(on)
+        if b == 4:
+            dm.set_controls(off)
+        assert dm.process(np.ascontiguousarray(caps[:, b * bs:(b + 1) * bs])) == 0
+        got.append(mono(dm.audio().reshape(2, -1)))
+    dm.close()
+    for b in range(nb):
+        want = always_on if 2 <= b < 4 else always_off
+        # the block after a switch: the audio FIRs (128 taps at 128 kHz) still hold 1 ms of the other signal
+        tail = slice(32, None) if b in (2, 4) else slice(None)
+        assert rms((got[b] - want[:, b])[:, tail]) <= 2 * TOL_RMS, b    # (the sum of two channels)
+
+
 def test_fast_mode_golden_chain_fixture(pkg, golden):
     """Against vectors dumped from the compiled reference (tests/golden/chain_b16384.npz), the same bar the exact mode meets."""
     g = golden("chain_b16384.npz")
