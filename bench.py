@@ -39,6 +39,16 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s s
 FP32_PEAK_TFLOPS = 157.3
 
 
+def algorithmic_flops_per_sample(fs: int) -> float:
+    """~385 flop per 256 kSa/s sample for the chain behind the first decimator; that decimator (M x 64 real taps on
+    complex samples, one output per M inputs) adds 4 * 64 flop per baseband sample at 1.024 / 2.048 MSa/s."""
+    m = fs // 256_000
+    return 385.0 / m + (256.0 if m > 1 else 0.0)
+
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: 256 CUs x 256 flop/clk x 2.4 GHz
+
+
 def algorithmic_bytes_per_sample(fs: int, u8: bool) -> float:
     """cf32 (or u8) IQ in + stereo f32 audio out + RDS symbol floats out, per baseband sample."""
     in_b = 2.0 if u8 else 8.0
@@ -483,8 +493,13 @@ def main() -> None:
                 vt = json.loads(vf.read_text()).get(f"valu_total_per_block|C={C}|fs={fs}|block={block}|{'u8' if args.u8 else 'cf32'}|{'fast' if args.fast_math else 'exact'}")
                 if vt:
                     clk = spec.get("pll_clock_mhz", 2400.0) * 1e6
-                    cap = 1024 * clk / 2.35   # one plain wave64 VALU instruction per ~2.35 cycles and SIMD (tools/valu_rate_probe.hip; DPP ~6.2, v_sin ~8)
-                    valu = {"wave_instructions_per_step": vt, "issue_capacity_per_s": cap, "issue_frac_of_step": vt / (cap * el / K)}
+                    # Two capacities (DESIGN.md "what bounds the step"): a stream of independent wave64 FMAs from >= 2 wavefronts per
+                    # SIMD issues every ~2.75 cycles (tools/valu_mix_probe.hip); a single wavefront every ~5, and the co-resident
+                    # kernels of this pipeline slow each other as if every instruction held its SIMD for 4 cycles (the classic
+                    # wave64-on-SIMD16 cadence, rocprof's VALUBusy convention) - the fraction of THAT capacity is what saturates.
+                    cap = 1024 * clk / 4.0
+                    valu = {"wave_instructions_per_step": vt, "issue_capacity_per_s": cap, "issue_frac_of_step": vt / (cap * el / K),
+                            "cycles_per_instruction_assumed": 4.0, "frac_at_probe_rate_2p75": vt / (1024 * clk / 2.75 * el / K)}
             except Exception:
                 valu = None
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -496,7 +511,10 @@ def main() -> None:
                     "whole_step_frac": (bps * C * block * K / el / 1e9) / HBM_PEAK_GBS if world == 1 else None,
                     "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in ktimes.items()},
                     "handover_ms": gaps,
-                    "valu": valu}
+                    "valu": valu,
+                    "flops": None if world != 1 else {"per_sample": algorithmic_flops_per_sample(fs), "achieved_tflops": algorithmic_flops_per_sample(fs) * value / 1e6,
+                                                       "peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
+                                                       "frac": algorithmic_flops_per_sample(fs) * value / 1e6 / FP32_VECTOR_PEAK_TFLOPS}}
 
     out = {
         "metric": "IQ MSamples/sec demodulated to stereo+RDS per GPU; channels @ real-time",

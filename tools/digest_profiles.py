@@ -15,12 +15,14 @@ dst = ROOT / "profiles" / rnd
 dst.mkdir(parents=True, exist_ok=True)
 
 bench = json.loads((src / "bench_default.json").read_text().strip().splitlines()[-1])
-(dst / "bench_default.json").write_text(json.dumps(bench, indent=1) + "\n")
+# the default command's files keep their names; the exact mode's (BENCH_ARGS=--exact) carry a suffix
+sfx = "" if str(bench["config"].get("mode", "")).startswith("fast") else "_exact"
+(dst / f"bench_default{sfx}.json").write_text(json.dumps(bench, indent=1) + "\n")
 under = json.loads((src / "bench_under_rocprof.json").read_text().strip().splitlines()[-1])
 
 stats = newest(str(src / "stats" / "*" / "*kernel_stats.csv"))
 rows = [r for r in csv.DictReader(open(stats))]
-with open(dst / "bench_default_kernel_stats.csv", "w") as f:
+with open(dst / f"bench_default_kernel_stats{sfx}.csv", "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline   (durations in ns)\n")
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
     w.writeheader()
@@ -74,7 +76,7 @@ for short in names:
 old_traffic.update(traffic)
 (ROOT / "profiles" / "hbm_traffic.json").write_text(json.dumps(old_traffic, indent=1) + "\n")
 algo = bench["roofline"]["algorithmic_bytes_per_launch"]
-(dst / "hbm_traffic_pmc.md").write_text(
+(dst / f"hbm_traffic_pmc{sfx}.md").write_text(
     "# HBM traffic per launch, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)\n\n"
     "Command: `rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 4 --warmup 1 --preroll 16 --no-cpu-baseline --no-other-mode --no-pipeline`"
     " (and WRITE_SIZE), " + cfg["workload"] + ".\nCounter unit KiB; reads doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE = 1/2 of a 16 B/lane coalesced stream)."
@@ -98,12 +100,13 @@ try:
             insts[short] = {k: sum(x[len(x) // 2:]) / len(x[len(x) // 2:]) for k, x in v.items()}
     total_valu = sum(v.get("SQ_INSTS_VALU", 0.0) for v in insts.values())
     clock_mhz = bench.get("speculation", {}).get("pll_clock_mhz", 2400.0)
-    cap = 1024 * clock_mhz * 1e6 / 2.35         # 256 CUs x 4 SIMDs; measured: one plain wave64 VALU instruction per 2.3-2.4 cycles and SIMD
-                                                # with >= 2 waves per SIMD (tools/valu_rate_probe.hip: 1.0 T wave-instructions/s); DPP ~6.2, v_sin ~8
+    # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles and SIMD: the cadence the co-resident kernels of the pipeline behave
+    # by; streams of independent FMAs from >= 2 wavefronts per SIMD reach one per 2.75 (tools/valu_mix_probe.hip)
+    cap = 1024 * clock_mhz * 1e6 / 4.0
     step_s = bench["ms_per_step"] * 1e-3
     summary = {"wave_instructions_per_block": insts, "valu_total_per_block": total_valu, "simd_issue_capacity_per_s": cap,
-               "valu_issue_fraction_of_step": total_valu / (cap * step_s), "clock_mhz_used": clock_mhz, "ms_per_step": bench["ms_per_step"]}
-    (dst / "valu_instructions_pmc.json").write_text(json.dumps(summary, indent=1) + "\n")
+               "valu_issue_fraction_of_step": total_valu / (cap * step_s), "cycles_per_instruction_assumed": 4.0, "clock_mhz_used": clock_mhz, "ms_per_step": bench["ms_per_step"]}
+    (dst / f"valu_instructions_pmc{sfx}.json").write_text(json.dumps(summary, indent=1) + "\n")
     try:
         old_v = json.loads((ROOT / "profiles" / "valu_instructions.json").read_text())
     except Exception:
@@ -114,4 +117,4 @@ try:
 except Exception as e:   # older gpurun_out without the pass
     print("no instruction-count pass:", e)
 print(json.dumps(traffic, indent=1))
-print(open(dst / "bench_default_kernel_stats.csv").read()[:3000])
+print(open(dst / f"bench_default_kernel_stats{sfx}.csv").read()[:3000])
