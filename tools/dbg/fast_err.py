@@ -31,3 +31,7 @@ for c in range(nch):
     d = np.asarray(g['pll_dt'][c], np.float64).reshape(nb, nfo) - o['pll_dt'].reshape(nb, nfo); d -= np.round(d)
     print("  pll_dt mean diff", " ".join(f"{np.mean(d[i]):+.1e}" for i in range(nb)))
     print("  lmr_phase gpu", g["lmr_phase"][c][-2:], "oracle", o["lmr_phase"][-2:])
+    if c == 0:
+        blk = 8
+        dd = d[blk]
+        print("  pll_dt diff, block 8, first 192 samples (x1e6):", np.array2string(dd[:192] * 1e6, precision=0, max_line_width=220))
