@@ -1243,7 +1243,10 @@ __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict
                 float part = 0.0f;
 #pragma unroll
                 for (int k = 0; k < kLmrInlineMax / kWave; k++) part += ev[k];
-                const float nxt = lmr_phase_finish(wave_sum_f32(part), d.n_est, off_prev);   // every lane the same value
+                // avg by a reciprocal; |phase + 0.1 avg| < 2 pi + 0.16, so the fmod is at most one exact subtraction
+                float nxt = fmaf(wave_sum_f32(part) * __builtin_amdgcn_rcpf((float)d.n_est), 0.1f, off_prev);   // every lane the same value
+                const float two_pi = bits_f32(kTwoPiBits);
+                nxt = (nxt >= two_pi) ? nxt - two_pi : ((nxt <= -two_pi) ? nxt + two_pi : nxt);
                 if (tid == 0) { off_s = nxt; if (tile == 0) st(state, field_cur, d.C, c) = nxt; }
             }
             __syncthreads();
