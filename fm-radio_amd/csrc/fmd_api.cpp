@@ -500,6 +500,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     // within the time-parallel kernel: 16 lanes per channel while a lone wavefront's latency is what matters (same-box A/B:
     // 8 % faster at 2560 channels, 6 % at 3072), 8 lanes per channel (30 % fewer VALU instructions) beyond (2 % faster at 4096)
     h->ctx.pll_k16_max_channels = (cfg->flags & FMD_FLAG_PLL_K8) ? 0 : 3584;
+    if (const char* e = getenv("FMD_DEBUG_PLL_K16_MAX")) h->ctx.pll_k16_max_channels = atoi(e);   // development knob
     d.n_fm_in = d.N / m; d.n_fm_out = d.n_fm_in / 2; d.n_rds = d.n_fm_out / 8; d.n_audio = d.n_fm_out / 4;
     d.n_est = (d.n_audio + 9) / 10;
     d.tail_base = front_tail_len(m, (cfg->flags & FMD_FLAG_FAST_MATH) != 0);
