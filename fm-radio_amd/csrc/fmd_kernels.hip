@@ -69,9 +69,13 @@ struct FrontGeom {
     static_assert(OFF_DEM % 4 == 0 && OFF_FO % 4 == 0 && NF % 8 == 0, "LDS sub-arrays must be 16-byte aligned");
 };
 
-__device__ __forceinline__ float2 load_iq(const float2* p, size_t i) { return p[i]; }
-__device__ __forceinline__ float2 load_iq(const uchar2* p, size_t i) {
-    const uchar2 v = p[i];
+// (a 32-bit BYTE offset from a uniform base: the load then takes the SGPR-base form, no 64-bit address arithmetic in the VALU;
+// a channel's block is far below 4 GB)
+__device__ __forceinline__ float2 load_iq(const float2* p, unsigned i) {
+    return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p) + (size_t)(unsigned)(i * 8u));
+}
+__device__ __forceinline__ float2 load_iq(const uchar2* p, unsigned i) {
+    const uchar2 v = *reinterpret_cast<const uchar2*>(reinterpret_cast<const char*>(p) + (size_t)(unsigned)(i * 2u));
     return make_float2((float)v.x - 127.0f, (float)v.y - 127.0f);  // reference src/app.cpp:56-62
 }
 
@@ -112,12 +116,24 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
     {
         constexpr int PER = (NW + 255) / 256;
         float2 buf[PER];
+        if (tile != 0) {
+            // no history involved (workgroup-uniform): a uniform base and 32-bit offsets, so the loads take the SGPR-base form and
+            // the address arithmetic stays out of the VALU (the general form below costs ~12 instructions per sample on 64-bit
+            // adds, compares and selects: a tenth of this kernel)
+            const unsigned g0 = (unsigned)g_lo;
 #pragma unroll
-        for (int r = 0; r < PER; r++) {
-            const int i = tid + 256 * r;
-            if (i < NW) {
-                const long g = g_lo + i;
-                buf[r] = (g < 0) ? tail_c[G::TAIL + g] : load_iq(in_c, (size_t)g);
+            for (int r = 0; r < PER; r++) {
+                const int i = tid + 256 * r;
+                if (i < NW) buf[r] = load_iq(in_c, (unsigned)(g0 + (unsigned)i));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+                const int i = tid + 256 * r;
+                if (i < NW) {
+                    const int g = (int)g_lo + i;
+                    buf[r] = (g < 0) ? tail_c[G::TAIL + g] : load_iq(in_c, (unsigned)g);
+                }
             }
         }
         __syncthreads();   // the arctangent table
@@ -233,7 +249,7 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
     // not the one maintaining it, the last 64 fm_out samples = the Hilbert FIR history the reference holds)
     if (tile == tiles - 1) {
         float2* tout = tail_out + (size_t)c * d.tail_base;
-        for (int idx = tid; idx < d.tail_base; idx += 256) tout[idx] = load_iq(in_c, (size_t)(d.N - d.tail_base + idx));
+        for (int idx = tid; idx < d.tail_base; idx += 256) tout[idx] = load_iq(in_c, (unsigned)(d.N - d.tail_base + idx));
         if (WU == 0 && !deemph_path && tid < 64) fo_tail_out[(size_t)c * 64 + tid] = fo[T + tid];
     }
 }
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(256) void k_predecim(Dims d, const InT* __restrict_
         *reinterpret_cast<float4*>(fm_in + (size_t)c * d.n_fm_in + n0 + il) = o;
     }
     // the last 64 input samples of the block are the next block's history
-    if (tile == tiles - 1 && tid < G::HIST) tail_out[(size_t)c * G::HIST + tid] = load_iq(in_c, (size_t)(d.N - G::HIST + tid));
+    if (tile == tiles - 1 && tid < G::HIST) tail_out[(size_t)c * G::HIST + tid] = load_iq(in_c, (unsigned)(d.N - G::HIST + tid));
 }
 
 // =============================================================================================
