@@ -193,6 +193,31 @@ void design_pilot_fast(const fmd_coeffs& k, PilotFastTab* t) {
     t->k = k.pilot_b[0]; t->a0 = k.pilot_a[0]; t->a1 = k.pilot_a[1];
 }
 
+// Operand images of k_front_mfma's FIRs (fmd_kernels.hip FrontGeomM): v_mfma_f32_16x16x32_bf16's A operand, lane l = row l % 16,
+// k = 8 (l / 16) + 0..7; A[m][t] = taps[t - stride m] inside the band, 0 outside; every fp32 tap as two bf16 (round to nearest even).
+static uint16_t bf16_rne(float x) {
+    uint32_t u; std::memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float bf16_to_f32(uint16_t h) { const uint32_t u = (uint32_t)h << 16; float x; std::memcpy(&x, &u, 4); return x; }
+void design_front_mfma(const fmd_coeffs& k, std::vector<uint16_t>& img) {
+    img.assign((size_t)2 * 3 * 2 * 64 * 8, 0);
+    for (int fir = 0; fir < 2; fir++) {
+        const float* taps = fir == 0 ? k.b_fm_out : k.b_hilbert;
+        const int n_taps = fir == 0 ? 64 : 65, stride = fir == 0 ? 2 : 1;
+        for (int sK = 0; sK < 3; sK++)
+            for (int l = 0; l < 64; l++)
+                for (int i = 0; i < 8; i++) {
+                    const int t = 32 * sK + 8 * (l / 16) + i, idx = t - stride * (l % 16);
+                    const float v = (idx >= 0 && idx < n_taps) ? taps[idx] : 0.0f;
+                    const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
+                    img[((((size_t)fir * 3 + sK) * 2 + 0) * 64 + l) * 8 + i] = hi;
+                    img[((((size_t)fir * 3 + sK) * 2 + 1) * 64 + l) * 8 + i] = lo;
+                }
+    }
+}
+
 void fill_ctx_coeffs(fmd_handle h) {
     const fmd_coeffs& k = h->base;
     LaunchCtx& x = h->ctx;
@@ -554,6 +579,11 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     if (!rc && h->ctx.fast) {
         rc = dev_alloc(h, &b.pilot_tab, 1);
         if (!rc) {
+            std::vector<uint16_t> img;
+            design_front_mfma(h->base, img);
+            rc = dev_alloc(h, &b.front_mfma, img.size() * 2 / sizeof(uint4));
+            if (!rc && (hipMemcpyAsync(b.front_mfma, img.data(), img.size() * 2, hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
+                        hipStreamSynchronize(h->own_stream) != hipSuccess)) rc = fail(h, FMD_ERR_DEVICE, "operand table upload failed");
             PilotFastTab tab;
             design_pilot_fast(h->base, &tab);
             if (hipMemcpyAsync(b.pilot_tab, &tab, sizeof(tab), hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||

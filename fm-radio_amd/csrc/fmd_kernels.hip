@@ -71,6 +71,37 @@ struct FrontGeom {
 
 // (a 32-bit BYTE offset from a uniform base: the load then takes the SGPR-base form, no 64-bit address arithmetic in the VALU;
 // a channel's block is far below 4 GB)
+// FMD_FLAG_FAST_MATH: k_front's two FIRs on the matrix cores.  Both have taps common to all stations, so each is a constant
+// banded-Toeplitz matrix times a matrix whose columns are overlapping windows of the signal:
+//   decimate-by-2, 64 taps:  Y[m][c] = y[16 c + m] = sum_t A[m][t] dem[32 c + t],  A[m][t] = h[t - 2 m]       (t < 94)
+//   Hilbert, 65 taps:        Y[m][c] = im[16 c + m] = sum_t A[m][t] fo[16 c + t],   A[m][t] = b[t - m]         (t < 80)
+// i.e. three v_mfma_f32_16x16x32_bf16 K-steps per 16 x 16 outputs.  fp32 operands are split into two bf16 halves (taps: rounded,
+// on the host; samples: truncated, x = hi + lo + O(2^-16 x)) and a product is hi hi + lo hi + hi lo, accumulated in fp32:
+// 9 MFMAs per 256 outputs and wavefront instead of 256 x 64 / 64 = 256 (128) VALU FMAs, on a pipe of their own — the VALU issue
+// slots are what bounds the step.  The operand images of A (lane l: row l % 16, k = 8 (l / 16) .. + 7, layout checked
+// by tools/mfma_bf16_probe.hip) come ready-made from the host (FrontMfmaTab).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int TT, int WU>
+struct FrontGeomM {
+    static constexpr int T = TT, NF = T + 64 + WU, NW = 2 * NF + 63, TAIL = 191 + 2 * WU;
+    static constexpr int NWB = (NW + 8 + 7) & ~7;        // bf16 elements per half (hi / lo) of the discriminator output, zero padded
+    static constexpr int NFB = NF + 16;                  // ... of fm_out
+    static constexpr int OFF_THETA = 0;                  // [NW] floats; then, in place: dem_hi [NWB] bf16, dem_lo [NWB] bf16
+    static constexpr int OFF_FO = NWB;                   // fm_out fp32 [NF]
+    static constexpr int OFF_FOB = OFF_FO + NF;          // fo_hi [NFB] bf16, fo_lo [NFB] bf16
+    static constexpr int OFF_ZS = OFF_FOB + NFB;         // WU > 0: segment end states of the de-emphasis IIR
+    static constexpr int LDS_FLOATS = OFF_ZS + (WU > 0 ? NF / 8 + 16 : 0);
+    static constexpr int NCOL = NF / 16;
+    static_assert(NF % 16 == 0 && NWB % 8 == 0 && OFF_FO % 4 == 0 && OFF_FOB % 4 == 0 && NWB >= NW + 1, "alignment");
+};
+// x = hi + lo (+ O(2^-16 x)), both halves as bf16 bit patterns in the upper 16 bits of a float
+__device__ __forceinline__ void split_bf16(float x, uint32_t& hi, uint32_t& lo) {
+    hi = f32_bits(x) & 0xffff0000u;
+    lo = f32_bits(x - bits_f32(hi));
+}
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xffff0000u); }   // bf16(a) low, bf16(b) high
+
 __device__ __forceinline__ float2 load_iq(const float2* p, unsigned i) {
     return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p) + (size_t)(unsigned)(i * 8u));
 }
@@ -247,6 +278,192 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
     }
     // keep the last TAIL input samples of the stream for the next block (and, when the de-emphasis path is
     // not the one maintaining it, the last 64 fm_out samples = the Hilbert FIR history the reference holds)
+    if (tile == tiles - 1) {
+        float2* tout = tail_out + (size_t)c * d.tail_base;
+        for (int idx = tid; idx < d.tail_base; idx += 256) tout[idx] = load_iq(in_c, (unsigned)(d.N - d.tail_base + idx));
+        if (WU == 0 && !deemph_path && tid < 64) fo_tail_out[(size_t)c * 64 + tid] = fo[T + tid];
+    }
+}
+
+// =============================================================================================
+// k_front_mfma — FMD_FLAG_FAST_MATH form of k_front: same stages, same tiles, same history; the minimax arctangent, and both FIRs
+// as bf16 x 3 matrix products (FrontGeomM above).  WU > 0: with the de-emphasis IIR inside the tile (see k_front).
+// =============================================================================================
+template <typename InT, int TT, int WU>
+__global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
+                                                    float2* __restrict__ tail_out, float2* __restrict__ fm_out_iq,
+                                                    float* __restrict__ fm_out_plain, float* __restrict__ fo_tail_out, float fm_gain,
+                                                    int deemph_path, const float* __restrict__ deemph, const uint4* __restrict__ tab) {
+    using G = FrontGeomM<TT, WU>;
+    constexpr int T = G::T, NW = G::NW, NF = G::NF;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* theta = smem + G::OFF_THETA;
+    uint32_t* dem_hi32 = reinterpret_cast<uint32_t*>(smem);                        // two bf16 per word
+    uint32_t* dem_lo32 = dem_hi32 + G::NWB / 2;
+    float* fo = smem + G::OFF_FO;
+    uint32_t* fo_hi32 = reinterpret_cast<uint32_t*>(smem + G::OFF_FOB);
+    uint32_t* fo_lo32 = fo_hi32 + G::NFB / 2;
+
+    const int tiles = d.n_fm_out / T;
+    const int c = blockIdx.x / tiles, tile = blockIdx.x % tiles, o0 = tile * T, tid = threadIdx.x;
+    const int lane = tid & (kWave - 1), wv = tid >> 6, lrow = lane & 15, lq = lane >> 4;
+    const int g_lo = 2 * o0 - G::TAIL;                            // first input index of the tile (block relative)
+    const InT* in_c = in + (size_t)c * d.N;
+    const float2* tail_c = tail_in + (size_t)c * d.tail_base + (d.tail_base - G::TAIL);
+
+    // the Toeplitz operands of the decimating FIR (the Hilbert FIR's are fetched when its turn comes)
+    bf16x8 adh[3], adl[3];
+#pragma unroll
+    for (int sK = 0; sK < 3; sK++) {
+        adh[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 0) * kWave + lane]);
+        adl[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 1) * kWave + lane]);
+    }
+    // a0-a2: staging, arctangent (all loads first)
+    {
+        constexpr int PER = (NW + 255) / 256;
+        float2 buf[PER];
+        if (tile != 0) {
+            const unsigned g0 = (unsigned)g_lo;
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+                const int i = tid + 256 * r;
+                if (i < NW) buf[r] = load_iq(in_c, (unsigned)(g0 + (unsigned)i));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+                const int i = tid + 256 * r;
+                if (i < NW) {
+                    const int g = g_lo + i;
+                    buf[r] = (g < 0) ? tail_c[G::TAIL + g] : load_iq(in_c, (unsigned)g);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int i = tid + 256 * r;
+            if (i < NW) theta[i] = fast_atan2f(buf[r].y, buf[r].x);
+        }
+    }
+    __syncthreads();
+    // phase difference, wrap, scale: two samples per thread and step, split into bf16 halves, in place over the phases
+    {
+        const float pi = bits_f32(kPiBits), two_pi = bits_f32(kTwoPiBits);
+        constexpr int NPW = G::NWB / 2;                              // words per half
+        constexpr int PERP = (NPW + 255) / 256;
+        uint32_t wh[PERP], wl[PERP];
+#pragma unroll
+        for (int r = 0; r < PERP; r++) {
+            const int pw = tid + 256 * r, j = 2 * pw;
+            wh[r] = 0u; wl[r] = 0u;
+            if (j < NW - 1) {
+                const float t0 = theta[j], t1 = theta[j + 1], t2 = (j + 2 < NW) ? theta[j + 2] : t1;
+                float d0 = t1 - t0, d1 = t2 - t1;
+                d0 = (d0 >= pi) ? d0 - two_pi : ((d0 <= -pi) ? d0 + two_pi : d0);
+                d1 = (d1 >= pi) ? d1 - two_pi : ((d1 <= -pi) ? d1 + two_pi : d1);
+                d0 *= fm_gain; d1 = (j + 1 < NW - 1) ? d1 * fm_gain : 0.0f;
+                uint32_t h0, l0, h1, l1;
+                split_bf16(d0, h0, l0); split_bf16(d1, h1, l1);
+                wh[r] = pack_hi16(h0, h1); wl[r] = pack_hi16(l0, l1);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PERP; r++) {
+            const int pw = tid + 256 * r;
+            if (pw < NPW) { dem_hi32[pw] = wh[r]; dem_lo32[pw] = wl[r]; }
+        }
+    }
+    __syncthreads();
+    // a3: decimate-by-2 FIR: wavefront w takes the 16-column tiles w, w + 4, ... (a column = 16 consecutive outputs)
+    for (int ct = wv; ct * 16 < G::NCOL; ct += 4) {
+        const int col = ct * 16 + lrow, colr = col < G::NCOL ? col : G::NCOL - 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sK = 0; sK < 3; sK++) {
+            const int e = 32 * colr + 32 * sK + 8 * lq;              // bf16 element index, a multiple of 8
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(dem_hi32 + e / 2));
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(dem_lo32 + e / 2));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adl[sK], bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bl, acc, 0, 0, 0);
+        }
+        if (col < G::NCOL) *reinterpret_cast<float4*>(fo + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    __syncthreads();
+    if constexpr (WU == 0) {
+        if (deemph_path) {   // a time constant beyond the in-tile form: hand fm_out to the k_deemphasis + k_hilbert stage
+            for (int uu = 64 + 4 * tid; uu < NF; uu += 1024)
+                *reinterpret_cast<float4*>(fm_out_plain + (size_t)c * d.n_fm_out + o0 + (uu - 64)) = *reinterpret_cast<const float4*>(fo + uu);
+        }
+    }
+    if constexpr (WU > 0) {
+        // a4 in the tile (see k_front): 8 samples per thread from a zero state, end states through LDS, 16 segments of history
+        const float b0 = deemph[4 * c + 0], b1 = deemph[4 * c + 1], a0 = deemph[4 * c + 2];
+        if (deemph[4 * c + 3] != 0.0f) {
+            float* zs = smem + G::OFF_ZS;
+            constexpr int NSEG = NF / 8;
+            float yv[8];
+            if (tid < 16) zs[tid] = 0.0f;
+            if (tid < NSEG) {
+                const float4 xa = *reinterpret_cast<const float4*>(fo + 8 * tid), xb = *reinterpret_cast<const float4*>(fo + 8 * tid + 4);
+                const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                float xp = tid ? fo[8 * tid - 1] : 0.0f, z = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { z = fmaf(a0, z, fmaf(xs[k], b1, xp * b0)); yv[k] = z; xp = xs[k]; }
+                zs[16 + tid] = z;
+            }
+            __syncthreads();
+            if (tid < NSEG) {
+                const float a2 = a0 * a0, a4 = a2 * a2, a8 = a4 * a4;
+                float e = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 16; k++) e = fmaf(a8, e, zs[tid + k]);
+                float pw = a0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { yv[k] = fmaf(pw, e, yv[k]); pw *= a0; }
+                *reinterpret_cast<float4*>(fo + 8 * tid) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+                *reinterpret_cast<float4*>(fo + 8 * tid + 4) = make_float4(yv[4], yv[5], yv[6], yv[7]);
+            }
+            __syncthreads();
+        }
+    }
+    // fm_out into bf16 halves for the Hilbert FIR (zero padded behind the tile)
+    for (int q4 = tid; q4 < G::NFB / 4; q4 += 256) {
+        const float4 v = (4 * q4 < NF) ? *reinterpret_cast<const float4*>(fo + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t h0, l0, h1, l1, h2, l2, h3, l3;
+        split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
+        *reinterpret_cast<uint2*>(fo_hi32 + 2 * q4) = make_uint2(pack_hi16(h0, h1), pack_hi16(h2, h3));
+        *reinterpret_cast<uint2*>(fo_lo32 + 2 * q4) = make_uint2(pack_hi16(l0, l1), pack_hi16(l2, l3));
+    }
+    __syncthreads();
+    // a5: Hilbert FIR, same form; the real rail is fm_out delayed by 32
+    if (WU > 0 || !deemph_path) {
+        bf16x8 ahh[3], ahl[3];
+#pragma unroll
+        for (int sK = 0; sK < 3; sK++) {
+            ahh[sK] = __builtin_bit_cast(bf16x8, tab[(6 + sK * 2 + 0) * kWave + lane]);
+            ahl[sK] = __builtin_bit_cast(bf16x8, tab[(6 + sK * 2 + 1) * kWave + lane]);
+        }
+        for (int ct = wv; ct * 256 < T; ct += 4) {
+            const int col = ct * 16 + lrow;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sK = 0; sK < 3; sK++) {
+                const int e = WU + 16 * col + 32 * sK + 8 * lq;
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fo_hi32 + e / 2));
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fo_lo32 + e / 2));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahh[sK], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahl[sK], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahh[sK], bl, acc, 0, 0, 0);
+            }
+            const int oo = 16 * col + 4 * lq;
+            const float4 re = *reinterpret_cast<const float4*>(fo + WU + oo + 32);
+            float4* o = reinterpret_cast<float4*>(fm_out_iq + (size_t)c * d.n_fm_out + o0 + oo);
+            o[0] = make_float4(re.x, acc[0], re.y, acc[1]);
+            o[1] = make_float4(re.z, acc[2], re.w, acc[3]);
+        }
+    }
     if (tile == tiles - 1) {
         float2* tout = tail_out + (size_t)c * d.tail_base;
         for (int idx = tid; idx < d.tail_base; idx += 256) tout[idx] = load_iq(in_c, (unsigned)(d.N - d.tail_base + idx));
@@ -1800,14 +2017,21 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
         if (d.n_fm_out % 1024 == 0) return launch_front<InT, 1024, FAST>(ctx, r, d_iq, s);
     }
     const int tiles = d.n_fm_out / G::T;
-    if constexpr (FAST) {
-        if (ctx.deemph_in_tile) {   // tolerance mode: the de-emphasis IIR inside the tile, no k_deemphasis / k_hilbert stage
-            using GW = FrontGeom<TT, kDeemphWarmup>;
-            auto kern = k_front<InT, TT, true, kDeemphWarmup>;
-            FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), sizeof(float) * GW::LDS_FLOATS, s, d, d_iq, ctx.b.base_tail[r.par],
-                       ctx.b.base_tail[r.par ^ 1], ctx.b.fm_out_iq[r.buf], ctx.b.fm_out[r.buf], ctx.b.fo_tail[r.par ^ 1], ctx.front, 0, ctx.b.deemph);
-            return hipGetLastError();
+    if constexpr (FAST) {   // tolerance mode: k_front_mfma; with the de-emphasis IIR inside the tile when a channel asks for it
+        if (ctx.deemph_in_tile) {
+            auto kern = k_front_mfma<InT, TT, kDeemphWarmup>;
+            using GM = FrontGeomM<TT, kDeemphWarmup>;
+            FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
+                       ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fm_out_iq[r.buf], ctx.b.fm_out[r.buf], ctx.b.fo_tail[r.par ^ 1],
+                       ctx.front.fm_gain, 0, ctx.b.deemph, ctx.b.front_mfma);
+        } else {
+            auto kern = k_front_mfma<InT, TT, 0>;
+            using GM = FrontGeomM<TT, 0>;
+            FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
+                       ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fm_out_iq[r.buf], ctx.b.fm_out[r.buf], ctx.b.fo_tail[r.par ^ 1],
+                       ctx.front.fm_gain, ctx.any_deemph, ctx.b.deemph, ctx.b.front_mfma);
         }
+        return hipGetLastError();
     }
     const size_t lds = sizeof(float) * G::LDS_FLOATS;
     auto kern = k_front<InT, TT, FAST>;
@@ -1945,11 +2169,11 @@ static hipError_t prepare_front() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front<InT, TT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(sizeof(float) * FrontGeom<TT>::LDS_FLOATS));
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front<InT, TT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(float) * FrontGeom<TT>::LDS_FLOATS));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(float) * FrontGeomM<TT, 0>::LDS_FLOATS));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_front<InT, TT, true, kDeemphWarmup>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(sizeof(float) * FrontGeom<TT, kDeemphWarmup>::LDS_FLOATS));
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, kDeemphWarmup>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(sizeof(float) * FrontGeomM<TT, kDeemphWarmup>::LDS_FLOATS));
 }
 
 hipError_t prepare_kernels() {
@@ -1963,7 +2187,7 @@ hipError_t prepare_kernels() {
 
 // k_front always runs at 256 kSa/s (the first decimator keeps its own 64 samples); the tolerance mode keeps the history its in-tile
 // de-emphasis needs, whether or not a channel uses it now
-int front_tail_len(int m, bool fast) { (void)m; return fast ? FrontGeom<512, kDeemphWarmup>::TAIL : FrontGeom<>::TAIL; }
+int front_tail_len(int m, bool fast) { (void)m; return fast ? FrontGeomM<512, kDeemphWarmup>::TAIL : FrontGeom<>::TAIL; }
 
 hipError_t launch_reset_state(const LaunchCtx& ctx, hipStream_t stream) {
     hipLaunchKernelGGL(k_reset, dim3((unsigned)((ctx.d.C + 255) / 256)), dim3(256), 0, stream, ctx.d, ctx.b.state);

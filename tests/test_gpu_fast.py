@@ -190,7 +190,7 @@ def test_fast_mode_de_emphasis_inside_the_front_tile(pkg, fs, bs):
             for k in ("fm_out_iq", "lpr", "lmr", "audio"):
                 e = rms(np.asarray(g[k][c], np.float64).reshape(-1) - o[k].reshape(-1))
                 assert e <= TOL_RMS, (sorted(per), c, k, e)
-            assert same_bits_once_in_lock(g["rds_bytes"][c], o["rds_bytes"], skip_bits=9 * 76)
+            assert same_bits_once_in_lock(g["rds_bytes"][c], o["rds_bytes"], skip_bits=12 * 76), (sorted(per), c)   # (a symbol slipped during acquisition re-pairs the Manchester decoder 0.5 s later)
 
 
 def test_fast_mode_de_emphasis_switched_on_and_off_between_blocks(pkg):
