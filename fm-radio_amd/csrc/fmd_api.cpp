@@ -60,6 +60,8 @@ struct fmd_handle_s {
     int bytes_cap = 0;
     std::string err;
     std::map<int, std::vector<float>> lpf_cache;  // cut-off Hz -> 128 taps
+    std::map<int, int> img_slot;                  // FMD_FLAG_FAST_MATH: cut-off Hz -> slot of its operand image in aud_img (k_extract_mfma)
+    size_t img_capacity = 0;                      // slots allocated in aud_img
     int profiling = 0;                       // 0 off, 1 every kernel of every block, 2 k_pilot_pll every block + the rest every 4th
     std::vector<ProfiledBlock*> marks;       // one per profiled block, drained by fmd_profile_read
 };
@@ -126,6 +128,28 @@ bool config_ok(const fmd_config* c, int* m) {
     return true;
 }
 
+// Operand images of k_front_mfma's FIRs (fmd_kernels.hip FrontGeomM): v_mfma_f32_16x16x32_bf16's A operand, lane l = row l % 16,
+// k = 8 (l / 16) + 0..7; A[m][t] = taps[t - stride m] inside the band, 0 outside; every fp32 tap as two bf16 (round to nearest even).
+static uint16_t bf16_rne(float x) {
+    uint32_t u; std::memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float bf16_to_f32(uint16_t h) { const uint32_t u = (uint32_t)h << 16; float x; std::memcpy(&x, &u, 4); return x; }
+// one FIR's image: A[m][t] = taps[t - stride m], t < 32 ksteps; [k-step][hi / lo][lane][8]
+void toeplitz_image(const float* taps, int n_taps, int stride, int ksteps, uint16_t* img) {
+    for (int sK = 0; sK < ksteps; sK++)
+        for (int l = 0; l < 64; l++)
+            for (int i = 0; i < 8; i++) {
+                const int t = 32 * sK + 8 * (l / 16) + i, idx = t - stride * (l % 16);
+                const float v = (idx >= 0 && idx < n_taps) ? taps[idx] : 0.0f;
+                const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
+                img[(((size_t)sK * 2 + 0) * 64 + l) * 8 + i] = hi;
+                img[(((size_t)sK * 2 + 1) * 64 + l) * 8 + i] = lo;
+            }
+}
+constexpr size_t kAudImgU16 = (size_t)6 * 2 * 64 * 8, kRdsImgU16 = (size_t)8 * 2 * 64 * 8;
+
 const std::vector<float>& lpf_taps(fmd_handle h, int hz) {
     auto it = h->lpf_cache.find(hz);
     if (it != h->lpf_cache.end()) return it->second;
@@ -158,6 +182,35 @@ int upload_controls(fmd_handle h, hipStream_t s) {
         mix[2 * c] = (float)k.audio_out; mix[2 * c + 1] = k.audio_stereo_mix_factor;
     }
     Buffers& b = h->ctx.b;
+    if (h->ctx.fast) {
+        // k_extract_mfma: one operand image per distinct audio cut-off, and which two each station uses
+        std::vector<int> idx((size_t)C * 2);
+        bool grew = false;
+        for (int c = 0; c < C; c++)
+            for (int which = 0; which < 2; which++) {
+                const int hz = which ? h->controls[c].lmr_cutoff_hz : h->controls[c].lpr_cutoff_hz;
+                auto it = h->img_slot.find(hz);
+                if (it == h->img_slot.end()) { it = h->img_slot.emplace(hz, (int)h->img_slot.size()).first; grew = true; }
+                idx[(size_t)c * 2 + which] = it->second;
+            }
+        if (grew) {
+            const size_t n_slots = h->img_slot.size();
+            if (n_slots > h->img_capacity) {   // (everything is idle here: upload_controls runs behind sync_all)
+                const size_t cap = std::max<size_t>(2 * n_slots, 8);
+                uint4* q = nullptr;
+                int rc = dev_alloc(h, &q, cap * kAudImgU16 * 2 / sizeof(uint4));
+                if (rc) return rc;
+                b.aud_img = q;       // the old table stays on the handle's allocation list until fmd_destroy
+                h->img_capacity = cap;
+            }
+            std::vector<uint16_t> imgs(n_slots * kAudImgU16);
+            for (const auto& kv : h->img_slot) toeplitz_image(lpf_taps(h, kv.first).data(), 128, 4, 6, imgs.data() + (size_t)kv.second * kAudImgU16);
+            HIP_TRY(h, hipMemcpyAsync(b.aud_img, imgs.data(), imgs.size() * 2, hipMemcpyHostToDevice, s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+        }
+        HIP_TRY(h, hipMemcpyAsync(b.aud_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+    }
     HIP_TRY(h, hipMemcpyAsync(b.b_lpr, lpr.data(), lpr.size() * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(b.b_lmr, lmr.data(), lmr.size() * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(b.deemph, de.data(), de.size() * 4, hipMemcpyHostToDevice, s));
@@ -193,29 +246,10 @@ void design_pilot_fast(const fmd_coeffs& k, PilotFastTab* t) {
     t->k = k.pilot_b[0]; t->a0 = k.pilot_a[0]; t->a1 = k.pilot_a[1];
 }
 
-// Operand images of k_front_mfma's FIRs (fmd_kernels.hip FrontGeomM): v_mfma_f32_16x16x32_bf16's A operand, lane l = row l % 16,
-// k = 8 (l / 16) + 0..7; A[m][t] = taps[t - stride m] inside the band, 0 outside; every fp32 tap as two bf16 (round to nearest even).
-static uint16_t bf16_rne(float x) {
-    uint32_t u; std::memcpy(&u, &x, 4);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-static float bf16_to_f32(uint16_t h) { const uint32_t u = (uint32_t)h << 16; float x; std::memcpy(&x, &u, 4); return x; }
 void design_front_mfma(const fmd_coeffs& k, std::vector<uint16_t>& img) {
     img.assign((size_t)2 * 3 * 2 * 64 * 8, 0);
-    for (int fir = 0; fir < 2; fir++) {
-        const float* taps = fir == 0 ? k.b_fm_out : k.b_hilbert;
-        const int n_taps = fir == 0 ? 64 : 65, stride = fir == 0 ? 2 : 1;
-        for (int sK = 0; sK < 3; sK++)
-            for (int l = 0; l < 64; l++)
-                for (int i = 0; i < 8; i++) {
-                    const int t = 32 * sK + 8 * (l / 16) + i, idx = t - stride * (l % 16);
-                    const float v = (idx >= 0 && idx < n_taps) ? taps[idx] : 0.0f;
-                    const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
-                    img[((((size_t)fir * 3 + sK) * 2 + 0) * 64 + l) * 8 + i] = hi;
-                    img[((((size_t)fir * 3 + sK) * 2 + 1) * 64 + l) * 8 + i] = lo;
-                }
-    }
+    toeplitz_image(k.b_fm_out, 64, 2, 3, img.data());
+    toeplitz_image(k.b_hilbert, 65, 1, 3, img.data() + (size_t)3 * 2 * 64 * 8);
 }
 
 void fill_ctx_coeffs(fmd_handle h) {
@@ -584,6 +618,14 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
             rc = dev_alloc(h, &b.front_mfma, img.size() * 2 / sizeof(uint4));
             if (!rc && (hipMemcpyAsync(b.front_mfma, img.data(), img.size() * 2, hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
                         hipStreamSynchronize(h->own_stream) != hipSuccess)) rc = fail(h, FMD_ERR_DEVICE, "operand table upload failed");
+            if (!rc) rc = dev_alloc(h, &b.aud_idx, C);
+            if (!rc) rc = dev_alloc(h, &b.rds_img, kRdsImgU16 * 2 / sizeof(uint4));
+            if (!rc) {
+                std::vector<uint16_t> rimg(kRdsImgU16);
+                toeplitz_image(h->base.b_rds, 128, 8, 8, rimg.data());
+                if (hipMemcpyAsync(b.rds_img, rimg.data(), rimg.size() * 2, hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
+                    hipStreamSynchronize(h->own_stream) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "operand table upload failed");
+            }
             PilotFastTab tab;
             design_pilot_fast(h->base, &tab);
             if (hipMemcpyAsync(b.pilot_tab, &tab, sizeof(tab), hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||

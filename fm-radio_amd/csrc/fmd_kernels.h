@@ -113,6 +113,9 @@ struct Buffers {
     float*  mix;            // [C][2]  audio mode (as float), stereo mix factor
     float*  state;          // [S_NUM_FIELDS][C]
     PilotFastTab* pilot_tab;         // FMD_FLAG_FAST_MATH only
+    uint4*  aud_img;                 // ... of k_extract_mfma's audio FIRs, one per distinct cut-off: [slot][k-step][hi/lo][lane]
+    int2*   aud_idx;                 // [C] slots of a station's L+R and L-R images
+    uint4*  rds_img;                 // ... of the RDS FIR
     uint4*  front_mfma;              // FMD_FLAG_FAST_MATH only: Toeplitz operand images of k_front_mfma's two FIRs, [fir][k-step][hi/lo][lane]
     unsigned int* pll_chain;         // [wavefronts of k_pilot_pll + 1] last block number each wavefront completed; [last] = watchdog flag
     unsigned long long* spec_stats;  // [8] speculation counters: pll {chunks, general, replayed, -}, rds {chunks, general, replayed, -}

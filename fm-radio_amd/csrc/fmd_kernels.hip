@@ -1586,6 +1586,212 @@ __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict
     }
 }
 
+// =============================================================================================
+// k_extract_mfma — FMD_FLAG_FAST_MATH form of k_extract<256>: the same tile, mixing and epilogue; the three decimating FIRs as
+// bf16 x 3 banded-Toeplitz products (see FrontGeomM):
+//   L+R, L-R (decimate by 4, 128 taps, taps per station):  Y[m][c] = y[16 c + m] = sum_t A[m][t] x[64 c + t],   A[m][t] = h[t - 4 m]   (t < 188: 6 K-steps)
+//   RDS (decimate by 8, 128 taps), both rails in one 16-column tile:   sum_t A[m][t] x[128 c + t],             A[m][t] = h[t - 8 m]   (t < 248: 8 K-steps)
+// The operand images of A are made on the host, one per distinct cut-off (aud_img, 12 KB each; aud_idx says which two a station
+// uses) and one for the RDS taps.  Signals are staged as bf16 hi / lo halves in natural order, 8 elements of padding after every
+// 32 (a lane's 16-byte operand read never crosses a group; column strides of 80 / 160 elements spread the lanes over the banks).
+// Wavefront 0: L+R, 1: L-R, 2: RDS, 3: the real rail of every 10th L-R output for the phase estimate (VALU, as before).
+// =============================================================================================
+struct ExtractGeomM {
+    static constexpr int TA = 256, XS = 4 * TA + 124, XSP = 1152;         // staged samples, padded with zeros to the operands' reach
+    static constexpr int NB = XSP + 8 * (XSP >> 5);                       // bf16 elements per half-array with the padding
+    static constexpr int NEST = TA / 10 + 2;
+    __device__ static __forceinline__ int pad(int i) { return i + 8 * (i >> 5); }
+};
+
+__global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float2* __restrict__ fm_out_iq, const float* __restrict__ pll_dt,
+                                                      const float2* __restrict__ iq_tail_in, const float* __restrict__ dt_tail_in,
+                                                      float2* __restrict__ iq_tail_out, float* __restrict__ dt_tail_out,
+                                                      const uint4* __restrict__ aud_img, const int2* __restrict__ aud_idx, const uint4* __restrict__ rds_img,
+                                                      const float* __restrict__ b_lmr, const float* __restrict__ mixctl, float* __restrict__ state,
+                                                      float* __restrict__ audio, float2* __restrict__ rds, float* __restrict__ lmr_est,
+                                                      float* __restrict__ lpr_out, float* __restrict__ lmr_out, int keep_taps,
+                                                      const float* __restrict__ lmr_est_prev, int field_cur, int field_prev) {
+    using G = ExtractGeomM;
+    constexpr int TA = G::TA, XS = G::XS, XSP = G::XSP, NBW = G::NB / 2;
+    __shared__ __attribute__((aligned(16))) uint32_t lpr_h[NBW], lpr_l[NBW], lmr_h[NBW], lmr_l[NBW];   // Re fm_out_iq; imaginary rail of the x2-mixed signal
+    __shared__ __attribute__((aligned(16))) uint32_t rre_h[NBW], rre_l[NBW], rim_h[NBW], rim_l[NBW];   // x3-mixed signal
+    __shared__ __attribute__((aligned(16))) float lmr_re[XSP];                                           // real rail of the x2-mixed signal (phase estimate)
+    __shared__ __attribute__((aligned(16))) float res_lpr[TA];
+    __shared__ __attribute__((aligned(16))) float res_lmr[TA];
+    __shared__ __attribute__((aligned(16))) float res_rds[TA];        // [TA/2][2]
+    __shared__ float res_est_re[G::NEST];
+    __shared__ float off_s;
+
+    const int tiles = d.n_audio / TA;
+    const int c = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int i0 = tile * TA, tid = threadIdx.x;
+    const int lane = tid & (kWave - 1), wv = tid >> 6, lrow = lane & 15, lq = lane >> 4;
+    const int s_lo = 4 * i0 - 124;               // first fm_out sample staged (block relative), even
+    const int n = d.n_fm_out;
+    const float2* x_c = fm_out_iq + (size_t)c * n;
+    const float* dt_c = pll_dt + (size_t)c * n;
+    const float off_prev = st(state, field_prev, d.C, c);
+    float off_cur = lmr_est_prev ? 0.0f : st(state, field_cur, d.C, c);
+
+    // stage + mix, two consecutive samples per thread and step: all loads first, then the arithmetic
+    {
+        constexpr int NPAIR = (XSP + 4) / 2 + 0;           // pairs e = 0, 2, ... up to the zero padding of the RDS arrays (e - 4 < XSP)
+        constexpr int PERP = (NPAIR + 255) / 256;
+        float4 xv[PERP]; float2 dv[PERP];
+        float ev[kLmrInlineMax / kWave];
+        if (lmr_est_prev && tid < kWave) {
+#pragma unroll
+            for (int k = 0; k < kLmrInlineMax / kWave; k++)
+                ev[k] = (tid + kWave * k < d.n_est) ? lmr_est_prev[(size_t)c * d.n_est + tid + kWave * k] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < PERP; r++) {
+            const int e = 2 * (tid + 256 * r);
+            xv[r] = make_float4(0.f, 0.f, 0.f, 0.f); dv[r] = make_float2(0.f, 0.f);
+            if (e < XS) {
+                const int sx = s_lo + e;
+                if (sx < 0) {   // (tile 0 only) history: last block's samples
+                    xv[r] = *reinterpret_cast<const float4*>(iq_tail_in + (size_t)c * 128 + 128 + sx);
+                    dv[r] = *reinterpret_cast<const float2*>(dt_tail_in + (size_t)c * 128 + 128 + sx);
+                } else {
+                    xv[r] = *reinterpret_cast<const float4*>(x_c + sx);
+                    dv[r] = *reinterpret_cast<const float2*>(dt_c + sx);
+                }
+            }
+        }
+        if (lmr_est_prev) {
+            if (tid < kWave) {
+                float part = 0.0f;
+#pragma unroll
+                for (int k = 0; k < kLmrInlineMax / kWave; k++) part += ev[k];
+                float nxt = fmaf(wave_sum_f32(part) * __builtin_amdgcn_rcpf((float)d.n_est), 0.1f, off_prev);
+                const float two_pi = bits_f32(kTwoPiBits);
+                nxt = (nxt >= two_pi) ? nxt - two_pi : ((nxt <= -two_pi) ? nxt + two_pi : nxt);
+                if (tid == 0) { off_s = nxt; if (tile == 0) st(state, field_cur, d.C, c) = nxt; }
+            }
+            __syncthreads();
+            off_cur = off_s;
+        }
+        const float co_cur = fast_cos_turns(off_cur), so_cur = fast_sin_turns(off_cur);
+        const float co_prev = fast_cos_turns(off_prev), so_prev = fast_sin_turns(off_prev);
+#pragma unroll
+        for (int r = 0; r < PERP; r++) {
+            const int e = 2 * (tid + 256 * r);
+            if (e < XSP + 4) {
+                const bool live = e < XS, hist = s_lo + e < 0;       // history samples were mixed with last block's offset
+                const float co = hist ? co_prev : co_cur, so = hist ? so_prev : so_cur;
+                float lp[2], m2r[2], m2i[2], m3r[2], m3i[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const float xr = u ? xv[r].z : xv[r].x, xi = u ? xv[r].w : xv[r].y, t = u ? dv[r].y : dv[r].x;
+                    const float c1 = fast_cos_turns(t), s1 = fast_sin_turns(t);
+                    const float c2 = fmaf(c1, c1, -(s1 * s1)), s2 = (c1 + c1) * s1;
+                    const float c2o = fmaf(c2, co, -(s2 * so)), s2o = fmaf(s2, co, c2 * so);
+                    const float c3 = fmaf(c2, c1, -(s2 * s1)), s3 = fmaf(s2, c1, c2 * s1);
+                    lp[u] = live ? xr : 0.0f;
+                    m2r[u] = live ? fmaf(c2o, xr, -(xi * s2o)) : 0.0f; m2i[u] = live ? fmaf(c2o, xi, xr * s2o) : 0.0f;
+                    m3r[u] = live ? fmaf(c3, xr, -(xi * s3)) : 0.0f; m3i[u] = live ? fmaf(c3, xi, xr * s3) : 0.0f;
+                }
+                uint32_t h0, l0, h1, l1;
+                if (e < XSP) {
+                    const int w4 = G::pad(e) >> 1;
+                    split_bf16(lp[0], h0, l0); split_bf16(lp[1], h1, l1); lpr_h[w4] = pack_hi16(h0, h1); lpr_l[w4] = pack_hi16(l0, l1);
+                    split_bf16(m2i[0], h0, l0); split_bf16(m2i[1], h1, l1); lmr_h[w4] = pack_hi16(h0, h1); lmr_l[w4] = pack_hi16(l0, l1);
+                    *reinterpret_cast<float2*>(lmr_re + e) = make_float2(m2r[0], m2r[1]);
+                }
+                if (e >= 4) {
+                    const int w8 = G::pad(e - 4) >> 1;
+                    split_bf16(m3r[0], h0, l0); split_bf16(m3r[1], h1, l1); rre_h[w8] = pack_hi16(h0, h1); rre_l[w8] = pack_hi16(l0, l1);
+                    split_bf16(m3i[0], h0, l0); split_bf16(m3i[1], h1, l1); rim_h[w8] = pack_hi16(h0, h1); rim_l[w8] = pack_hi16(l0, l1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const float* taps_lmr = b_lmr + (size_t)c * 128;
+    const int est_first = (10 - (i0 % 10)) % 10;   // first output of this tile whose block index is a multiple of 10
+    if (wv < 2) {
+        // L+R / L-R: one 16 x 16 tile = the 256 outputs of the workgroup
+        const int2 slot = aud_idx[c];
+        const uint4* img = aud_img + (size_t)(wv ? slot.y : slot.x) * (6 * 2 * kWave);
+        const uint32_t* sh = wv ? lmr_h : lpr_h;
+        const uint32_t* sl = wv ? lmr_l : lpr_l;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sK = 0; sK < 6; sK++) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, img[(sK * 2 + 0) * kWave + lane]);
+            const bf16x8 al = __builtin_bit_cast(bf16x8, img[(sK * 2 + 1) * kWave + lane]);
+            const int e = 64 * lrow + 32 * sK + 8 * lq, w4 = (e + 8 * (2 * lrow + sK)) >> 1;
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sh + w4));
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sl + w4));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+        }
+        *reinterpret_cast<float4*>((wv ? res_lmr : res_lpr) + 16 * lrow + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else if (wv == 2) {
+        // RDS: columns 0-7 the real rail's 128 outputs, 8-15 the imaginary rail's
+        const int rail = lrow >> 3, colr = lrow & 7;
+        const uint32_t* sh = rail ? rim_h : rre_h;
+        const uint32_t* sl = rail ? rim_l : rre_l;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sK = 0; sK < 8; sK++) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, rds_img[(sK * 2 + 0) * kWave + lane]);
+            const bf16x8 al = __builtin_bit_cast(bf16x8, rds_img[(sK * 2 + 1) * kWave + lane]);
+            const int e = 128 * colr + 32 * sK + 8 * lq, w8 = (e + 8 * (4 * colr + sK)) >> 1;
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sh + w8));
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sl + w8));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) res_rds[2 * (16 * colr + 4 * lq + i) + rail] = acc[i];
+    } else {
+        // real rail of the L-R outputs that feed the phase estimate (one output per thread)
+        const int u = lane, ii = est_first + 10 * u;
+        if (ii < TA) {
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int jj = 0; jj < 32; jj++) {
+                const float4 x4 = *reinterpret_cast<const float4*>(lmr_re + 4 * (ii + jj));
+                a[0] = fmaf(x4.x, taps_lmr[4 * jj + 0], a[0]); a[1] = fmaf(x4.y, taps_lmr[4 * jj + 1], a[1]);
+                a[2] = fmaf(x4.z, taps_lmr[4 * jj + 2], a[2]); a[3] = fmaf(x4.w, taps_lmr[4 * jj + 3], a[3]);
+            }
+            res_est_re[u] = (a[0] + a[2]) + (a[1] + a[3]);
+        }
+    }
+    __syncthreads();
+
+    {
+        const int i = i0 + tid;
+        const float lpr = res_lpr[tid], lmr = res_lmr[tid];
+        const int mode = (int)mixctl[2 * c];
+        const float kmix = mixctl[2 * c + 1];
+        float l, r;
+        if (mode == FMD_AUDIO_STEREO) { l = fmaf(lmr, kmix, lpr); r = fmaf(-lmr, kmix, lpr); }
+        else if (mode == FMD_AUDIO_LMR) { l = lmr; r = lmr; }
+        else { l = lpr; r = lpr; }
+        reinterpret_cast<float2*>(audio)[(size_t)c * d.n_audio + i] = make_float2(l + l, r + r);
+        if (keep_taps) { lpr_out[(size_t)c * d.n_audio + i] = lpr; lmr_out[(size_t)c * d.n_audio + i] = lmr; }
+        if (tid < TA / 2) rds[(size_t)c * d.n_rds + i0 / 2 + tid] = make_float2(res_rds[2 * tid], res_rds[2 * tid + 1]);
+        // reference :500-510: estimate against the +-pi/2 constellation, every 10th output of the block
+        const int ii = est_first + 10 * tid;
+        if (ii < TA) {
+            const float ph = fast_atan2f(res_lmr[ii], res_est_re[tid]);
+            const float half_pi = bits_f32(kHalfPiBits);
+            lmr_est[(size_t)c * d.n_est + (i0 + ii) / 10] = (ph > 0.0f) ? (half_pi - ph) : (-half_pi - ph);
+        }
+    }
+    // history for the next block: last 128 fm_out_iq / pll_dt samples
+    if (tile == tiles - 1 && tid < 128) {
+        iq_tail_out[(size_t)c * 128 + tid] = x_c[n - 128 + tid];
+        dt_tail_out[(size_t)c * 128 + tid] = dt_c[n - 128 + tid];
+    }
+}
+
 // a11 — reference ExtractComponents :511-516: integrate the mean L-R phase error of the block (sequential sum in sample order).
 // Tolerance mode, blocks of up to 10 * kLmrInlineMax audio samples: the NEXT block's k_extract does it for itself
 // (in its prologue — a kernel of its own behind k_extract put two launch gaps per block on the one chain of that
@@ -2129,6 +2335,13 @@ static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Buffers& b = ctx.b;
     if constexpr (!FAST) {
         if (ctx.fast) return launch_extract_ta<TA, true>(ctx, r, s);
+    }
+    if constexpr (FAST && TA == 256) {   // tolerance mode: the FIRs on the matrix cores
+        FMD_LAUNCH(r, true, true, k_extract_mfma, dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fm_out_iq[r.buf], b.pll_dt[r.buf],
+                   b.iq_tail[r.par], b.dt_tail[r.par], b.iq_tail[r.par ^ 1], b.dt_tail[r.par ^ 1], b.aud_img, b.aud_idx, b.rds_img, b.b_lmr, b.mix,
+                   b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est[r.par], b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps,
+                   lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr, lmr_field(r.par), lmr_field(r.par ^ 1));
+        return;
     }
     FMD_LAUNCH(r, true, true, (k_extract<TA, FAST>), dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fm_out_iq[r.buf], b.pll_dt[r.buf],
                        b.iq_tail[r.par], b.dt_tail[r.par], b.iq_tail[r.par ^ 1], b.dt_tail[r.par ^ 1], b.b_lpr, b.b_lmr, ctx.rds_taps, b.mix,
