@@ -47,16 +47,16 @@ __device__ __forceinline__ float& st(float* state, int field, int C, int c) { re
 // =============================================================================================
 // TT: fm_out samples per workgroup.  A larger tile recomputes less halo (the 191-sample halo of the three cascaded stages costs
 // 19 % extra discriminator work at 512, 9 % at 1024); 1024 is used whenever the block length allows it.
-// WU > 0 (tolerance mode with de-emphasis): the de-emphasis IIR runs inside the tile from a zero state WU fm_out samples before the
-// first sample the Hilbert FIR needs; its pole is at most 0.9 (75 us), so what the zero state leaves at the first used sample is
-// below 0.9^128 = 1.4e-6 of the signal.  Costs WU more outputs of the two front stages per tile (12.5 % at 1024).
+// (Tolerance mode, k_front_mfma: with a de-emphasised channel the IIR runs inside the tile from a zero state WU = kDeemphWarmup fm_out
+// samples before the first sample the Hilbert FIR needs; its pole is at most 0.9 (75 us), so what the zero state leaves at the
+// first used sample is below 0.9^128 = 1.4e-6 of the signal.  Costs WU more outputs of the two front stages per tile: 12.5 % at 1024.)
 static constexpr int kDeemphWarmup = 128;
-template <int TT = 512, int WU = 0>
+template <int TT = 512>
 struct FrontGeom {
     static constexpr int T = TT;
-    static constexpr int NF = T + 64 + WU;                               // fm_out samples a tile makes (64: history of the Hilbert FIR)
+    static constexpr int NF = T + 64;                                    // fm_out samples a tile makes (64: history of the Hilbert FIR)
     static constexpr int NW = 2 * NF + 63;                               // fm_in samples (incl. one for prev_theta)
-    static constexpr int TAIL = 191 + 2 * WU;                            // history samples of the input stream
+    static constexpr int TAIL = 191;                                     // history samples of the input stream
     // LDS carve-up in floats; every sub-array starts on a 16-byte boundary (a ds_read_b64 that is only 4-byte
     // aligned is replayed at ~64 cycles per wave instruction)
     static constexpr int NWP = (NW + 3) & ~3;
@@ -64,13 +64,11 @@ struct FrontGeom {
     static constexpr int OFF_DEM = OFF_THETA;                            // the discriminator output replaces the phases in place: 9 KB less
                                                                          // LDS per workgroup (13.7 KB), more workgroups beside the other stages' kernels
     static constexpr int OFF_FO = OFF_DEM + NWP;
-    static constexpr int OFF_ATAN = (OFF_FO + NF + 7) & ~7;              // AtanTable (32-byte aligned rows); WU > 0: the segment end states of the IIR
-    static constexpr int LDS_FLOATS = OFF_ATAN + (WU > 0 ? NF / 8 + 16 : kAtanTableWords);
-    static_assert(OFF_DEM % 4 == 0 && OFF_FO % 4 == 0 && NF % 8 == 0, "LDS sub-arrays must be 16-byte aligned");
+    static constexpr int OFF_ATAN = (OFF_FO + NF + 7) & ~7;              // AtanTable (32-byte aligned rows)
+    static constexpr int LDS_FLOATS = OFF_ATAN + kAtanTableWords;
+    static_assert(OFF_DEM % 4 == 0 && OFF_FO % 4 == 0, "LDS sub-arrays must be 16-byte aligned");
 };
 
-// (a 32-bit BYTE offset from a uniform base: the load then takes the SGPR-base form, no 64-bit address arithmetic in the VALU;
-// a channel's block is far below 4 GB)
 // FMD_FLAG_FAST_MATH: k_front's two FIRs on the matrix cores.  Both have taps common to all stations, so each is a constant
 // banded-Toeplitz matrix times a matrix whose columns are overlapping windows of the signal:
 //   decimate-by-2, 64 taps:  Y[m][c] = y[16 c + m] = sum_t A[m][t] dem[32 c + t],  A[m][t] = h[t - 2 m]       (t < 94)
@@ -117,21 +115,19 @@ __device__ __forceinline__ float4 load_iq2(const uchar2* p, size_t i) {
     return make_float4((float)v.x - 127.0f, (float)v.y - 127.0f, (float)v.z - 127.0f, (float)v.w - 127.0f);
 }
 
-template <typename InT, int TT = 512, bool FAST = false, int WU = 0>
+template <typename InT, int TT = 512>
 __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
                                                float2* __restrict__ tail_out, float2* __restrict__ fm_out_iq,
                                                float* __restrict__ fm_out_plain, float* __restrict__ fo_tail_out, FrontTaps taps,
-                                               int deemph_path, const float* __restrict__ deemph) {
-    using G = FrontGeom<TT, WU>;
+                                               int deemph_path) {
+    using G = FrontGeom<TT>;
     constexpr int T = G::T, NW = G::NW, NF = G::NF;
-    static_assert(WU == 0 || FAST, "the in-tile de-emphasis is a tolerance-mode form");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* theta = smem + G::OFF_THETA;                           // [NW]
     float* dem = smem + G::OFF_DEM;                               // [NW-1]
     float* fo = smem + G::OFF_FO;                                 // [T+64]
     AtanTable* atab = reinterpret_cast<AtanTable*>(smem + G::OFF_ATAN);
-    if constexpr (!FAST) atan_table_fill(atab, threadIdx.x, 256);   // visible after the first barrier below
-    (void)atab; (void)deemph;
+    atan_table_fill(atab, threadIdx.x, 256);   // visible after the first barrier below
 
     const int tiles = d.n_fm_out / T;
     const int c = blockIdx.x / tiles;
@@ -172,8 +168,7 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
         for (int r = 0; r < PER; r++) {
             const int i = tid + 256 * r;
             if (i < NW) {
-                if constexpr (FAST) theta[i] = fast_atan2f(buf[r].y, buf[r].x);      // FMD_FLAG_FAST_MATH: ~21 instructions instead of ~60
-                else theta[i] = fmd_atan2f_table<sizeof(InT) == 2>(buf[r].y, buf[r].x, atab);   // u8 IQ: small integers
+                theta[i] = fmd_atan2f_table<sizeof(InT) == 2>(buf[r].y, buf[r].x, atab);   // u8 IQ: small integers
             }
         }
     }
@@ -221,48 +216,12 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
             y[v] = (a0 + a2) + (a1 + a3);
         }
         *reinterpret_cast<float2*>(fo + uu) = make_float2(y[0], y[1]);
-        if constexpr (WU == 0) {
-            if (deemph_path && uu >= 64) *reinterpret_cast<float2*>(fm_out_plain + (size_t)c * d.n_fm_out + o0 + (uu - 64)) = make_float2(y[0], y[1]);
-        }
+        if (deemph_path && uu >= 64) *reinterpret_cast<float2*>(fm_out_plain + (size_t)c * d.n_fm_out + o0 + (uu - 64)) = make_float2(y[0], y[1]);
     }
     __syncthreads();
-    if constexpr (WU > 0) {
-        // a4 (reference :403-406, IIR_Filter<float> K=2: y[n] = b0 x[n-1] + b1 x[n] + a0 y[n-1]) over the tile's NF samples, in place,
-        // from a zero state at its first sample: threads take 8 consecutive samples each from a zero state, the end states go
-        // through LDS, and every thread adds what the 16 segments before its own leave behind (a0^136 < 1e-6: older ones do not
-        // matter).  Channels that do not use the filter skip it (workgroup-uniform).
-        const float b0 = deemph[4 * c + 0], b1 = deemph[4 * c + 1], a0 = deemph[4 * c + 2];
-        if (deemph[4 * c + 3] != 0.0f) {
-            float* zs = smem + G::OFF_ATAN;                      // [16 zeros][NF / 8 segment end states]
-            constexpr int NSEG = NF / 8;
-            float yv[8];
-            if (tid < 16) zs[tid] = 0.0f;
-            if (tid < NSEG) {
-                const float4 xa = *reinterpret_cast<const float4*>(fo + 8 * tid), xb = *reinterpret_cast<const float4*>(fo + 8 * tid + 4);
-                const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-                float xp = tid ? fo[8 * tid - 1] : 0.0f, z = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 8; k++) { z = fmaf(a0, z, fmaf(xs[k], b1, xp * b0)); yv[k] = z; xp = xs[k]; }
-                zs[16 + tid] = z;
-            }
-            __syncthreads();
-            if (tid < NSEG) {
-                const float a2 = a0 * a0, a4 = a2 * a2, a8 = a4 * a4;
-                float e = 0.0f;                                  // state at the end of the previous segment
-#pragma unroll
-                for (int k = 0; k < 16; k++) e = fmaf(a8, e, zs[tid + k]);
-                float pw = a0;
-#pragma unroll
-                for (int k = 0; k < 8; k++) { yv[k] = fmaf(pw, e, yv[k]); pw *= a0; }
-                *reinterpret_cast<float4*>(fo + 8 * tid) = make_float4(yv[0], yv[1], yv[2], yv[3]);
-                *reinterpret_cast<float4*>(fo + 8 * tid + 4) = make_float4(yv[4], yv[5], yv[6], yv[7]);
-            }
-            __syncthreads();
-        }
-    }
     // a5: Hilbert FIR; only lanes 1,3,5,7 of the reference's 8-lane accumulator see non-zero taps
-    if (WU > 0 || !deemph_path) {
-        const float* fh = fo + WU;                             // the Hilbert FIR's window of output oo starts at fo[WU + oo]
+    if (!deemph_path) {
+        const float* fh = fo;                                  // the Hilbert FIR's window of output oo starts at fo[oo]
         for (int oo = tid; oo < T; oo += 256) {
             float l1 = 0.f, l3 = 0.f, l5 = 0.f, l7 = 0.f;
 #pragma unroll
@@ -281,7 +240,7 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
     if (tile == tiles - 1) {
         float2* tout = tail_out + (size_t)c * d.tail_base;
         for (int idx = tid; idx < d.tail_base; idx += 256) tout[idx] = load_iq(in_c, (unsigned)(d.N - d.tail_base + idx));
-        if (WU == 0 && !deemph_path && tid < 64) fo_tail_out[(size_t)c * 64 + tid] = fo[T + tid];
+        if (!deemph_path && tid < 64) fo_tail_out[(size_t)c * 64 + tid] = fo[T + tid];
     }
 }
 
@@ -2240,9 +2199,9 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
         return hipGetLastError();
     }
     const size_t lds = sizeof(float) * G::LDS_FLOATS;
-    auto kern = k_front<InT, TT, FAST>;
+    auto kern = k_front<InT, TT>;
     FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), lds, s, d, d_iq, ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1],
-                       ctx.b.fm_out_iq[r.buf], ctx.b.fm_out[r.buf], ctx.b.fo_tail[r.par ^ 1], ctx.front, ctx.any_deemph, ctx.b.deemph);
+                       ctx.b.fm_out_iq[r.buf], ctx.b.fm_out[r.buf], ctx.b.fo_tail[r.par ^ 1], ctx.front, ctx.any_deemph);
     return hipGetLastError();
 }
 
@@ -2379,7 +2338,7 @@ hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
 
 template <typename InT, int TT = 512>
 static hipError_t prepare_front() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front<InT, TT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front<InT, TT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(sizeof(float) * FrontGeom<TT>::LDS_FLOATS));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
