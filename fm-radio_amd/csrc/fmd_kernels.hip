@@ -1824,7 +1824,7 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
         }
         return;
     }
-    __builtin_amdgcn_s_setprio(3);
+    if constexpr (!FAST) __builtin_amdgcn_s_setprio(3);   // (tolerance mode: measured +1.5 % without, now that the FIR kernels beside it no longer fight for VALU slots)
     __syncthreads();
     // a13: AGC power pass (reference AGC_Filter::calculate_average_power, agc.h:21-30)
     float power = 0.0f;
