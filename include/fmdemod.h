@@ -67,11 +67,13 @@ typedef struct {
 #define FMD_FLAG_PLL_STREAM_ORDER  32u  /* consecutive blocks' pilot-PLL launches ordered by the stream (kernel boundary) instead of handing over per wavefront while both run (A/B and debugging; same results) */
 #define FMD_FLAG_PLL_LOW_WORK      8u  /* force the low-work pilot-PLL kernel (default: larger batches); same results either way */
 /* Tolerance mode.  Default (flag clear): every output is bit-identical to the CPU restatement of the reference (oracle/).
- * With the flag the chain keeps the reference's signal flow but uses cheaper arithmetic — minimax arctangent, hardware
- * sine/cosine, free summation order, the pilot peak filter and its AGC power as a parallel scan, the pilot PLL's NCO
- * frequency held for up to 16 samples while it moves by less than 1/8 Hz — within the parity BASELINE.json's north star
- * asks for: audio / L-R / RDS symbols within 1e-4 RMS of the reference, RDS bits identical (tests/test_gpu_fast.py).
- * Cost per sample no longer depends on whether a station's pilot PLL is in lock.  The FMD_FLAG_PLL_* selectors are ignored. */
+ * With the flag the chain keeps the reference's signal flow and state variables but uses cheaper arithmetic: minimax arctangent,
+ * hardware sine/cosine, the FIRs as bf16 x 3 products on the matrix cores (fp32 accumulation, ~1e-6 relative), the pilot peak filter
+ * and its AGC power as a parallel scan, the pilot PLL evaluated 64 samples at a time with its NCO frequency held and corrected to
+ * first order, the optional de-emphasis inside the front-end tile (time constants up to ~79 us) — within the parity BASELINE.json's
+ * north star asks for: audio / L-R within 1e-4 RMS of the reference, RDS bits identical once the synchroniser is in lock
+ * (tests/test_gpu_fast.py, DESIGN.md 3b for the two places where the reference's own decisions are discontinuous).
+ * Cost per sample does not depend on whether a station's pilot PLL is in lock.  The FMD_FLAG_PLL_* selectors are ignored. */
 #define FMD_FLAG_FAST_MATH        64u
 
 /* reference Broadcast_FM_Demod_Controls (broadcast_fm_demod.h:64-89); defaults in fmd_default_controls */
