@@ -1777,6 +1777,22 @@ __global__ __launch_bounds__(kWave) void k_lmr_phase(Dims d, const float* __rest
     out_row[c] = lmr_phase_finish(sum, d.n_est, state[(size_t)field_in * d.C + c]);
 }
 
+// Tolerance-mode form of k_lmr_phase for the batches whose k_extract does not integrate the L-R phase itself: one wavefront per
+// station doing exactly what that prologue does (same partial sums, same butterfly, same finish), so a station's outputs do not
+// depend on which side of the batch-size switch it runs.
+__global__ __launch_bounds__(kWave) void k_lmr_phase_fast(Dims d, const float* __restrict__ lmr_est, const float* __restrict__ state, int field_in,
+                                                          float* __restrict__ out_row) {
+    const int c = blockIdx.x, tid = threadIdx.x;
+    float part = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kLmrInlineMax / kWave; k++)
+        part += (tid + kWave * k < d.n_est) ? lmr_est[(size_t)c * d.n_est + tid + kWave * k] : 0.0f;
+    float nxt = fmaf(wave_sum_f32(part) * __builtin_amdgcn_rcpf((float)d.n_est), 0.1f, state[(size_t)field_in * d.C + c]);
+    const float two_pi = bits_f32(kTwoPiBits);
+    nxt = (nxt >= two_pi) ? nxt - two_pi : ((nxt <= -two_pi) ? nxt + two_pi : nxt);
+    if (tid == 0) out_row[c] = nxt;
+}
+
 // =============================================================================================
 // k_rds_sync — reference ExtractComponents :511-516 (phase integrate), SynchroniseRDS :538-547,
 // AGC_Filter (agc.h:12-30), BPSK_Synchroniser::Process (bpsk_synchroniser.cpp:94-186) with TED_Clock
@@ -2311,15 +2327,23 @@ static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
 hipError_t launch_stage_extract(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     if (ctx.d.n_audio % 256 == 0) launch_extract_ta<256>(ctx, r, s);
     else launch_extract_ta<128>(ctx, r, s);
-    if (!lmr_inline(ctx))   // P_{b+1} behind block b
-        hipLaunchKernelGGL(k_lmr_phase, dim3(serial_waves(ctx.d)), dim3(kWave), 0, s, ctx.d, ctx.b.lmr_est[r.par], ctx.b.state, lmr_field(r.par),
-                           ctx.b.state + (size_t)lmr_field(r.par ^ 1) * ctx.d.C);
+    if (!lmr_inline(ctx)) {   // P_{b+1} behind block b
+        if (ctx.fast && ctx.d.n_est <= kLmrInlineMax)
+            hipLaunchKernelGGL(k_lmr_phase_fast, dim3((unsigned)ctx.d.C), dim3(kWave), 0, s, ctx.d, ctx.b.lmr_est[r.par], ctx.b.state, lmr_field(r.par),
+                               ctx.b.state + (size_t)lmr_field(r.par ^ 1) * ctx.d.C);
+        else
+            hipLaunchKernelGGL(k_lmr_phase, dim3(serial_waves(ctx.d)), dim3(kWave), 0, s, ctx.d, ctx.b.lmr_est[r.par], ctx.b.state, lmr_field(r.par),
+                               ctx.b.state + (size_t)lmr_field(r.par ^ 1) * ctx.d.C);
+    }
     return hipGetLastError();
 }
 
 // the value the reference's GetAudioLMRPhaseError() shows after the newest block (parity `par`): P_{b+1}, into out_row[C]
 hipError_t launch_lmr_phase_peek(const LaunchCtx& ctx, int par, float* out_row, hipStream_t s) {
-    hipLaunchKernelGGL(k_lmr_phase, dim3(serial_waves(ctx.d)), dim3(kWave), 0, s, ctx.d, ctx.b.lmr_est[par], ctx.b.state, lmr_field(par), out_row);
+    if (ctx.fast && ctx.d.n_est <= kLmrInlineMax)
+        hipLaunchKernelGGL(k_lmr_phase_fast, dim3((unsigned)ctx.d.C), dim3(kWave), 0, s, ctx.d, ctx.b.lmr_est[par], ctx.b.state, lmr_field(par), out_row);
+    else
+        hipLaunchKernelGGL(k_lmr_phase, dim3(serial_waves(ctx.d)), dim3(kWave), 0, s, ctx.d, ctx.b.lmr_est[par], ctx.b.state, lmr_field(par), out_row);
     return hipGetLastError();
 }
 
