@@ -198,20 +198,20 @@ def test_release_outputs_holds_a_slot_for_a_slow_consumer(pkg):
     dm.close()
 
 
-@pytest.mark.parametrize("fs", [256_000, 1_024_000])
-def test_state_snapshot_moves_a_station_between_handles(pkg, fs):
+@pytest.mark.parametrize("fs,fast", [(256_000, False), (1_024_000, False), (256_000, True), (1_024_000, True)])
+def test_state_snapshot_moves_a_station_between_handles(pkg, fs, fast):
     """fmd_get_state / fmd_set_state: a station's state taken from channel 1 of one handle after 3 blocks and restored into
     channel 4 of another handle (different batch size, different block parity) continues bit-identically."""
     bs = fs * 32 // 1000
     nb = 7
     caps = _caps(3, nb * bs, float(fs), seed=7300)
-    a = pkg.BatchDemod(3, bs, fs, keep_taps=True)
+    a = pkg.BatchDemod(3, bs, fs, keep_taps=True, fast_math=fast)
     for b in range(3):
         a.process(caps[:, b * bs:(b + 1) * bs])
     blob = a.get_state(1)
     assert len(blob) == pkg.load_library().fmd_state_size(a.h)
     other = _caps(6, 2 * bs, float(fs), seed=7400)
-    bdm = pkg.BatchDemod(6, bs, fs, keep_taps=True)
+    bdm = pkg.BatchDemod(6, bs, fs, keep_taps=True, fast_math=fast)
     for b in range(2):                                   # two blocks: the opposite history-buffer parity
         bdm.process(other[:, b * bs:(b + 1) * bs])
     bdm.set_state(4, blob)
@@ -232,7 +232,11 @@ def test_state_snapshot_moves_a_station_between_handles(pkg, fs):
     c = pkg.BatchDemod(1, 2048 if fs != 256_000 else 8192, 256_000 if fs != 256_000 else 1_024_000)
     with pytest.raises(pkg.FmdError):
         c.set_state(0, blob)
-    a.close(); bdm.close(); c.close()
+    # ... and so is a blob of the other arithmetic mode (the tolerance mode keeps a longer input history)
+    e = pkg.BatchDemod(1, bs, fs, fast_math=not fast)
+    with pytest.raises(pkg.FmdError):
+        e.set_state(0, blob)
+    a.close(); bdm.close(); c.close(); e.close()
 
 
 def test_dead_and_pilotless_channels_do_not_change_their_neighbours(pkg):
