@@ -400,7 +400,9 @@ def main() -> None:
         gstream = torch.cuda.Stream(device)   # consumes outputs; the submitting stream never waits on them
 
     def step(k: int):
-        dm.process(x[k % n_blocks_resident])
+        # the resident blocks are never rewritten: submitted without ordering the caller's stream behind the demodulator's reads
+        # (fmd_submit_cf32_dev; with fmd_process_cf32_dev consecutive front-end launches are two cross-queue hand-overs apart)
+        dm.submit(x[k % n_blocks_resident])
         if do_gather:
             with torch.cuda.stream(gstream):
                 s = gather.slot(k)
@@ -553,11 +555,11 @@ def main() -> None:
             dm2.set_controls(ctl)
         K2 = min(K, 20)
         for k in range(P + W):
-            dm2.process(x[k % n_blocks_resident])
+            dm2.submit(x[k % n_blocks_resident])
         dm2.synchronize(); torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         for k in range(P + W, P + W + K2):
-            dm2.process(x[k % n_blocks_resident])
+            dm2.submit(x[k % n_blocks_resident])
         dm2.synchronize(); torch.cuda.synchronize(device)
         el2 = time.perf_counter() - t0
         dm2.close()

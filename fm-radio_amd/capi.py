@@ -125,12 +125,13 @@ def load_library():
     L.fmd_get_controls.argtypes = [H, C.c_int, C.POINTER(Controls)]
     L.fmd_get_rates.argtypes = [H, C.POINTER(Rates)]
     L.fmd_get_coeffs.argtypes = [H, C.c_int, C.POINTER(Coeffs)]
-    for name in ("fmd_process_cf32_dev", "fmd_process_u8_dev"):
+    for name in ("fmd_process_cf32_dev", "fmd_process_u8_dev", "fmd_submit_cf32_dev", "fmd_submit_u8_dev"):
         getattr(L, name).argtypes = [H, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     for name in ("fmd_process_cf32_host", "fmd_process_u8_host"):
         getattr(L, name).argtypes = [H, C.c_void_p, C.c_int, C.c_int]
     L.fmd_synchronize.argtypes = [H]
     L.fmd_wait_outputs.argtypes = [H, C.c_void_p]
+    L.fmd_wait_input.argtypes = [H, C.c_void_p]
     L.fmd_release_outputs.argtypes = [H, C.c_void_p]
     L.fmd_output_lifetime_blocks.restype = C.c_int
     L.fmd_state_size.restype = C.c_size_t
@@ -285,6 +286,31 @@ class BatchDemod:
         if rc not in (FMD_OK, FMD_ERR_SIZE):
             self._check(rc)
         return rc
+
+    def submit(self, iq, ready_stream=None) -> int:
+        """fmd_submit_*_dev: like process() for a torch CUDA tensor, but nothing is queued on the caller's streams.  The block is
+        read after everything already queued on `ready_stream` (None: the data is in place now); wait_input() tells when the
+        buffer may be rewritten.  For hosts that rotate input buffers (bench.py's resident blocks, station_ring.hpp)."""
+        import torch
+        shape = tuple(iq.shape)
+        if len(shape) != 3 or shape[2] != 2 or not iq.is_cuda or not iq.is_contiguous():
+            raise ValueError("iq must be a contiguous CUDA tensor [C, N, 2]")
+        if hasattr(ready_stream, "cuda_stream"):
+            ready_stream = ready_stream.cuda_stream
+        fn = {torch.float32: self.L.fmd_submit_cf32_dev, torch.uint8: self.L.fmd_submit_u8_dev}[iq.dtype]
+        rc = fn(self.h, iq.data_ptr(), shape[0], shape[1], C.c_void_p(ready_stream) if ready_stream else None)
+        if rc not in (FMD_OK, FMD_ERR_SIZE):
+            self._check(rc)
+        return rc
+
+    def wait_input(self, stream=None):
+        """Make `stream` wait (on the device) until the newest submitted block's input buffer has been read."""
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        elif hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+        self._check(self.L.fmd_wait_input(self.h, C.c_void_p(stream)))
 
     def synchronize(self):
         self._check(self.L.fmd_synchronize(self.h))

@@ -56,12 +56,14 @@ struct fmd_handle_s {
     bool pipelined = true;
     long n_blocks = 0;                       // blocks submitted since create/reset; slot = n_blocks % kSlots
     int out_slot = 0;                        // slot holding the newest block's outputs
+    hipEvent_t ev_consumed = nullptr;        // fires when the newest block's input buffer has been read (fmd_wait_input)
     int device = 0;
     int bytes_cap = 0;
     std::string err;
     std::map<int, std::vector<float>> lpf_cache;  // cut-off Hz -> 128 taps
     std::map<int, int> img_slot;                  // FMD_FLAG_FAST_MATH: cut-off Hz -> slot of its operand image in aud_img (k_extract_mfma)
     size_t img_capacity = 0;                      // slots allocated in aud_img
+    unsigned debug_skip = 0;                 // development knob FMD_DEBUG_SKIP_STAGES: bit (1 << Stage) = do not launch that stage (timing experiments only: outputs are garbage)
     int profiling = 0;                       // 0 off, 1 every kernel of every block, 2 k_pilot_pll every block + the rest every 4th
     std::vector<ProfiledBlock*> marks;       // one per profiled block, drained by fmd_profile_read
 };
@@ -286,6 +288,7 @@ int zero_history(fmd_handle h, hipStream_t s) {
     if (b.pll_chain) HIP_TRY(h, hipMemsetAsync(b.pll_chain, 0, sizeof(unsigned) * ((size_t)h->pll_waves + 1), s));
     h->pll_seq = 0;
     h->n_blocks = 0;
+    h->ev_consumed = nullptr;
     h->out_slot = 0;
     for (bool& u : h->slot_used) u = false;
     for (bool& u : h->consumer_pending) u = false;
@@ -310,8 +313,10 @@ int sync_all(fmd_handle h) {
     return FMD_OK;
 }
 
+// ordered: fmd_process_*_dev (the caller's stream is ordered behind the library's read of the block); otherwise fmd_submit_*_dev
+// (`stream` only says when the input is ready, NULL = now; nothing is queued on it)
 template <typename InT>
-int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, void* stream) {
+int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, void* stream, bool ordered = true) {
     if (!h) return FMD_ERR_ARG;
     if (!d_iq) return fail(h, FMD_ERR_ARG, "null input pointer");
     if (n_channels != h->cfg.n_channels || n_samples != h->cfg.block_size)
@@ -328,6 +333,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     const SlotRef ref{slot, (int)(h->n_blocks & 1), nullptr, nullptr};
     const bool u8 = sizeof(InT) == 2;
     const bool pipe = h->pipelined;
+    if (!pipe) ordered = true;                     // every stage runs on `s` itself
     hipStream_t sF = pipe ? h->sF : s, sA = pipe ? h->sA : s, sX = pipe ? h->sX : s, sR = pipe ? h->sR : s;
     // consecutive blocks' PLL launches alternate between two streams when they hand over per wavefront (fmd_kernels.hip)
     const bool chained = pipe && h->pll_chained;
@@ -354,6 +360,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         if (pipe && !r.t1) r.done = done;
         if (st == ST_PLL && chained) r.seq = ++h->pll_seq;
         dep = r.t1 ? r.t1 : done;
+        if (h->debug_skip & (1u << st)) return pipe ? hipEventRecord(dep, on) : hipSuccess;
         return fn(h->ctx, r, on);
     };
     hipError_t e = hipSuccess;
@@ -372,8 +379,10 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     hipStream_t s_first = predecim ? sP : sF;      // the stream of the stage that reads the caller's input
     if (pipe) {
         // input is ready once everything queued so far on the caller's stream has run
-        HIP_TRY(h, hipEventRecord(h->ev_in, s));
-        HIP_TRY(h, hipStreamWaitEvent(s_first, h->ev_in, 0));
+        if (ordered || s) {
+            HIP_TRY(h, hipEventRecord(h->ev_in, s));
+            HIP_TRY(h, hipStreamWaitEvent(s_first, h->ev_in, 0));
+        }
         // WAR: this slot's fm_in / fm_out_iq / pilot / pll_dt were last read by the stages of the block kSlots blocks ago
         if (h->slot_used[slot]) {
             HIP_TRY(h, hipStreamWaitEvent(sF, h->ev_X[slot], 0));
@@ -399,7 +408,8 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         hipEvent_t front_done = h->ctx.any_deemph ? h->ev_D[slot] : h->ev_F[slot];
         if (pipe && !r.t1) r.done = front_done;
         dep = r.t1 ? r.t1 : front_done;
-        e = launch_stage_front(h->ctx, r, d_iq, u8, sF);
+        if (h->debug_skip & (1u << ST_FRONT)) e = pipe ? hipEventRecord(dep, sF) : hipSuccess;
+        else e = launch_stage_front(h->ctx, r, d_iq, u8, sF);
     }
     if (e != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_front launch: %s", hipGetErrorString(e));
     hipEvent_t front_dep = dep;                    // k_front itself: the caller's buffer (256 kSa/s captures) has been consumed
@@ -411,7 +421,13 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         if ((e = run(ST_DEEMPH, sDe, launch_stage_deemph, h->ev_F[slot])) != hipSuccess)
             return fail(h, FMD_ERR_DEVICE, "de-emphasis launch: %s", hipGetErrorString(e));
     }
-    if (pipe) HIP_TRY(h, hipStreamWaitEvent(s, input_done ? input_done : front_dep, 0));   // the caller may reuse `iq` in stream order after this call
+    if (pipe && ordered) HIP_TRY(h, hipStreamWaitEvent(s, input_done ? input_done : front_dep, 0));   // the caller may reuse `iq` in stream order after this call
+    if (pipe) {
+        // fmd_wait_input: an event that outlives this call (a timed stage's stop event belongs to the profiling marks)
+        hipEvent_t persistent = predecim ? h->ev_P[slot] : (h->ctx.any_deemph ? h->ev_D[slot] : h->ev_F[slot]);
+        if ((input_done ? input_done : front_dep) != persistent) HIP_TRY(h, hipEventRecord(persistent, predecim ? sP : sF));
+        h->ev_consumed = persistent;
+    }
     if (!h->ctx.fast) {   // (FMD_FLAG_FAST_MATH: the pilot peak filter runs inside the PLL kernel, there is no power pass)
         if (pipe) HIP_TRY(h, hipStreamWaitEvent(sA, dep, 0));
         if ((e = run(ST_POWER, sA, launch_stage_power, h->ev_A[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_pilot_power launch: %s", hipGetErrorString(e));
@@ -568,6 +584,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     h->ctx.keep_taps = (cfg->flags & FMD_FLAG_KEEP_TAPS) ? 1 : 0;
     h->ctx.fast = (cfg->flags & FMD_FLAG_FAST_MATH) ? 1 : 0;
     h->ctx.pll_hold_hz = 2.0f;
+    if (const char* e = getenv("FMD_DEBUG_SKIP_STAGES")) h->debug_skip = (unsigned)strtoul(e, nullptr, 0);   // development knob
     if (const char* e = getenv("FMD_DEBUG_PLL_HOLD_HZ")) h->ctx.pll_hold_hz = (float)atof(e);   // development knob (tools/dbg): 0 = one sample per span
 
     fmd_controls def;
@@ -716,6 +733,19 @@ int fmd_process_cf32_dev(fmd_handle h, const float* d_iq, int n_channels, int n_
 }
 int fmd_process_u8_dev(fmd_handle h, const uint8_t* d_iq, int n_channels, int n_samples, void* stream) {
     return process_dev<uchar2>(h, reinterpret_cast<const uchar2*>(d_iq), n_channels, n_samples, stream);
+}
+int fmd_submit_cf32_dev(fmd_handle h, const float* d_iq, int n_channels, int n_samples, void* ready_stream) {
+    return process_dev<float2>(h, reinterpret_cast<const float2*>(d_iq), n_channels, n_samples, ready_stream, false);
+}
+int fmd_submit_u8_dev(fmd_handle h, const uint8_t* d_iq, int n_channels, int n_samples, void* ready_stream) {
+    return process_dev<uchar2>(h, reinterpret_cast<const uchar2*>(d_iq), n_channels, n_samples, ready_stream, false);
+}
+int fmd_wait_input(fmd_handle h, void* stream) {
+    if (!h) return FMD_ERR_ARG;
+    if (!h->pipelined || h->n_blocks == 0 || !h->ev_consumed) return FMD_OK;   // unpipelined: the read is already ordered on the submitting stream
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->ev_consumed, 0));
+    return FMD_OK;
 }
 int fmd_process_cf32_host(fmd_handle h, const float* iq, int n_channels, int n_samples) {
     return process_host<float2>(h, reinterpret_cast<const float2*>(iq), n_channels, n_samples);

@@ -7,8 +7,8 @@
 //
 //   producers (any threads, one per station at a time)        owner thread                       GPU
 //   Push(station, iq, n) -> memcpy into the station's row     Poll(): block complete in every    H2D copy   (copy-in stream)
-//   of a PINNED staging block [C][N][2] u8; a station may     station -> hipMemcpyAsync, then    fmd_process_u8_dev (library streams)
-//   run up to `depth - 1` blocks ahead of the slowest         fmd_process_u8_dev, then async     D2H audio / RDS bytes (copy-out stream)
+//   of a PINNED staging block [C][N][2] u8; a station may     station -> hipMemcpyAsync, then    fmd_submit_u8_dev (library streams)
+//   run up to `depth - 1` blocks ahead of the slowest         fmd_submit_u8_dev, then async      D2H audio / RDS bytes (copy-out stream)
 //   (ConsumeBuffer semantics: returns what it took)           D2H of the outputs; finished
 //                                                             blocks -> observers, per station
 //
@@ -171,12 +171,12 @@ private:
 
     void submit(Slot& s) {
         const size_t in_bytes = (size_t)C * N * 2;
-        // the device input block was last read by the demodulator kDepth blocks ago: ordered by the library onto s_proc
+        // the device input block was last read by the demodulator D blocks ago (ev_consumed, recorded behind fmd_wait_input)
         hip(hipStreamWaitEvent(s_in, s.ev_consumed, 0), "wait consumed");
         hip(hipMemcpyAsync(s.d_in, s.h_in, in_bytes, hipMemcpyHostToDevice, s_in), "H2D");
-        hip(hipEventRecord(s.ev_copied, s_in), "record");
-        hip(hipStreamWaitEvent(s_proc, s.ev_copied, 0), "wait copied");
-        check(fmd_process_u8_dev(h, s.d_in, C, N, s_proc), "fmd_process_u8_dev");
+        // submitted behind the copy on s_in; nothing is queued on s_in (the next block's copy does not wait for this block's front end)
+        check(fmd_submit_u8_dev(h, s.d_in, C, N, s_in), "fmd_submit_u8_dev");
+        check(fmd_wait_input(h, s_proc), "fmd_wait_input");
         hip(hipEventRecord(s.ev_consumed, s_proc), "record");   // fires once the library has consumed the input block
         // outputs: device views of the newest block -> pinned host memory, behind the block's last stage, on the copy-out stream
         check(fmd_wait_outputs(h, s_out), "fmd_wait_outputs");

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FMD_API_VERSION 2
+#define FMD_API_VERSION 3
 /* further fmd_process_* calls during which a block's outputs stay valid (see the lifetime rule above) */
 #define FMD_OUTPUT_LIFETIME_BLOCKS 5
 
@@ -142,6 +142,18 @@ int fmd_process_cf32_dev(fmd_handle h, const float* d_iq, int n_channels, int n_
 int fmd_process_u8_dev(fmd_handle h, const uint8_t* d_iq, int n_channels, int n_samples, void* stream);
 int fmd_process_cf32_host(fmd_handle h, const float* iq, int n_channels, int n_samples);
 int fmd_process_u8_host(fmd_handle h, const uint8_t* iq, int n_channels, int n_samples);
+/* The same blocks submitted WITHOUT touching the caller's streams (API v3) — for hosts that rotate several input buffers, as the
+ * reference's device thread does with its USB buffers (src/device/device.cpp:107-119) and fm-radio_amd/host/station_ring.hpp does
+ * with its staging blocks.  The block is read after everything already queued on `ready_stream` (NULL: the data is in place
+ * now); nothing is queued on `ready_stream` or any other stream of the caller, so the caller's streams never wait for the
+ * demodulator and consecutive blocks' first stages run back to back (fmd_process_*_dev orders the caller's stream behind the
+ * library's read of every block, which also orders the next block's submission behind it: two cross-queue hand-overs, ~0.1 ms,
+ * between consecutive front-end launches).  The buffer may be rewritten once fmd_wait_input() says so. */
+int fmd_submit_cf32_dev(fmd_handle h, const float* d_iq, int n_channels, int n_samples, void* ready_stream);
+int fmd_submit_u8_dev(fmd_handle h, const uint8_t* d_iq, int n_channels, int n_samples, void* ready_stream);
+/* make `stream` wait (on the device, no host block) until the library has finished reading the input buffer of the newest
+ * block submitted with fmd_submit_*_dev / fmd_process_*_dev */
+int fmd_wait_input(fmd_handle h, void* stream);
 int fmd_synchronize(fmd_handle h);
 /* make `stream` wait (on the device, no host block) until the newest block's outputs are complete */
 int fmd_wait_outputs(fmd_handle h, void* stream);
