@@ -152,6 +152,7 @@ def load_library():
     L.fmd_selftest_atan2_small.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.fmd_selftest_fast_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.fmd_get_spec_stats.argtypes = [H, C.c_void_p, C.c_int]
+    L.fmd_design_pll_span.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.fmd_profile_enable.argtypes = [H, C.c_int]
     L.fmd_profile_read.argtypes = [H, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]
     L.fmd_chan_design.argtypes = [C.c_double, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]

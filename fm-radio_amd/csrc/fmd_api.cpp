@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <new>
@@ -248,6 +249,63 @@ void design_pilot_fast(const fmd_coeffs& k, PilotFastTab* t) {
     t->k = k.pilot_b[0]; t->a0 = k.pilot_a[0]; t->a1 = k.pilot_a[1];
 }
 
+// Tables of k_pll_span (fmd_kernels.h PllSpanTab): the pilot PLL's loop filter, integrator and NCO over one span as a linear map,
+// in double.  Unknowns v = (lpf, I, e1, e2, r0, eh[0..L-1]); conventions of the reference loop (broadcast_fm_demod.cpp:430-456):
+// at sample n it uses the previous sample's error, lpf[n] = b0 e[n-2] + b1 e[n-1] + a0 lpf[n-1], I[n] = I[n-1] + 0.1 Ts e[n-1],
+// f[n] = -19000 - 100 (0.01 lpf[n] + I[n]), t[n] = t[n-1] + Ts f[n]; with the hold at F0 = f[0] + r0 the error is
+// e[n] = 2 pi (eh[n] + dev[n]), dev[n] = Ts sum_{j <= n} (f[j] - F0): substituting sample by sample is the triangular solve.
+void design_pll_span(const fmd_coeffs& k, PllSpanTab* t) {
+    constexpr int L = kSpan, NV = 5 + L;
+    const double b0 = k.pll_lpf_b[0], b1 = k.pll_lpf_b[1], a0 = k.pll_lpf_a[0];
+    const float Ts32 = 1.0f / 128000.0f;                       // the reference's PLL_Mixer KTs (broadcast_fm_demod.cpp:226-235), a float
+    const double Ts = (double)Ts32, ktsi = (double)(0.1f * Ts32), two_pi = 6.283185307179586476925;
+    using Vec = std::vector<double>;
+    auto unit = [&](int i) { Vec v(NV, 0.0); v[(size_t)i] = 1.0; return v; };
+    Vec lpf = unit(0), I = unit(1), e1 = unit(2), e2 = unit(3), dev(NV, 0.0), g0;
+    Vec rows[kSpanRows];
+    for (int n = 0; n < L; n++) {
+        Vec g(NV), e(NV);
+        for (int i = 0; i < NV; i++) {
+            lpf[i] = b0 * e2[i] + b1 * e1[i] + a0 * lpf[i];
+            I[i] += ktsi * e1[i];
+            g[i] = -100.0 * (0.01 * lpf[i] + I[i]);
+        }
+        if (n == 0) g0 = g;
+        for (int i = 0; i < NV; i++) dev[i] += Ts * (g[i] - g0[i]);
+        dev[4] -= Ts;                                           // the hold runs r0 faster than f[0]
+        for (int i = 0; i < NV; i++) e[i] = two_pi * dev[i];
+        e[5 + n] += two_pi;
+        if (n == kSpanN1) rows[2] = dev;
+        if (n == kSpanN2) rows[3] = dev;
+        if (n == L - 1) { rows[0] = lpf; rows[1] = I; rows[4] = dev; }
+        e2 = e1; e1 = e;
+    }
+    std::memset(t, 0, sizeof(*t));
+    for (int r = 0; r < kSpanRows; r++) {
+        for (int n = 0; n < L; n++) t->w[r][n] = (float)rows[r][(size_t)(5 + n)];
+        for (int i = 0; i < 5; i++) t->s[r][i] = (float)rows[r][(size_t)i];
+    }
+    // dev(n) ~ alpha n + beta n^2 + gamma n^3 through the three deviation rows
+    const double x[3] = {(double)kSpanN1, (double)kSpanN2, (double)(L - 1)};
+    double A[3][3], inv[3][3];
+    for (int i = 0; i < 3; i++) { A[i][0] = x[i]; A[i][1] = x[i] * x[i]; A[i][2] = x[i] * x[i] * x[i]; }
+    const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) + A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            inv[j][i] = (A[i1][j1] * A[i2][j2] - A[i1][j2] * A[i2][j1]) / det;     // cofactor (cyclic indices carry the sign), transposed
+        }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) t->minv[i][j] = (float)inv[i][j];
+    // quadrature of the filtered pilot's real rail.  The reference's Hilbert rail is im[n] = sum_k b[k] s[n - 64 + k] beside
+    // re[n] = s[n - 32] (hilbert_fir_filter.h:26-46); for s = cos(w0 n) that is |H(w0)| sin(w0 (n - 32)), and
+    // re[n-1] - re[n+1] = 2 sin(w0) sin(w0 (n - 32)): im[n] = quad (re[n-1] - re[n+1]), quad = |H(w0)| / (2 sin w0)
+    const double w0 = two_pi * 19000.0 / 128000.0;
+    double hr = 0.0, hi = 0.0;
+    for (int i = 0; i < 65; i++) { hr += k.b_hilbert[i] * std::cos(w0 * i); hi += k.b_hilbert[i] * std::sin(w0 * i); }
+    t->quad = (float)(std::sqrt(hr * hr + hi * hi) / (2.0 * std::sin(w0)));
+    t->kappa = (float)(-19000.0 * Ts + 19.0 / 128.0);
+}
+
 void design_front_mfma(const fmd_coeffs& k, std::vector<uint16_t>& img) {
     img.assign((size_t)2 * 3 * 2 * 64 * 8, 0);
     toeplitz_image(k.b_fm_out, 64, 2, 3, img.data());
@@ -280,6 +338,11 @@ int zero_history(fmd_handle h, hipStream_t s) {
         HIP_TRY(h, hipMemsetAsync(b.lmr_est[p], 0, sizeof(float) * (size_t)d.C * d.n_est, s));
     }
     for (int p = 0; p < kSlots; p++) {
+        if (b.fo_pl[p]) {   // the history in front of the planes' rows (and the rows themselves)
+            HIP_TRY(h, hipMemsetAsync(b.fo_pl[p], 0, sizeof(float) * (size_t)d.C * ((size_t)kFoPad + d.n_fm_out), s));
+            HIP_TRY(h, hipMemsetAsync(b.im_pl[p], 0, sizeof(float) * (size_t)d.C * ((size_t)kImPad + d.n_fm_out), s));
+            HIP_TRY(h, hipMemsetAsync(b.pll_poly[p], 0, sizeof(float4) * (size_t)d.C * ((size_t)1 + d.n_fm_out / kSpan), s));
+        }
         HIP_TRY(h, hipMemsetAsync(b.rds_count[p], 0, sizeof(int) * (size_t)d.C, s));
         HIP_TRY(h, hipMemsetAsync(b.rds_bytes_count[p], 0, sizeof(int) * (size_t)d.C, s));
     }
@@ -603,12 +666,19 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
         if (!rc) rc = dev_alloc(h, &b.dt_tail[p], C * 128);
         if (!rc) rc = dev_alloc(h, &b.fo_tail[p], C * 64);
     }
+    // Tolerance mode: the analytic signal as two planes and the NCO phase as span polynomials; the interleaved / per-sample streams
+    // only for FMD_FLAG_KEEP_TAPS (the getters) and for block lengths that run k_extract<128> (audio blocks not multiples of 256)
+    const bool fast = h->ctx.fast != 0;
+    const bool streams = !fast || h->ctx.keep_taps || (d.n_audio % 256) != 0;
     for (int p = 0; p < kSlots && !rc; p++) {
-        rc = dev_alloc(h, &b.fm_out_iq[p], C * d.n_fm_out);
+        if (streams) rc = dev_alloc(h, &b.fm_out_iq[p], C * d.n_fm_out);
         if (!rc && m > 1) rc = dev_alloc(h, &b.fm_in[p], C * d.n_fm_in);
-        if (!rc) rc = dev_alloc(h, &b.fm_out[p], C * d.n_fm_out);
-        if (!rc && !h->ctx.fast) rc = dev_alloc(h, &b.pilot[p], C * d.n_fm_out);   // (fast mode never materialises the pilot stream)
-        if (!rc) rc = dev_alloc(h, &b.pll_dt[p], C * d.n_fm_out);
+        if (!rc && !fast) rc = dev_alloc(h, &b.fm_out[p], C * d.n_fm_out);
+        if (!rc && !fast) rc = dev_alloc(h, &b.pilot[p], C * d.n_fm_out);   // (fast mode never materialises the pilot stream)
+        if (!rc && streams) rc = dev_alloc(h, &b.pll_dt[p], C * d.n_fm_out);
+        if (!rc && fast) rc = dev_alloc(h, &b.fo_pl[p], C * ((size_t)kFoPad + d.n_fm_out));
+        if (!rc && fast) rc = dev_alloc(h, &b.im_pl[p], C * ((size_t)kImPad + d.n_fm_out));
+        if (!rc && fast) rc = dev_alloc(h, &b.pll_poly[p], C * ((size_t)1 + d.n_fm_out / kSpan));
         if (!rc) rc = dev_alloc(h, &b.audio[p], C * d.n_audio * 2);
         if (!rc) rc = dev_alloc(h, &b.rds_sym[p], C * d.n_rds);
         if (!rc) rc = dev_alloc(h, &b.rds_raw_sym[p], h->ctx.keep_taps ? C * d.n_rds : 4);
@@ -642,6 +712,13 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
                 toeplitz_image(h->base.b_rds, 128, 8, 8, rimg.data());
                 if (hipMemcpyAsync(b.rds_img, rimg.data(), rimg.size() * 2, hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
                     hipStreamSynchronize(h->own_stream) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "operand table upload failed");
+            }
+            if (!rc) rc = dev_alloc(h, &b.span_tab, 1);
+            if (!rc) {
+                PllSpanTab st_;
+                design_pll_span(h->base, &st_);
+                if (hipMemcpyAsync(b.span_tab, &st_, sizeof(st_), hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
+                    hipStreamSynchronize(h->own_stream) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "span table upload failed");
             }
             PilotFastTab tab;
             design_pilot_fast(h->base, &tab);
@@ -854,8 +931,10 @@ int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats
     bool from_state = false, lmr_peek = false;
     int field = 0;
     const std::string s(name);
-    if (s == "fm_out_iq") { p = b.fm_out_iq[o]; n = 2 * C * d.n_fm_out; }
-    else if (s == "pll_dt") { p = b.pll_dt[o]; n = C * d.n_fm_out; }
+    if (s == "fm_out_iq" && b.fm_out_iq[o]) { p = b.fm_out_iq[o]; n = 2 * C * d.n_fm_out; }
+    else if (s == "pll_dt" && b.pll_dt[o]) { p = b.pll_dt[o]; n = C * d.n_fm_out; }
+    else if (s == "fm_out_iq" || s == "pll_dt") return fail(h, FMD_ERR_NAME, "stream '%s' needs FMD_FLAG_KEEP_TAPS in the tolerance mode (it is not materialised otherwise)", name);
+    else if (s == "pll_poly" && b.pll_poly[o]) { p = b.pll_poly[o]; n = 4 * C * ((size_t)1 + d.n_fm_out / kSpan); }   // tolerance mode: [C][1 + spans][4], entry 0 = the previous block's last span
     else if (s == "audio") { p = b.audio[o]; n = 2 * C * d.n_audio; }
     else if (s == "rds_sym") { p = b.rds_sym[o]; n = C * d.n_rds; }
     else if (s == "lmr_est") { p = b.lmr_est[(h->n_blocks + 1) & 1]; n = C * d.n_est; }
@@ -886,18 +965,28 @@ extern "C++" {
 namespace {
 struct StateHeader { uint32_t magic, version; int32_t fs_baseband, m, n_fields, tail_base; uint32_t reserved[2]; };
 constexpr uint32_t kStateMagic = 0x53444d46u;   // "FMDS"
-struct StatePart { void* base[2]; size_t floats; int par_flip; };   // per-channel row of `floats` floats at base[par ^ par_flip] + channel * floats
+struct StatePart { float* base; size_t floats; size_t stride; };   // the channel's `floats` floats at base + channel * stride
 
+// the histories the NEXT block reads (parity / slot of block number n_blocks)
 std::vector<StatePart> state_parts(fmd_handle h) {
     const Dims& d = h->ctx.d;
     Buffers& b = h->ctx.b;
+    const int par = (int)(h->n_blocks & 1), slot = (int)(h->n_blocks % kSlots);
     std::vector<StatePart> v;
-    v.push_back({{b.base_tail[0], b.base_tail[1]}, (size_t)d.tail_base * 2, 0});
-    if (d.m > 1) v.push_back({{b.pre_tail[0], b.pre_tail[1]}, 64 * 2, 0});
-    v.push_back({{b.iq_tail[0], b.iq_tail[1]}, 128 * 2, 0});
-    v.push_back({{b.dt_tail[0], b.dt_tail[1]}, 128, 0});
-    v.push_back({{b.fo_tail[0], b.fo_tail[1]}, 64, 0});
-    v.push_back({{b.lmr_est[0], b.lmr_est[1]}, (size_t)d.n_est, 1});   // the newest block's L-R phase estimates (the next k_extract integrates them)
+    auto by_par = [&](void* const* base, size_t floats, int flip) { v.push_back({static_cast<float*>(base[par ^ flip]), floats, floats}); };
+    { void* p[2] = {b.base_tail[0], b.base_tail[1]}; by_par(p, (size_t)d.tail_base * 2, 0); }
+    if (d.m > 1) { void* p[2] = {b.pre_tail[0], b.pre_tail[1]}; by_par(p, 64 * 2, 0); }
+    if (b.fm_out_iq[0]) {   // the interleaved streams' consumers keep their own tails (exact mode; tolerance mode with k_extract<128>)
+        { void* p[2] = {b.iq_tail[0], b.iq_tail[1]}; by_par(p, 128 * 2, 0); }
+        { void* p[2] = {b.dt_tail[0], b.dt_tail[1]}; by_par(p, 128, 0); }
+    }
+    { void* p[2] = {b.fo_tail[0], b.fo_tail[1]}; by_par(p, 64, 0); }
+    { void* p[2] = {b.lmr_est[0], b.lmr_est[1]}; by_par(p, (size_t)d.n_est, 1); }   // the newest block's L-R phase estimates (the next k_extract integrates them)
+    if (b.fo_pl[0]) {       // tolerance mode: the previous block's tails in front of the next slot's rows (k_pll_span)
+        v.push_back({b.fo_pl[slot], (size_t)kFoPad, (size_t)kFoPad + d.n_fm_out});
+        v.push_back({b.im_pl[slot], (size_t)kImPad, (size_t)kImPad + d.n_fm_out});
+        v.push_back({reinterpret_cast<float*>(b.pll_poly[slot]), 4, 4 * ((size_t)1 + d.n_fm_out / kSpan)});
+    }
     return v;
 }
 size_t state_floats(fmd_handle h) {
@@ -918,7 +1007,7 @@ int fmd_get_state(fmd_handle h, int channel, void* blob, size_t cap_bytes) {
     int rc = sync_all(h);
     if (rc) return rc;
     const Dims& d = h->ctx.d;
-    StateHeader hd{kStateMagic, 2u, h->cfg.fs_baseband, d.m, (int32_t)S_NUM_FIELDS, d.tail_base, {0u, 0u}};
+    StateHeader hd{kStateMagic, 3u, h->cfg.fs_baseband, d.m, (int32_t)S_NUM_FIELDS, d.tail_base, {0u, 0u}};
     std::memcpy(blob, &hd, sizeof(hd));
     float* out = reinterpret_cast<float*>(static_cast<char*>(blob) + sizeof(hd));
     // SoA fields [field][C] -> one float per field
@@ -928,7 +1017,7 @@ int fmd_get_state(fmd_handle h, int channel, void* blob, size_t cap_bytes) {
     if (par == 1) std::swap(out[S_LMR_PHASE_CUR], out[S_LMR_PHASE_PREV]);
     out += S_NUM_FIELDS;
     for (const StatePart& p : state_parts(h)) {
-        HIP_TRY(h, hipMemcpy(out, static_cast<float*>(p.base[par ^ p.par_flip]) + (size_t)channel * p.floats, sizeof(float) * p.floats, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(out, p.base + (size_t)channel * p.stride, sizeof(float) * p.floats, hipMemcpyDeviceToHost));
         out += p.floats;
     }
     return FMD_OK;
@@ -942,7 +1031,7 @@ int fmd_set_state(fmd_handle h, int channel, const void* blob, size_t n_bytes) {
     StateHeader hd;
     if (n_bytes < sizeof(hd)) return fail(h, FMD_ERR_ARG, "state blob too short");
     std::memcpy(&hd, blob, sizeof(hd));
-    if (hd.magic != kStateMagic || hd.version != 2u || hd.fs_baseband != h->cfg.fs_baseband || hd.m != d.m || hd.n_fields != (int32_t)S_NUM_FIELDS ||
+    if (hd.magic != kStateMagic || hd.version != 3u || hd.fs_baseband != h->cfg.fs_baseband || hd.m != d.m || hd.n_fields != (int32_t)S_NUM_FIELDS ||
         hd.tail_base != d.tail_base || n_bytes != fmd_state_size(h))
         return fail(h, FMD_ERR_ARG, "state blob does not match this handle (rate %d vs %d, %zu vs %zu bytes)", hd.fs_baseband, h->cfg.fs_baseband, n_bytes, fmd_state_size(h));
     int rc = sync_all(h);
@@ -954,7 +1043,7 @@ int fmd_set_state(fmd_handle h, int channel, const void* blob, size_t n_bytes) {
     HIP_TRY(h, hipMemcpy2D(h->ctx.b.state + channel, sizeof(float) * (size_t)d.C, fields.data(), sizeof(float), sizeof(float), S_NUM_FIELDS, hipMemcpyHostToDevice));
     in += S_NUM_FIELDS;
     for (const StatePart& p : state_parts(h)) {
-        HIP_TRY(h, hipMemcpy(static_cast<float*>(p.base[par ^ p.par_flip]) + (size_t)channel * p.floats, in, sizeof(float) * p.floats, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(p.base + (size_t)channel * p.stride, in, sizeof(float) * p.floats, hipMemcpyHostToDevice));
         in += p.floats;
     }
     return FMD_OK;
@@ -993,6 +1082,20 @@ int fmd_selftest_fast_math(int kind, const float* a, const float* b, float* out,
 int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t* ok, size_t n) {
     if (!ok) return FMD_ERR_ARG;
     return selftest_atan2_host(y, x, out, ok, n);
+}
+
+int fmd_design_pll_span(int fs_baseband, float* w, float* s, float* minv, float* misc2) {
+    if (!w || !s || !minv || !misc2) return FMD_ERR_ARG;
+    if (fs_baseband != 256000 && fs_baseband != 1024000 && fs_baseband != 2048000) return FMD_ERR_ARG;
+    fmd_controls def;
+    fmd_default_controls(&def);
+    fmd_coeffs k{};
+    design_all(&k, fs_baseband, &def);
+    PllSpanTab t;
+    design_pll_span(k, &t);
+    std::memcpy(w, t.w, sizeof(t.w)); std::memcpy(s, t.s, sizeof(t.s)); std::memcpy(minv, t.minv, sizeof(t.minv));
+    misc2[0] = t.quad; misc2[1] = t.kappa;
+    return FMD_OK;
 }
 
 int fmd_get_spec_stats(fmd_handle h, uint64_t* out8, int reset) {

@@ -59,6 +59,31 @@ struct PilotFastTab {
     float k, a0, a1;
 };
 
+// FMD_FLAG_FAST_MATH, round 3: the pilot PLL advanced one span of kSpan samples at a time (k_pll_span).  Behind the pilot peak
+// filter the phase detector's input is a line a few Hz wide, and everything between the detector and the NCO (loop filter,
+// integrator, NCO phase) is linear: with the NCO frequency word of the span's first sample HELD, the error sequence
+//   eh[n] = wrap(arg pilot[n] + t_prev + (n + 1) F0 Ts)                       (turns; one arctangent per sample, independent of the loop)
+// determines the loop state after the span and the NCO phase at any sample as fixed weight vectors applied to eh — the feedback
+// of the phase deviation from the hold into the later errors included exactly (a triangular solve, done on the host in double).
+// Rows: 0 loop filter output after the span, 1 integrator after the span, 2..4 phase deviation from the hold at samples
+// kSpanN1, kSpanN2, kSpan - 1.  v = (lpf, I, e1, e2, r0): the state the span starts from (e1 = newest error, radians) and
+// r0 = F0 (as rounded to float, like the reference's frequency word) - its unrounded value.
+static constexpr int kSpan = 128;
+static constexpr int kSpanN1 = 41, kSpanN2 = 84;
+static constexpr int kSpanRows = 5;
+struct PllSpanTab {
+    float w[kSpanRows][kSpan];       // weights of eh[n] (eh in TURNS: the 2 pi is folded in)
+    float s[kSpanRows][8];           // weights of (lpf, I, e1, e2, r0), padded
+    float minv[3][4];                // (alpha, beta, gamma) of dev(n) = alpha n + beta n^2 + gamma n^3 from the three deviation rows
+    float quad;                      // quadrature of the filtered pilot's real rail P: im[n] = quad (P[n-1] - P[n+1]) (Hilbert FIR gain at 19 kHz / (2 sin w0))
+    float kappa;                     // -19000 Ts + 19/128 with Ts = (float)(1 / 128000) as the reference's NCO has it: 7e-9 turns per sample, 9e-4 Hz
+    float pad[2];
+};
+// rows of the fast-mode planes carry the previous block's last samples in front (written by k_pll_span of that block), so the
+// consumers address history and block uniformly
+static constexpr int kFoPad = 160;   // fm_out: k_extract_mfma reaches back 124 + 32 samples, k_pll_span 33
+static constexpr int kImPad = 128;   // Hilbert rail: 124
+
 struct Dims {
     int C;          // channels
     int N;          // baseband samples per block
@@ -112,6 +137,11 @@ struct Buffers {
     float*  deemph;         // [C][4]  b0,b1,a0,flag
     float*  mix;            // [C][2]  audio mode (as float), stereo mix factor
     float*  state;          // [S_NUM_FIELDS][C]
+    // FMD_FLAG_FAST_MATH (round 3): planar analytic signal and the PLL's span polynomials
+    float*  fo_pl[kSlots];           // [C][kFoPad + n_fm_out]  fm_out (the analytic signal's real rail is this delayed by 32)
+    float*  im_pl[kSlots];           // [C][kImPad + n_fm_out]  Hilbert rail, aligned with the delayed real rail
+    float4* pll_poly[kSlots];        // [C][1 + n_fm_out / kSpan]  NCO phase of a span: c0 + c1 u + c2 u^2 + c3 u^3 - frac(19 (u + 1) / 128), u = sample in span
+    PllSpanTab* span_tab;
     PilotFastTab* pilot_tab;         // FMD_FLAG_FAST_MATH only
     uint4*  aud_img;                 // ... of k_extract_mfma's audio FIRs, one per distinct cut-off: [slot][k-step][hi/lo][lane]
     int2*   aud_idx;                 // [C] slots of a station's L+R and L-R images

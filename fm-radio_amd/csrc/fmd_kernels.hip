@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
 // =============================================================================================
 template <typename InT, int TT, int WU>
 __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
-                                                    float2* __restrict__ tail_out, float2* __restrict__ fm_out_iq,
-                                                    float* __restrict__ fm_out_plain, float* __restrict__ fo_tail_out, float fm_gain,
+                                                    float2* __restrict__ tail_out, float* __restrict__ fo_pl, float* __restrict__ im_pl,
+                                                    float* __restrict__ fo_tail_out, float fm_gain,
                                                     int deemph_path, const float* __restrict__ deemph, const uint4* __restrict__ tab) {
     using G = FrontGeomM<TT, WU>;
     constexpr int T = G::T, NW = G::NW, NF = G::NF;
@@ -350,10 +350,11 @@ __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restric
         if (col < G::NCOL) *reinterpret_cast<float4*>(fo + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
     __syncthreads();
+    float* fo_row = fo_pl + (size_t)c * (kFoPad + d.n_fm_out) + kFoPad + o0;   // the planes' rows start with the previous block's tail (k_pll_span)
     if constexpr (WU == 0) {
-        if (deemph_path) {   // a time constant beyond the in-tile form: hand fm_out to the k_deemphasis + k_hilbert stage
+        if (deemph_path) {   // a time constant beyond the in-tile form: hand fm_out to the k_deemphasis + k_hilbert_plane stage
             for (int uu = 64 + 4 * tid; uu < NF; uu += 1024)
-                *reinterpret_cast<float4*>(fm_out_plain + (size_t)c * d.n_fm_out + o0 + (uu - 64)) = *reinterpret_cast<const float4*>(fo + uu);
+                *reinterpret_cast<float4*>(fo_row + (uu - 64)) = *reinterpret_cast<const float4*>(fo + uu);
         }
     }
     if constexpr (WU > 0) {
@@ -416,11 +417,10 @@ __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restric
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahl[sK], bh, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahh[sK], bl, acc, 0, 0, 0);
             }
+            // planar: fm_out itself (the consumers delay it by 32 for the real rail) and the Hilbert rail
             const int oo = 16 * col + 4 * lq;
-            const float4 re = *reinterpret_cast<const float4*>(fo + WU + oo + 32);
-            float4* o = reinterpret_cast<float4*>(fm_out_iq + (size_t)c * d.n_fm_out + o0 + oo);
-            o[0] = make_float4(re.x, acc[0], re.y, acc[1]);
-            o[1] = make_float4(re.z, acc[2], re.w, acc[3]);
+            *reinterpret_cast<float4*>(fo_row + oo) = *reinterpret_cast<const float4*>(fo + WU + 64 + oo);
+            *reinterpret_cast<float4*>(im_pl + (size_t)c * (kImPad + d.n_fm_out) + kImPad + o0 + oo) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
     }
     if (tile == tiles - 1) {
@@ -1562,9 +1562,8 @@ struct ExtractGeomM {
     __device__ static __forceinline__ int pad(int i) { return i + 8 * (i >> 5); }
 };
 
-__global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float2* __restrict__ fm_out_iq, const float* __restrict__ pll_dt,
-                                                      const float2* __restrict__ iq_tail_in, const float* __restrict__ dt_tail_in,
-                                                      float2* __restrict__ iq_tail_out, float* __restrict__ dt_tail_out,
+__global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __restrict__ fo_pl, const float* __restrict__ im_pl,
+                                                      const float4* __restrict__ pll_poly,
                                                       const uint4* __restrict__ aud_img, const int2* __restrict__ aud_idx, const uint4* __restrict__ rds_img,
                                                       const float* __restrict__ b_lmr, const float* __restrict__ mixctl, float* __restrict__ state,
                                                       float* __restrict__ audio, float2* __restrict__ rds, float* __restrict__ lmr_est,
@@ -1587,8 +1586,11 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float2* __re
     const int lane = tid & (kWave - 1), wv = tid >> 6, lrow = lane & 15, lq = lane >> 4;
     const int s_lo = 4 * i0 - 124;               // first fm_out sample staged (block relative), even
     const int n = d.n_fm_out;
-    const float2* x_c = fm_out_iq + (size_t)c * n;
-    const float* dt_c = pll_dt + (size_t)c * n;
+    // the planes' rows carry the previous block's tail in front (k_pll_span): history and block are addressed alike.
+    // Analytic signal: re[s] = fm_out[s - 32], im[s] = the Hilbert rail; NCO phase: the span's cubic (PllSpanTab)
+    const float* fo_c = fo_pl + (size_t)c * (kFoPad + n) + kFoPad;
+    const float* im_c = im_pl + (size_t)c * (kImPad + n) + kImPad;
+    const float4* po_c = pll_poly + (size_t)c * (1 + n / kSpan) + 1;
     const float off_prev = st(state, field_prev, d.C, c);
     float off_cur = lmr_est_prev ? 0.0f : st(state, field_cur, d.C, c);
 
@@ -1596,7 +1598,7 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float2* __re
     {
         constexpr int NPAIR = (XSP + 4) / 2 + 0;           // pairs e = 0, 2, ... up to the zero padding of the RDS arrays (e - 4 < XSP)
         constexpr int PERP = (NPAIR + 255) / 256;
-        float4 xv[PERP]; float2 dv[PERP];
+        float4 xv[PERP]; float2 dv[PERP]; float4 pv[PERP];
         float ev[kLmrInlineMax / kWave];
         if (lmr_est_prev && tid < kWave) {
 #pragma unroll
@@ -1607,16 +1609,23 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float2* __re
         for (int r = 0; r < PERP; r++) {
             const int e = 2 * (tid + 256 * r);
             xv[r] = make_float4(0.f, 0.f, 0.f, 0.f); dv[r] = make_float2(0.f, 0.f);
+            pv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < XS) {
-                const int sx = s_lo + e;
-                if (sx < 0) {   // (tile 0 only) history: last block's samples
-                    xv[r] = *reinterpret_cast<const float4*>(iq_tail_in + (size_t)c * 128 + 128 + sx);
-                    dv[r] = *reinterpret_cast<const float2*>(dt_tail_in + (size_t)c * 128 + 128 + sx);
-                } else {
-                    xv[r] = *reinterpret_cast<const float4*>(x_c + sx);
-                    dv[r] = *reinterpret_cast<const float2*>(dt_c + sx);
-                }
+                const int sx = s_lo + e;                     // even, >= -124
+                const float2 re2 = *reinterpret_cast<const float2*>(fo_c + (sx - 32));
+                const float2 im2 = *reinterpret_cast<const float2*>(im_c + sx);
+                xv[r] = make_float4(re2.x, im2.x, re2.y, im2.y);
+                pv[r] = po_c[sx >> 7];                       // (span -1: the previous block's last)
             }
+        }
+        // NCO phases of the pairs: c0 + c1 u + c2 u^2 + c3 u^3 - frac(19 (u + 1) / 128), u = sample within its span (both samples of a pair share one)
+#pragma unroll
+        for (int r = 0; r < PERP; r++) {
+            const int u0 = (s_lo + 2 * (tid + 256 * r)) & (kSpan - 1);
+            const float ua = (float)u0, ub = (float)(u0 + 1);
+            const float fa_ = (float)((19 * (u0 + 1)) & 127) * (1.0f / 128.0f), fb_ = (float)((19 * (u0 + 2)) & 127) * (1.0f / 128.0f);
+            dv[r] = make_float2(fmaf(fmaf(fmaf(pv[r].w, ua, pv[r].z), ua, pv[r].y), ua, pv[r].x) - fa_,
+                                fmaf(fmaf(fmaf(pv[r].w, ub, pv[r].z), ub, pv[r].y), ub, pv[r].x) - fb_);
         }
         if (lmr_est_prev) {
             if (tid < kWave) {
@@ -1744,11 +1753,14 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float2* __re
             lmr_est[(size_t)c * d.n_est + (i0 + ii) / 10] = (ph > 0.0f) ? (half_pi - ph) : (-half_pi - ph);
         }
     }
-    // history for the next block: last 128 fm_out_iq / pll_dt samples
-    if (tile == tiles - 1 && tid < 128) {
-        iq_tail_out[(size_t)c * 128 + tid] = x_c[n - 128 + tid];
-        dt_tail_out[(size_t)c * 128 + tid] = dt_c[n - 128 + tid];
-    }
+}
+
+// Tolerance mode, FMD_FLAG_KEEP_TAPS (the "fm_out_iq" getter) and block lengths whose audio blocks are not multiples of 256 (those run
+// k_extract<128, true> on the interleaved stream, with the history tails it keeps for itself): the analytic signal assembled from the planes.
+__global__ __launch_bounds__(256) void k_planes_to_iq(Dims d, const float* __restrict__ fo_pl, const float* __restrict__ im_pl, float2* __restrict__ fm_out_iq) {
+    const int n = d.n_fm_out, tiles = n / 256, c = blockIdx.x / tiles;     // (n_fm_out is a multiple of 512)
+    const int s_ = (blockIdx.x % tiles) * 256 + threadIdx.x;
+    fm_out_iq[(size_t)c * n + s_] = make_float2(fo_pl[(size_t)c * (kFoPad + n) + kFoPad + s_ - 32], im_pl[(size_t)c * (kImPad + n) + kImPad + s_]);
 }
 
 // a11 — reference ExtractComponents :511-516: integrate the mean L-R phase error of the block (sequential sum in sample order).
@@ -2036,7 +2048,7 @@ __device__ __forceinline__ void chunk_store_f(const ChunkRegsF& r, float* lds) {
 // (lane per channel) and only STORES.  On gfx9 loads and stores share one in-order counter and complete out of order with
 // respect to each other, so a wave that has both in flight waits for "everything": with the chunk prefetch and the result
 // stores in one wave this kernel paid an HBM round trip per 32-sample chunk (4100 cycles per chunk for 770 cycles of work).
-__global__ __launch_bounds__(2 * kWave) void k_deemphasis(Dims d, float* __restrict__ fm_out, const float* __restrict__ deemph, float* __restrict__ state) {
+__global__ __launch_bounds__(2 * kWave) void k_deemphasis(Dims d, float* __restrict__ fm_out, const float* __restrict__ deemph, float* __restrict__ state, int stride) {
     constexpr int kRingSlots = 4;
     __shared__ __attribute__((aligned(16))) float ring[kRingSlots][kWave * kRowF];
     const bool loader = threadIdx.x >= kWave;              // wave-uniform
@@ -2048,19 +2060,19 @@ __global__ __launch_bounds__(2 * kWave) void k_deemphasis(Dims d, float* __restr
     // a workgroup none of whose channels filters has nothing to do (both waves see the same 64 channels)
     if (__builtin_amdgcn_ballot_w64(on && live) == 0ull) return;
     if (loader) {
-        ChunkRegsF ra = chunk_load_f(fm_out, n, c0, d.C, 0);
-        ChunkRegsF rb = chunk_load_f(fm_out, n, c0, d.C, kChunk);
+        ChunkRegsF ra = chunk_load_f(fm_out, stride, c0, d.C, 0);
+        ChunkRegsF rb = chunk_load_f(fm_out, stride, c0, d.C, kChunk);
         chunk_store_f(ra, ring[0]);
-        ra = chunk_load_f(fm_out, n, c0, d.C, (2 < chunks ? 2 : chunks - 1) * kChunk);
+        ra = chunk_load_f(fm_out, stride, c0, d.C, (2 < chunks ? 2 : chunks - 1) * kChunk);
         chunk_store_f(rb, ring[1]);
-        rb = chunk_load_f(fm_out, n, c0, d.C, (3 < chunks ? 3 : chunks - 1) * kChunk);
+        rb = chunk_load_f(fm_out, stride, c0, d.C, (3 < chunks ? 3 : chunks - 1) * kChunk);
         __syncthreads();                                   // chunks 0 and 1 are in the ring
         for (int ch = 0; ch < chunks; ch += 2) {           // while wave 0 filters chunk ch: chunk ch + 2 into its slot
             chunk_store_f(ra, ring[(ch + 2) & (kRingSlots - 1)]);
-            ra = chunk_load_f(fm_out, n, c0, d.C, (ch + 4 < chunks ? ch + 4 : chunks - 1) * kChunk);
+            ra = chunk_load_f(fm_out, stride, c0, d.C, (ch + 4 < chunks ? ch + 4 : chunks - 1) * kChunk);
             __syncthreads();
             chunk_store_f(rb, ring[(ch + 3) & (kRingSlots - 1)]);
-            rb = chunk_load_f(fm_out, n, c0, d.C, (ch + 5 < chunks ? ch + 5 : chunks - 1) * kChunk);
+            rb = chunk_load_f(fm_out, stride, c0, d.C, (ch + 5 < chunks ? ch + 5 : chunks - 1) * kChunk);
             __syncthreads();
         }
         return;
@@ -2093,19 +2105,21 @@ __global__ __launch_bounds__(2 * kWave) void k_deemphasis(Dims d, float* __restr
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        chunk_flush_f(buf, fm_out, n, c0, d.C, ch * kChunk);     // stores only: nothing in this wave ever waits for them
+        chunk_flush_f(buf, fm_out, stride, c0, d.C, ch * kChunk);     // stores only: nothing in this wave ever waits for them
         __syncthreads();
     }
     if (live && on) { st(state, S_DE_X1, d.C, c) = x1; st(state, S_DE_Y1, d.C, c) = y1; }
 }
 
+// PLANE (tolerance mode): fm_out lives in the padded rows of fo_pl and the output is the Hilbert plane im_pl
+template <bool PLANE>
 __global__ __launch_bounds__(256) void k_hilbert(Dims d, const float* __restrict__ fm_out, const float* __restrict__ fo_tail_in,
-                                                 float* __restrict__ fo_tail_out, float2* __restrict__ fm_out_iq, FrontTaps taps) {
+                                                 float* __restrict__ fo_tail_out, float2* __restrict__ fm_out_iq, float* __restrict__ im_pl, FrontTaps taps) {
     constexpr int T = 256;
     __shared__ float fo[T + 64];
     const int tiles = d.n_fm_out / T;
     const int c = blockIdx.x / tiles, tile = blockIdx.x % tiles, o0 = tile * T, tid = threadIdx.x;
-    const float* row = fm_out + (size_t)c * d.n_fm_out;
+    const float* row = PLANE ? fm_out + (size_t)c * (kFoPad + d.n_fm_out) + kFoPad : fm_out + (size_t)c * d.n_fm_out;
     for (int uu = tid; uu < T + 64; uu += 256) {
         const int u = o0 - 64 + uu;
         fo[uu] = (u < 0) ? fo_tail_in[(size_t)c * 64 + 64 + u] : row[u];
@@ -2121,7 +2135,8 @@ __global__ __launch_bounds__(256) void k_hilbert(Dims d, const float* __restrict
         l7 = fmaf(fo[oo + 7 + 8 * k], taps.b_hilbert_odd[4 * k + 3], l7);
     }
     const float im = (0.0f + ((l1 + l5) + (l3 + l7))) + 0.0f;
-    fm_out_iq[(size_t)c * d.n_fm_out + o0 + oo] = make_float2(fo[oo + 32], im);
+    if constexpr (PLANE) im_pl[(size_t)c * (kImPad + d.n_fm_out) + kImPad + o0 + oo] = im;
+    else fm_out_iq[(size_t)c * d.n_fm_out + o0 + oo] = make_float2(fo[oo + 32], im);
     if (tile == tiles - 1 && tid < 64) fo_tail_out[(size_t)c * 64 + tid] = row[d.n_fm_out - 64 + tid];
 }
 
@@ -2203,13 +2218,13 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
             auto kern = k_front_mfma<InT, TT, kDeemphWarmup>;
             using GM = FrontGeomM<TT, kDeemphWarmup>;
             FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
-                       ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fm_out_iq[r.buf], ctx.b.fm_out[r.buf], ctx.b.fo_tail[r.par ^ 1],
+                       ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.b.im_pl[r.buf], ctx.b.fo_tail[r.par ^ 1],
                        ctx.front.fm_gain, 0, ctx.b.deemph, ctx.b.front_mfma);
         } else {
             auto kern = k_front_mfma<InT, TT, 0>;
             using GM = FrontGeomM<TT, 0>;
             FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
-                       ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fm_out_iq[r.buf], ctx.b.fm_out[r.buf], ctx.b.fo_tail[r.par ^ 1],
+                       ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.b.im_pl[r.buf], ctx.b.fo_tail[r.par ^ 1],
                        ctx.front.fm_gain, ctx.any_deemph, ctx.b.deemph, ctx.b.front_mfma);
         }
         return hipGetLastError();
@@ -2257,9 +2272,15 @@ static unsigned serial_waves(const Dims& d) { return (unsigned)((d.C + kWave - 1
 hipError_t launch_stage_deemph(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
-    FMD_LAUNCH(r, true, false, k_deemphasis, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.fm_out[r.buf], b.deemph, b.state);
-    FMD_LAUNCH(r, false, true, k_hilbert, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, b.fm_out[r.buf], b.fo_tail[r.par],
-                       b.fo_tail[r.par ^ 1], b.fm_out_iq[r.buf], ctx.front);
+    if (ctx.fast) {   // the planes' rows: kFoPad samples of history in front of the block
+        FMD_LAUNCH(r, true, false, k_deemphasis, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.fo_pl[r.buf] + kFoPad, b.deemph, b.state, kFoPad + d.n_fm_out);
+        FMD_LAUNCH(r, false, true, k_hilbert<true>, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, b.fo_pl[r.buf], b.fo_tail[r.par],
+                   b.fo_tail[r.par ^ 1], (float2*)nullptr, b.im_pl[r.buf], ctx.front);
+        return hipGetLastError();
+    }
+    FMD_LAUNCH(r, true, false, k_deemphasis, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.fm_out[r.buf], b.deemph, b.state, d.n_fm_out);
+    FMD_LAUNCH(r, false, true, k_hilbert<false>, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, b.fm_out[r.buf], b.fo_tail[r.par],
+                       b.fo_tail[r.par ^ 1], b.fm_out_iq[r.buf], (float*)nullptr, ctx.front);
     return hipGetLastError();
 }
 
@@ -2278,8 +2299,12 @@ hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
 hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     if (ctx.fast) {
-        FMD_LAUNCH(r, true, true, k_pll_fast, dim3((unsigned)((d.C + 1) / 2)), dim3(2 * kWave), 0, s, d, ctx.b.fm_out_iq[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
-                   ctx.loops, ctx.b.pilot_tab, ctx.b.spec_stats, ctx.pll_hold_hz);
+        const int nxt = (r.buf + 1) % kSlots;
+        const bool iq = ctx.b.fm_out_iq[r.buf] != nullptr;    // FMD_FLAG_KEEP_TAPS, or audio blocks that are not multiples of 256: the interleaved streams too
+        FMD_LAUNCH(r, true, !iq, k_pll_span, dim3((unsigned)((d.C + 1) / 2)), dim3(kWave), 0, s, d, ctx.b.fo_pl[r.buf], ctx.b.fo_pl[nxt], ctx.b.im_pl[r.buf], ctx.b.im_pl[nxt],
+                   ctx.b.pll_poly[r.buf], ctx.b.pll_poly[nxt], iq ? ctx.b.pll_dt[r.buf] : (float*)nullptr, ctx.b.state, ctx.loops, ctx.b.pilot_tab, ctx.b.span_tab, ctx.b.spec_stats);
+        if (iq) FMD_LAUNCH(r, false, true, k_planes_to_iq, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, ctx.b.fo_pl[r.buf], ctx.b.im_pl[r.buf],
+                           ctx.b.fm_out_iq[r.buf]);
         return hipGetLastError();
     }
     if (d.C > ctx.pll_time_parallel_max_channels) {
@@ -2312,8 +2337,8 @@ static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
         if (ctx.fast) return launch_extract_ta<TA, true>(ctx, r, s);
     }
     if constexpr (FAST && TA == 256) {   // tolerance mode: the FIRs on the matrix cores
-        FMD_LAUNCH(r, true, true, k_extract_mfma, dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fm_out_iq[r.buf], b.pll_dt[r.buf],
-                   b.iq_tail[r.par], b.dt_tail[r.par], b.iq_tail[r.par ^ 1], b.dt_tail[r.par ^ 1], b.aud_img, b.aud_idx, b.rds_img, b.b_lmr, b.mix,
+        FMD_LAUNCH(r, true, true, k_extract_mfma, dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fo_pl[r.buf], b.im_pl[r.buf], b.pll_poly[r.buf],
+                   b.aud_img, b.aud_idx, b.rds_img, b.b_lmr, b.mix,
                    b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est[r.par], b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps,
                    lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr, lmr_field(r.par), lmr_field(r.par ^ 1));
         return;

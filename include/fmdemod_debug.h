@@ -37,6 +37,12 @@ int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t
  * kind 0: out = fast atan2(a, b); kind 1: out = sin(2 pi a) (hardware, argument in turns); kind 2: out = cos(2 pi a). */
 int fmd_selftest_fast_math(int kind, const float* a, const float* b, float* out, size_t n);
 
+/* Host-only (no GPU needed): the tables of the tolerance mode's span-wise pilot PLL (fm-radio_amd/csrc/fmd_kernels.h PllSpanTab) as
+ * the library designs them for fs_baseband — w [5][128] weights of the held-frequency error sequence (rows: loop filter, integrator,
+ * phase deviation at samples 41, 84, 127), s [5][8] weights of the state (lpf, I, e1, e2, r0), minv [3][4] cubic fit, misc[0] = the
+ * quadrature factor, misc[1] = kappa.  tests/test_span_design.py checks them against an independent float64 restatement. */
+int fmd_design_pll_span(int fs_baseband, float* w, float* s, float* minv, float* misc2);
+
 /* Counters of k_pilot_pll's frequency speculation since creation / the last reset (DESIGN.md "Pilot PLL"):
  * out8[0] = 128-sample chunks, summed over wavefronts (4 channels each); out8[1] = of those, chunks run with the plain serial
  * iteration (wavefront out of lock); out8[2] = spans redone with the reference forms (a short form outside its domain);

@@ -27,7 +27,7 @@ def test_library_exports_declared_abi(pkg):
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/fmdemod.h but not exported"
-    assert lib.fmd_api_version() == 2
+    assert lib.fmd_api_version() == 3
     assert lib.fmd_status_string(-4).decode().startswith("no gfx950")
     assert "fmd_reset" in lib.fmd_status_string(-6).decode()
 

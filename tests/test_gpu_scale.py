@@ -58,19 +58,21 @@ def _tiled_run(pkg, base, n_ch, bs, fs, nb, read_at, **demod_kw):
         if b in read_at:
             syms, cnt = dm.rds_symbols()
             by, bc = dm.rds_bytes()
-            got[b] = dict(audio=dm.audio(), pll_dt=dm.stream("pll_dt"), syms=syms, cnt=cnt, by=by, bc=bc)
+            # the PLL's result: the per-sample phase stream, or (tolerance mode, which does not materialise it) the span polynomials
+            got[b] = dict(audio=dm.audio(), pll_dt=dm.stream("pll_poly" if demod_kw.get("fast_math") else "pll_dt"), syms=syms, cnt=cnt, by=by, bc=bc)
     spec = dm.spec_stats()
     dm.close()
     return got, spec
 
 
-def _check_against_small(got, small, n_base, n_ch, bs_audio, n_fm_out):
+def _check_against_small(got, small, n_base, n_ch, bs_audio, n_fm_out, pll="pll_dt"):
     """small: run_gpu() result of the n_base base captures (every block concatenated)."""
     idx = np.arange(n_ch) % n_base
     for b, g in got.items():
         want_audio = small["audio"][:, b * 2 * bs_audio:(b + 1) * 2 * bs_audio].reshape(n_base, bs_audio, 2)
         assert np.array_equal(g["audio"].view(np.uint32), want_audio[idx].view(np.uint32)), f"audio, block {b}"
-        want_dt = small["pll_dt"][:, b * n_fm_out:(b + 1) * n_fm_out]
+        w = n_fm_out if pll == "pll_dt" else 4 * (1 + n_fm_out // 128)
+        want_dt = small[pll][:, b * w:(b + 1) * w]
         assert np.array_equal(g["pll_dt"].view(np.uint32), want_dt[idx].view(np.uint32)), f"pll_dt, block {b}"
         want_cnt = small["rds_count"][:, b]
         assert np.array_equal(g["cnt"], want_cnt[idx]), f"rds symbol counts, block {b}"
@@ -108,18 +110,16 @@ def test_tolerance_mode_bench_path_in_lock_against_oracle_verified_tiles(pkg, fs
     base = _caps(8, nb * bs, float(fs), seed=4200 + (1 if u8 else 0), u8=u8)
     small = run_gpu(pkg, base, bs, fs, fast_math=True)
     for c in range(8):
-        o = O.run_chain(base[c], bs, fs, u8=u8, coeffs=lib_coeffs_to_oracle(small["coeffs"][c]), streams=["fm_out_iq", "lpr", "lmr", "audio", "rds_sym"])
+        o = O.run_chain(base[c], bs, fs, u8=u8, coeffs=lib_coeffs_to_oracle(small["coeffs"][c]), streams=["fm_out_iq", "lpr", "lmr", "audio", "rds_sym", "lmr_phase"])
         for k in ("fm_out_iq", "lpr"):
             assert F.rms(np.asarray(small[k][c], np.float64).reshape(-1) - o[k].reshape(-1)) <= F.TOL_RMS, (c, k)
-        for k in ("lmr", "audio"):   # per block: a flipped L-R phase estimate may rotate a block's L-R by up to 1e-3
-            d = (np.asarray(small[k][c], np.float64).reshape(nb, -1) - o[k].reshape(nb, -1)) ** 2
-            per_block = np.sqrt(d.mean(axis=1))
-            assert per_block.max() <= (2e-3 if k == "audio" else 1e-3) and np.sum(per_block > F.TOL_RMS) <= 2, (c, k, per_block)
+        ex, _, _, _ = F.lmr_audio_excess(small, o, c, nb)      # L-R and audio: every block within 1e-4 (the helper documents the one allowance)
+        assert ex <= 1.0, (c, ex)
         assert F.same_bits_once_in_lock(small["rds_bytes"][c], o["rds_bytes"], skip_bits=5 * 76), c
     got, spec = _tiled_run(pkg, base, n_ch, bs, fs, nb, read_at={4, 9, 11, 13}, fast_math=True)
     n_fm_out = bs // (fs // 256_000) // 2
-    _check_against_small(got, small, 8, n_ch, n_fm_out // 4, n_fm_out)
-    assert spec["pll"]["samples_per_span"] == 64.0
+    _check_against_small(got, small, 8, n_ch, n_fm_out // 4, n_fm_out, pll="pll_poly")
+    assert spec["pll"]["samples_per_span"] == 128.0
 
 
 def test_low_work_pll_kernel_pipelined_without_host_sync(pkg):
