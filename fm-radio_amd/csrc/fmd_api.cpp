@@ -679,6 +679,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
         if (!rc && fast) rc = dev_alloc(h, &b.fo_pl[p], C * ((size_t)kFoPad + d.n_fm_out));
         if (!rc && fast) rc = dev_alloc(h, &b.im_pl[p], C * ((size_t)kImPad + d.n_fm_out));
         if (!rc && fast) rc = dev_alloc(h, &b.pll_poly[p], C * ((size_t)1 + d.n_fm_out / kSpan));
+        if (!rc && fast) rc = dev_alloc(h, &b.rds_pow[p], C * (size_t)(2 * (d.n_audio / 256) + 2));
         if (!rc) rc = dev_alloc(h, &b.audio[p], C * d.n_audio * 2);
         if (!rc) rc = dev_alloc(h, &b.rds_sym[p], C * d.n_rds);
         if (!rc) rc = dev_alloc(h, &b.rds_raw_sym[p], h->ctx.keep_taps ? C * d.n_rds : 4);

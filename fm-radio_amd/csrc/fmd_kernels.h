@@ -141,6 +141,7 @@ struct Buffers {
     float*  fo_pl[kSlots];           // [C][kFoPad + n_fm_out]  fm_out (the analytic signal's real rail is this delayed by 32)
     float*  im_pl[kSlots];           // [C][kImPad + n_fm_out]  Hilbert rail, aligned with the delayed real rail
     float4* pll_poly[kSlots];        // [C][1 + n_fm_out / kSpan]  NCO phase of a span: c0 + c1 u + c2 u^2 + c3 u^3 - frac(19 (u + 1) / 128), u = sample in span
+    float*  rds_pow[kSlots];         // [C][2 n_audio / 256]  partial sums of |rds|^2 (k_extract_mfma -> k_rds_sync's AGC)
     PllSpanTab* span_tab;
     PilotFastTab* pilot_tab;         // FMD_FLAG_FAST_MATH only
     uint4*  aud_img;                 // ... of k_extract_mfma's audio FIRs, one per distinct cut-off: [slot][k-step][hi/lo][lane]

@@ -337,16 +337,18 @@ __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restric
     // a3: decimate-by-2 FIR: wavefront w takes the 16-column tiles w, w + 4, ... (a column = 16 consecutive outputs)
     for (int ct = wv; ct * 16 < G::NCOL; ct += 4) {
         const int col = ct * 16 + lrow, colr = col < G::NCOL ? col : G::NCOL - 1;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // (round 3, PMC: a wavefront of this kernel spent 37 % of its cycles waiting for the previous MFMA of one nine-long chain)
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
 #pragma unroll
         for (int sK = 0; sK < 3; sK++) {
             const int e = 32 * colr + 32 * sK + 8 * lq;              // bf16 element index, a multiple of 8
             const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(dem_hi32 + e / 2));
             const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(dem_lo32 + e / 2));
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adl[sK], bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bl, acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adl[sK], bh, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bl, acc2, 0, 0, 0);
         }
+        acc = acc + (acc1 + acc2);
         if (col < G::NCOL) *reinterpret_cast<float4*>(fo + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
     __syncthreads();
@@ -407,16 +409,17 @@ __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restric
         }
         for (int ct = wv; ct * 256 < T; ct += 4) {
             const int col = ct * 16 + lrow;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
 #pragma unroll
             for (int sK = 0; sK < 3; sK++) {
                 const int e = WU + 16 * col + 32 * sK + 8 * lq;
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fo_hi32 + e / 2));
                 const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fo_lo32 + e / 2));
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahh[sK], bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahl[sK], bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahh[sK], bl, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahl[sK], bh, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahh[sK], bl, acc2, 0, 0, 0);
             }
+            acc = acc + (acc1 + acc2);
             // planar: fm_out itself (the consumers delay it by 32 for the real rail) and the Hilbert rail
             const int oo = 16 * col + 4 * lq;
             *reinterpret_cast<float4*>(fo_row + oo) = *reinterpret_cast<const float4*>(fo + WU + 64 + oo);
@@ -1568,7 +1571,7 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
                                                       const float* __restrict__ b_lmr, const float* __restrict__ mixctl, float* __restrict__ state,
                                                       float* __restrict__ audio, float2* __restrict__ rds, float* __restrict__ lmr_est,
                                                       float* __restrict__ lpr_out, float* __restrict__ lmr_out, int keep_taps,
-                                                      const float* __restrict__ lmr_est_prev, int field_cur, int field_prev) {
+                                                      const float* __restrict__ lmr_est_prev, int field_cur, int field_prev, float* __restrict__ rds_pow) {
     using G = ExtractGeomM;
     constexpr int TA = G::TA, XS = G::XS, XSP = G::XSP, NBW = G::NB / 2;
     __shared__ __attribute__((aligned(16))) uint32_t lpr_h[NBW], lpr_l[NBW], lmr_h[NBW], lmr_l[NBW];   // Re fm_out_iq; imaginary rail of the x2-mixed signal
@@ -1685,7 +1688,7 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
         const uint4* img = aud_img + (size_t)(wv ? slot.y : slot.x) * (6 * 2 * kWave);
         const uint32_t* sh = wv ? lmr_h : lpr_h;
         const uint32_t* sl = wv ? lmr_l : lpr_l;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
 #pragma unroll
         for (int sK = 0; sK < 6; sK++) {
             const bf16x8 ah = __builtin_bit_cast(bf16x8, img[(sK * 2 + 0) * kWave + lane]);
@@ -1694,16 +1697,17 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
             const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sh + w4));
             const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sl + w4));
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc2, 0, 0, 0);
         }
+        acc = acc + (acc1 + acc2);
         *reinterpret_cast<float4*>((wv ? res_lmr : res_lpr) + 16 * lrow + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     } else if (wv == 2) {
         // RDS: columns 0-7 the real rail's 128 outputs, 8-15 the imaginary rail's
         const int rail = lrow >> 3, colr = lrow & 7;
         const uint32_t* sh = rail ? rim_h : rre_h;
         const uint32_t* sl = rail ? rim_l : rre_l;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
 #pragma unroll
         for (int sK = 0; sK < 8; sK++) {
             const bf16x8 ah = __builtin_bit_cast(bf16x8, rds_img[(sK * 2 + 0) * kWave + lane]);
@@ -1712,9 +1716,10 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
             const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sh + w8));
             const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sl + w8));
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc2, 0, 0, 0);
         }
+        acc = acc + (acc1 + acc2);
 #pragma unroll
         for (int i = 0; i < 4; i++) res_rds[2 * (16 * colr + 4 * lq + i) + rail] = acc[i];
     } else {
@@ -1744,7 +1749,14 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
         else { l = lpr; r = lpr; }
         reinterpret_cast<float2*>(audio)[(size_t)c * d.n_audio + i] = make_float2(l + l, r + r);
         if (keep_taps) { lpr_out[(size_t)c * d.n_audio + i] = lpr; lmr_out[(size_t)c * d.n_audio + i] = lmr; }
-        if (tid < TA / 2) rds[(size_t)c * d.n_rds + i0 / 2 + tid] = make_float2(res_rds[2 * tid], res_rds[2 * tid + 1]);
+        if (tid < TA / 2) {
+            const float rr = res_rds[2 * tid], ri = res_rds[2 * tid + 1];
+            rds[(size_t)c * d.n_rds + i0 / 2 + tid] = make_float2(rr, ri);
+            // a13: the RDS AGC's block power (reference AGC_Filter::calculate_average_power, agc.h:21-30), summed here per half tile
+            // instead of in a pass of its own over the block in k_rds_sync (the lone wavefront's latency there sets small batches' step)
+            const float pw = wave_sum_f32(fmaf(rr, rr, ri * ri));
+            if (lane == 0) rds_pow[((size_t)c * tiles + tile) * 2 + wv] = pw;
+        }
         // reference :500-510: estimate against the +-pi/2 constellation, every 10th output of the block
         const int ii = est_first + 10 * tid;
         if (ii < TA) {
@@ -1823,16 +1835,19 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
                                                         float* __restrict__ state, LoopCoeffs k, float* __restrict__ rds_sym,
                                                         float2* __restrict__ rds_raw_sym, int* __restrict__ rds_count,
                                                         uint8_t* __restrict__ rds_bytes, int* __restrict__ rds_bytes_count,
-                                                        int bytes_cap, int keep_taps) {
+                                                        int bytes_cap, int keep_taps, const float* __restrict__ rds_pow, int n_pow) {
     constexpr int kRingSlots = 4;
-    constexpr int kSignWords = 33;                                       // up to 1024 symbols per block and lane (+1: odd stride, no bank conflicts)
+    constexpr int kSignWords = 33;                                       // 1024 symbols per lane between two runs of the decoder (+1: odd stride, no bank conflicts)
     __shared__ __attribute__((aligned(16))) float2 ring[kRingSlots][kWave * kRowC];
     __shared__ unsigned sign_bits[kWave * kSignWords];
     const bool loader = threadIdx.x >= kWave;                            // wave-uniform
     const int lane = threadIdx.x & (kWave - 1), c0 = blockIdx.x * kWave, c = c0 + lane;
     const bool live = c < d.C;
     const int cs = live ? c : d.C - 1;
-    const int n = d.n_rds, chunks = n / kChunk, steps = 2 * chunks;      // step i handles chunk i mod chunks
+    // rds_pow (tolerance mode with k_extract_mfma): the block's power arrives as n_pow partial sums per station and the block is
+    // walked once; otherwise twice (power pass, then the synchroniser pass)
+    const bool one_pass = FAST && rds_pow != nullptr;
+    const int n = d.n_rds, chunks = n / kChunk, steps = one_pass ? chunks : 2 * chunks;      // step i handles chunk i mod chunks
     if (loader) {
         auto at = [&](int i) { return (i < steps ? i % chunks : chunks - 1) * kChunk; };
         ChunkRegsC ra = chunk_load_c(rds, n, c0, d.C, at(0));
@@ -1857,14 +1872,18 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
     // a13: AGC power pass (reference AGC_Filter::calculate_average_power, agc.h:21-30)
     float power = 0.0f;
     int step = 0;
-    for (; step < chunks; step++) {
-        const float2* buf = ring[step & (kRingSlots - 1)];
+    if (one_pass) {
+        for (int i = 0; i < n_pow; i++) power += rds_pow[(size_t)cs * n_pow + i];
+    } else {
+        for (; step < chunks; step++) {
+            const float2* buf = ring[step & (kRingSlots - 1)];
 #pragma unroll 8
-        for (int t = 0; t < kChunk; t++) {
-            const float2 x = buf[lane * kRowC + t];
-            power = power + fmaf(x.x, x.x, x.y * x.y);
+            for (int t = 0; t < kChunk; t++) {
+                const float2 x = buf[lane * kRowC + t];
+                power = power + fmaf(x.x, x.x, x.y * x.y);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     float gain = st(state, S_AGC_RDS_GAIN, d.C, cs);
     {
@@ -1882,13 +1901,59 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
     float dump_r = st(state, S_B_DUMP_R, d.C, cs), dump_i = st(state, S_B_DUMP_I, d.C, cs);
     int n_sym = 0;
     unsigned sign_word = 0u;
+    // differential Manchester (reference rds_decoder/differential_manchester_decoder.h:32-60): every second symbol,
+    // bit = sign(cur) xor sign(prev), MSB first, bytes handed on in buffers of 16.
+    // state: flags = is_read_bit | prev_bit<<1 | bit_index<<2 | byte_index<<5
+    unsigned mflags = __float_as_uint(st(state, S_M_FLAGS, d.C, cs));
+    unsigned mbuf[4] = {__float_as_uint(st(state, S_M_BUF0, d.C, cs)), __float_as_uint(st(state, S_M_BUF1, d.C, cs)),
+                        __float_as_uint(st(state, S_M_BUF2, d.C, cs)), __float_as_uint(st(state, S_M_BUF3, d.C, cs))};
+    int n_bytes = 0;
+    int wsym = 0;                                        // symbols in the sign buffer (it holds 32 (kSignWords - 1) per lane)
+    // the decoder over the buffered signs, then the buffer starts over: behind the sample loop, and inside it whenever a lane's row
+    // is nearly full (blocks of more than ~4800 RDS samples; the symbol clock tops out at 3500 Hz of 16 kHz)
+    auto decode_buffered = [&]() __attribute__((always_inline)) {
+        sign_bits[lane * kSignWords + (wsym >> 5)] = sign_word;            // the last, partial word
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        int max_sym = wsym;
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) { const int o = __shfl_xor(max_sym, dd, kWave); max_sym = o > max_sym ? o : max_sym; }
+        for (int i = 0; i < max_sym; i++) {
+            if (i < wsym) {
+                const unsigned cur = (sign_bits[lane * kSignWords + (i >> 5)] >> (i & 31)) & 1u;
+                mflags ^= 1u;
+                if (mflags & 1u) {
+                    const unsigned bit = cur ^ ((mflags >> 1) & 1u);
+                    mflags = (mflags & ~2u) | (cur << 1);
+                    unsigned bit_index = (mflags >> 2) & 7u, byte_index = (mflags >> 5) & 31u;
+                    const unsigned word = byte_index >> 2, shift = (byte_index & 3u) * 8u;
+                    if (bit_index == 0u) mbuf[word] &= ~(0xffu << shift);
+                    mbuf[word] |= (bit << (7u - bit_index)) << shift;
+                    bit_index++;
+                    byte_index += bit_index >> 3;
+                    bit_index &= 7u;
+                    if (byte_index == 16u) {
+                        byte_index = 0u;
+                        if (live && n_bytes + 16 <= bytes_cap) {
+                            uint32_t* o = reinterpret_cast<uint32_t*>(rds_bytes + (size_t)c * bytes_cap + n_bytes);
+                            o[0] = mbuf[0]; o[1] = mbuf[1]; o[2] = mbuf[2]; o[3] = mbuf[3];
+                        }
+                        n_bytes += 16;
+                    }
+                    mflags = (mflags & 3u) | (bit_index << 2) | (byte_index << 5);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        wsym = 0; sign_word = 0u;
+    };
 
     const float Ts = 1.0f / 16e3f;
     const float KTs_pi = (10.0f * Ts) * (2e3f / 16e3f);
     const float half_pi = bits_f32(kHalfPiBits), two_over_pi = bits_f32(kTwoOverPiBits);
 
     for (; step < steps; step++) {
-        const int ch = step - chunks;
+        const int ch = one_pass ? step : step - chunks;
         float2* buf = ring[step & (kRingSlots - 1)];
         for (int t = 0; t < kChunk; t++) {
             const float2 xr = buf[lane * kRowC + t];
@@ -1951,11 +2016,13 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
                     if (keep_taps) rds_raw_sym[(size_t)c * n + n_sym] = make_float2(sr, si);
                 }
                 // the symbol's sign for the Manchester decoder behind the loop
-                sign_word |= ((si > 0.0f) ? 1u : 0u) << (n_sym & 31);
-                if ((n_sym & 31) == 31) { sign_bits[lane * kSignWords + (n_sym >> 5)] = sign_word; sign_word = 0u; }
-                n_sym++;
+                sign_word |= ((si > 0.0f) ? 1u : 0u) << (wsym & 31);
+                if ((wsym & 31) == 31) { sign_bits[lane * kSignWords + (wsym >> 5)] = sign_word; sign_word = 0u; }
+                n_sym++; wsym++;
             }
         }
+        // a chunk adds at most kChunk / 4 symbols to a lane's row (3500 Hz of 16 kHz is fewer): decode before any row can overflow
+        if (__builtin_amdgcn_ballot_w64(wsym > 32 * (kSignWords - 1) - kChunk) != 0ull) decode_buffered();
         if (keep_taps) {
             // write the post-AGC RDS signal back (reference GetRDSOutput)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1964,46 +2031,7 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
         }
         __syncthreads();
     }
-    sign_bits[lane * kSignWords + (n_sym >> 5)] = sign_word;            // the last, partial word
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-
-    // differential Manchester (reference rds_decoder/differential_manchester_decoder.h:32-60): every second symbol,
-    // bit = sign(cur) xor sign(prev), MSB first, bytes handed on in buffers of 16.
-    // state: flags = is_read_bit | prev_bit<<1 | bit_index<<2 | byte_index<<5
-    unsigned mflags = __float_as_uint(st(state, S_M_FLAGS, d.C, cs));
-    unsigned mbuf[4] = {__float_as_uint(st(state, S_M_BUF0, d.C, cs)), __float_as_uint(st(state, S_M_BUF1, d.C, cs)),
-                        __float_as_uint(st(state, S_M_BUF2, d.C, cs)), __float_as_uint(st(state, S_M_BUF3, d.C, cs))};
-    int n_bytes = 0;
-    int max_sym = n_sym;
-#pragma unroll
-    for (int dd = 32; dd >= 1; dd >>= 1) { const int o = __shfl_xor(max_sym, dd, kWave); max_sym = o > max_sym ? o : max_sym; }
-    for (int i = 0; i < max_sym; i++) {
-        if (i < n_sym) {
-            const unsigned cur = (sign_bits[lane * kSignWords + (i >> 5)] >> (i & 31)) & 1u;
-            mflags ^= 1u;
-            if (mflags & 1u) {
-                const unsigned bit = cur ^ ((mflags >> 1) & 1u);
-                mflags = (mflags & ~2u) | (cur << 1);
-                unsigned bit_index = (mflags >> 2) & 7u, byte_index = (mflags >> 5) & 31u;
-                const unsigned word = byte_index >> 2, shift = (byte_index & 3u) * 8u;
-                if (bit_index == 0u) mbuf[word] &= ~(0xffu << shift);
-                mbuf[word] |= (bit << (7u - bit_index)) << shift;
-                bit_index++;
-                byte_index += bit_index >> 3;
-                bit_index &= 7u;
-                if (byte_index == 16u) {
-                    byte_index = 0u;
-                    if (live && n_bytes + 16 <= bytes_cap) {
-                        uint32_t* o = reinterpret_cast<uint32_t*>(rds_bytes + (size_t)c * bytes_cap + n_bytes);
-                        o[0] = mbuf[0]; o[1] = mbuf[1]; o[2] = mbuf[2]; o[3] = mbuf[3];
-                    }
-                    n_bytes += 16;
-                }
-                mflags = (mflags & 3u) | (bit_index << 2) | (byte_index << 5);
-            }
-        }
-    }
+    decode_buffered();
     if (live) {
         st(state, S_AGC_RDS_GAIN, d.C, c) = gain;
         st(state, S_B_PLL_X1, d.C, c) = pll_x1; st(state, S_B_PLL_Y1, d.C, c) = pll_y1; st(state, S_B_PLL_INT, d.C, c) = pll_int;
@@ -2340,7 +2368,7 @@ static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
         FMD_LAUNCH(r, true, true, k_extract_mfma, dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fo_pl[r.buf], b.im_pl[r.buf], b.pll_poly[r.buf],
                    b.aud_img, b.aud_idx, b.rds_img, b.b_lmr, b.mix,
                    b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est[r.par], b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps,
-                   lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr, lmr_field(r.par), lmr_field(r.par ^ 1));
+                   lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr, lmr_field(r.par), lmr_field(r.par ^ 1), b.rds_pow[r.buf]);
         return;
     }
     FMD_LAUNCH(r, true, true, (k_extract<TA, FAST>), dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fm_out_iq[r.buf], b.pll_dt[r.buf],
@@ -2376,11 +2404,13 @@ hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
     if (ctx.fast) {
+        const bool partials = d.n_audio % 256 == 0;       // k_extract_mfma ran and left the block's power as 2 partial sums per tile
         FMD_LAUNCH(r, true, true, k_rds_sync<true>, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
-                   b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps);
+                   b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps,
+                   partials ? b.rds_pow[r.buf] : (const float*)nullptr, 2 * (d.n_audio / 256));
     } else {
         FMD_LAUNCH(r, true, true, k_rds_sync<false>, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
-                   b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps);
+                   b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps, (const float*)nullptr, 0);
     }
     return hipGetLastError();
 }

@@ -302,8 +302,9 @@ def test_fast_mode_with_detuned_noisy_and_missing_pilots(pkg):
     """Stations the pilot PLL cannot hold (pilot 130 Hz off, 30 Hz outside the loop's range: saturated control and integrator;
     weak pilot under heavy noise; no pilot at all), next to a normal one.  The weak pilot is tracked within the audio tolerance.
     A loop 30 Hz out of range never locks: its phase error sweeps through 2 pi thirty times a second and the trajectory is that of
-    a driven nonlinear oscillator, on which last-bits differences grow (1e-5 ... 2e-4 RMS on audio depending on where the spans
-    happen to end; the stereo image of such a station is meaningless in the reference too) - bounded at 5e-4 here.  The
+    a driven nonlinear oscillator, on which differences grow; the control enters and leaves its rail twice per beat and the span in which
+    it does is evaluated with the linear model (fmd_kernels_fast.inc k_pll_span): ~1e-3 turns of NCO phase, 2e-3 RMS on audio, after
+    0.6 s; the stereo image of such a station is meaningless in the reference too - bounded at 3e-3 here.  The
     pilot-less station's L-R is demodulated noise, compared on L+R only."""
     n = 10 * 16384
     caps = np.stack([
@@ -323,8 +324,8 @@ def test_fast_mode_with_detuned_noisy_and_missing_pilots(pkg):
         dlt = g["pll_dt"][c].astype(np.float64) - o["pll_dt"]
         dlt -= np.round(dlt)
         print(f"channel {c}: audio rms err {e_audio:.2e}, pll phase rms err {rms(dlt):.2e} turns")
-        if c in (1, 3):
-            assert e_audio <= 5e-4, (c, e_audio)
+        if c in (1, 3):   # (an unlocked loop has no restoring force: what a span's approximation leaves in the NCO phase stays there)
+            assert e_audio <= 3e-3, (c, e_audio)
         elif c < 4:
             assert lmr_audio_excess(g, o, c, 10)[0] <= 1.0, (c, e_audio)
 

@@ -299,6 +299,25 @@ def test_pll_speculation_commits_long_spans_in_lock_and_short_ones_before(pkg):
     assert sum(p["serial_chunks"] for p in locked) == 0
 
 
+def test_blocks_with_more_symbols_than_the_sign_buffer_holds(pkg):
+    """k_rds_sync buffers the symbols' signs for the Manchester decoder in LDS, 1024 per station; a block of
+    131072 samples at 256 kSa/s (8192 RDS samples, ~1200 symbols; ~1790 at the symbol clock's upper rail) overflows one buffer, so the
+    decoder runs whenever a row is nearly full.  Symbols, counts and bytes bit-identical to the oracle, both ingest paths; and the
+    tolerance mode (single-pass synchroniser) carries the same bits."""
+    bs, fs = 131072, 256_000
+    caps = _caps(3, 3 * bs, fs=float(fs), seed=8800)
+    rep = compare_with_oracle(pkg, caps, bs, fs)
+    _assert_exact(rep)
+    g = run_gpu(pkg, caps[:1], bs, fs)
+    assert int(g["rds_count"][0].max()) > 1055            # the case: more symbols in a block than one buffer row holds
+    import test_gpu_fast as F
+    import oraclelib as O
+    f = run_gpu(pkg, caps, bs, fs, fast_math=True)
+    for c in range(3):
+        o = O.run_chain(caps[c], bs, fs, u8=False, coeffs=lib_coeffs_to_oracle(f["coeffs"][c]), streams=["rds_sym"])
+        assert F.same_bits_once_in_lock(f["rds_bytes"][c], o["rds_bytes"], skip_bits=5 * 76), c
+
+
 def test_pcm16_audio_frames_match_the_scraper_conversion(pkg):
     """fmd_audio_pcm16_dev (the multi-GPU gather's payload): the reference scraper's float -> int16 conversion of the audio
     block (fm_scraper.cpp:79-82: sample * (32767 * 0.95f), truncated toward zero), on the device, behind the block's outputs."""
