@@ -798,6 +798,12 @@ int fmd_get_rates(fmd_handle h, fmd_rates* r) {
     return FMD_OK;
 }
 
+int fmd_get_config(fmd_handle h, fmd_config* cfg) {
+    if (!h || !cfg) return FMD_ERR_ARG;
+    *cfg = h->cfg;
+    return FMD_OK;
+}
+
 int fmd_get_coeffs(fmd_handle h, int channel, fmd_coeffs* k) {
     if (!h || !k) return FMD_ERR_ARG;
     if (channel >= h->cfg.n_channels) return fail(h, FMD_ERR_ARG, "channel %d out of range", channel);

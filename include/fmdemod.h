@@ -128,6 +128,8 @@ int fmd_reset(fmd_handle h);
 int fmd_set_controls(fmd_handle h, int channel, const fmd_controls* c);
 int fmd_get_controls(fmd_handle h, int channel, fmd_controls* c);
 int fmd_get_rates(fmd_handle h, fmd_rates* r);
+/* the configuration the handle was created with (device resolved to the ordinal in use) */
+int fmd_get_config(fmd_handle h, fmd_config* cfg);
 int fmd_get_coeffs(fmd_handle h, int channel, fmd_coeffs* k);
 
 /* Broadcast_FM_Demod::Process (broadcast_fm_demod.cpp:309-328) for all channels.

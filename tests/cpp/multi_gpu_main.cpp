@@ -1,0 +1,128 @@
+// Test driver of fm-radio_amd/host/multi_gpu_host.hpp + libfmdgather.so (include/fmdemod_gather.h).
+//
+//   multi_gpu_main <captures.u8> <n_ranks> <stations_per_rank> <block_size> <fs> <n_blocks> <f32|pcm16> <loopback 0|1> [fast]
+//       captures.u8 holds [n_ranks * stations_per_rank][n_blocks * block_size][2] u8; rank r gets device r when the box has that
+//       many GPUs, otherwise every rank shares device 0 (copy hand-over; with loopback = 1 and one rank the shard travels through
+//       ncclSend / ncclRecv to the self peer).
+//   Pass 1, lock-step: after every block the gathered audio / RDS bytes / counts on the collector must equal what every rank's own
+//   fmd_get_audio / fmd_get_rds_bytes return (PCM16: the reference scraper's conversion of it, fm_scraper.cpp:79-82).
+//   Pass 2, fresh handles, two blocks in flight ahead of the collector: the gathered blocks must equal pass 1's bit for bit.
+//   Prints one JSON line; exit code 0 only if everything matched.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "multi_gpu_host.hpp"
+
+using fmd_host::MultiGpuHost;
+
+#define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 5; } } while (0)
+
+struct Block { std::vector<char> audio; std::vector<uint8_t> bytes; std::vector<int> counts; };
+
+int main(int argc, char** argv) {
+    if (argc < 9) { fprintf(stderr, "usage: multi_gpu_main <captures.u8> <n_ranks> <stations_per_rank> <block> <fs> <n_blocks> <f32|pcm16> <loopback> [fast]\n"); return 1; }
+    const std::string path = argv[1];
+    const int R = atoi(argv[2]), C = atoi(argv[3]), N = atoi(argv[4]), fs = atoi(argv[5]), nb = atoi(argv[6]);
+    const bool pcm = std::string(argv[7]) == "pcm16", loopback = atoi(argv[8]) != 0, fast = argc > 9 && std::string(argv[9]) == "fast";
+    FILE* fp = fopen(path.c_str(), "rb");
+    if (!fp) return 2;
+    std::vector<uint8_t> data((size_t)R * C * nb * N * 2);
+    if (fread(data.data(), 1, data.size(), fp) != data.size()) return 2;
+    fclose(fp);
+    int ndev = 0;
+    HIPC(hipGetDeviceCount(&ndev));
+    std::vector<int> devs((size_t)R);
+    for (int r = 0; r < R; r++) devs[(size_t)r] = ndev >= R ? r : 0;
+    try {
+        // every rank's blocks on its device: [nb][C][N][2]
+        std::vector<std::vector<uint8_t*>> d_in((size_t)R, std::vector<uint8_t*>((size_t)nb, nullptr));
+        const size_t blk = (size_t)C * N * 2;
+        std::vector<uint8_t> tmp(blk);
+        for (int r = 0; r < R; r++) {
+            HIPC(hipSetDevice(devs[(size_t)r]));
+            for (int b = 0; b < nb; b++) {
+                for (int c = 0; c < C; c++)
+                    std::memcpy(tmp.data() + (size_t)c * N * 2, data.data() + (((size_t)(r * C + c) * nb + b) * N) * 2, (size_t)N * 2);
+                HIPC(hipMalloc(reinterpret_cast<void**>(&d_in[(size_t)r][(size_t)b]), blk));
+                HIPC(hipMemcpy(d_in[(size_t)r][(size_t)b], tmp.data(), blk, hipMemcpyHostToDevice));
+            }
+        }
+        const unsigned dflags = fast ? FMD_FLAG_FAST_MATH : 0u, gflags = loopback ? FMD_GATHER_LOOPBACK_RCCL : 0u;
+        const int fmt = pcm ? FMD_GATHER_PCM16 : FMD_GATHER_F32;
+        long mismatches = 0;
+        std::vector<Block> pass1((size_t)nb);
+        size_t remote = 0;
+        int n_audio = 0, cap = 0;
+        auto fetch = [&](const MultiGpuHost::Views& v, Block& out, int n_audio_, int root_dev) -> int {
+            const size_t ab = (size_t)R * C * n_audio_ * 2 * (pcm ? 2 : 4);
+            out.audio.resize(ab); out.bytes.resize((size_t)R * C * v.rds_cap); out.counts.resize((size_t)R * C);
+            HIPC(hipSetDevice(root_dev));
+            HIPC(hipMemcpy(out.audio.data(), v.audio, ab, hipMemcpyDeviceToHost));
+            HIPC(hipMemcpy(out.bytes.data(), v.rds_bytes, out.bytes.size(), hipMemcpyDeviceToHost));
+            HIPC(hipMemcpy(out.counts.data(), v.rds_counts, out.counts.size() * sizeof(int), hipMemcpyDeviceToHost));
+            return 0;
+        };
+        {
+            MultiGpuHost host(devs, C, N, fs, dflags, fmt, gflags, 0);
+            n_audio = host.Rates().n_audio;
+            remote = host.RemoteBytesPerBlock();
+            std::vector<float> a((size_t)C * n_audio * 2);
+            for (int b = 0; b < nb; b++) {
+                std::vector<const uint8_t*> ptrs((size_t)R);
+                for (int r = 0; r < R; r++) ptrs[(size_t)r] = d_in[(size_t)r][(size_t)b];
+                host.SubmitU8(ptrs);
+                const MultiGpuHost::Views v = host.Collect();
+                cap = v.rds_cap;
+                if (int rc = fetch(v, pass1[(size_t)b], n_audio, devs[0])) return rc;
+                for (int r = 0; r < R; r++) {      // what the rank's own handle holds for this block
+                    if (fmd_get_audio(host.Handle(r), a.data()) != FMD_OK) return 6;
+                    std::vector<uint8_t> by((size_t)C * cap); std::vector<int> cn((size_t)C);
+                    if (fmd_get_rds_bytes(host.Handle(r), by.data(), cap, cn.data()) != FMD_OK) return 6;
+                    for (size_t i = 0; i < a.size(); i++) {
+                        if (pcm) {
+                            const int16_t want = (int16_t)(int)(a[i] * (32767.0f * 0.95f));
+                            mismatches += reinterpret_cast<const int16_t*>(pass1[(size_t)b].audio.data())[(size_t)r * a.size() + i] != want;
+                        } else mismatches += std::memcmp(&reinterpret_cast<const float*>(pass1[(size_t)b].audio.data())[(size_t)r * a.size() + i], &a[i], 4) != 0;
+                    }
+                    for (int c = 0; c < C; c++) {
+                        mismatches += pass1[(size_t)b].counts[(size_t)r * C + c] != cn[(size_t)c];
+                        mismatches += std::memcmp(pass1[(size_t)b].bytes.data() + ((size_t)r * C + c) * cap, by.data() + (size_t)c * cap, (size_t)cn[(size_t)c]) != 0;
+                    }
+                }
+            }
+        }
+        long bytes_total = 0;
+        for (const Block& b : pass1) for (int c : b.counts) bytes_total += c;
+        long mismatches2 = 0;
+        {
+            MultiGpuHost host(devs, C, N, fs, dflags, fmt, gflags, 0);
+            int submitted = 0, collected = 0;
+            Block got;
+            while (collected < nb) {
+                while (submitted < nb && submitted - collected < 3) {     // two blocks in flight beyond the one being collected
+                    std::vector<const uint8_t*> ptrs((size_t)R);
+                    for (int r = 0; r < R; r++) ptrs[(size_t)r] = d_in[(size_t)r][(size_t)submitted];
+                    host.SubmitU8(ptrs);
+                    submitted++;
+                }
+                const MultiGpuHost::Views v = host.Collect();
+                if (int rc = fetch(v, got, n_audio, devs[0])) return rc;
+                const Block& w = pass1[(size_t)collected];
+                mismatches2 += got.audio != w.audio;
+                mismatches2 += got.counts != w.counts;
+                for (size_t s = 0; s < w.counts.size(); s++) mismatches2 += std::memcmp(got.bytes.data() + s * cap, w.bytes.data() + s * cap, (size_t)w.counts[s]) != 0;
+                collected++;
+            }
+        }
+        printf("{\"ranks\": %d, \"devices\": %d, \"stations_per_rank\": %d, \"blocks\": %d, \"format\": \"%s\", \"loopback_rccl\": %s, \"lockstep_mismatches\": %ld, "
+               "\"pipelined_mismatches\": %ld, \"rds_bytes_gathered\": %ld, \"remote_bytes_per_block\": %zu}\n",
+               R, ndev, C, nb, pcm ? "pcm16" : "f32", loopback ? "true" : "false", mismatches, mismatches2, bytes_total, remote);
+        return (mismatches == 0 && mismatches2 == 0 && bytes_total > 0) ? 0 : 3;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "multi_gpu_main: %s\n", e.what());
+        return 4;
+    }
+}

@@ -2,7 +2,7 @@
 # Round-2 measurement table: one line per configuration, on one box.
 export GPU_MAX_HW_QUEUES=8
 O=gpurun_out/r2_final; mkdir -p $O
-run() { python bench.py $2 --no-cpu-baseline --no-other-mode --no-host-fed 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps({'cfg': sys.argv[1], 'value': round(d['value']), 'ms': round(d['ms_per_step'],4), 'kernels': {k: round(v,3) for k,v in d['roofline']['kernels_ms_per_step'].items()}, 'spec': d.get('speculation', {}).get('pll', {}).get('samples_per_span')}))" "$1" | tee -a $O/table.jsonl; }
+run() { python bench.py $2 --no-cpu-baseline --no-other-mode --no-configs --no-host-fed 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps({'cfg': sys.argv[1], 'value': round(d['value']), 'ms': round(d['ms_per_step'],4), 'kernels': {k: round(v,3) for k,v in d['roofline']['kernels_ms_per_step'].items()}, 'spec': d.get('speculation', {}).get('pll', {}).get('samples_per_span')}))" "$1" | tee -a $O/table.jsonl; }
 rm -f $O/table.jsonl
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.json; echo
 run "fast 4096" ""

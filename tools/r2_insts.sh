@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/insts; rm -rf $O; mkdir -p $O; cd $R
 export GPU_MAX_HW_QUEUES=8
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/a -- python3 bench.py ${BENCH_ARGS:-} --steps 4 --warmup 1 --preroll 16 --no-cpu-baseline --no-other-mode --no-host-fed --no-pipeline > /dev/null 2> $O/a.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/a -- python3 bench.py ${BENCH_ARGS:-} --steps 4 --warmup 1 --preroll 16 --no-cpu-baseline --no-other-mode --no-configs --no-host-fed --no-pipeline > /dev/null 2> $O/a.err
 python3 - <<'PY'
 import csv, glob, collections, os
 O = os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/insts"

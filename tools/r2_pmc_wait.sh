@@ -7,8 +7,8 @@ rm -rf $O && mkdir -p $O
 cd $R
 export GPU_MAX_HW_QUEUES=8
 ARGS="${BENCH_ARGS:---fast-math}"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_SALU --output-format csv -d $O/a -- python3 bench.py $ARGS --steps 12 --warmup 2 --preroll 8 --no-cpu-baseline --no-other-mode ${PIPE:---no-pipeline} > /dev/null 2> $O/a.err
-rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT --output-format csv -d $O/b -- python3 bench.py $ARGS --steps 12 --warmup 2 --preroll 8 --no-cpu-baseline --no-other-mode ${PIPE:---no-pipeline} > /dev/null 2> $O/b.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_SALU --output-format csv -d $O/a -- python3 bench.py $ARGS --steps 12 --warmup 2 --preroll 8 --no-cpu-baseline --no-other-mode --no-configs ${PIPE:---no-pipeline} > /dev/null 2> $O/a.err
+rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT --output-format csv -d $O/b -- python3 bench.py $ARGS --steps 12 --warmup 2 --preroll 8 --no-cpu-baseline --no-other-mode --no-configs ${PIPE:---no-pipeline} > /dev/null 2> $O/b.err
 python3 - <<'PY'
 import csv, glob, collections, os
 O = os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/pmc_wait"
