@@ -57,12 +57,13 @@ def algorithmic_bytes_per_sample(fs: int, u8: bool) -> float:
     return in_b + audio + syms
 
 
-UNLOCKED_KINDS = ("nopilot", "noise", "zero")
+UNLOCKED_KINDS = ("nopilot", "noise", "zero", "detuned")
 
 
 def unlocked_plan(n_ch: int, frac: float, kind: str, seed: int) -> np.ndarray:
     """Which channels cannot lock, and how: 0 = normal station, 1 = mono station (no 19 kHz pilot, no L-R, no RDS), 2 = empty
-    channel (receiver noise only), 3 = dead channel (all-zero IQ: pilot AGC divides by zero, reference agc.h:12-19).  The
+    channel (receiver noise only), 3 = dead channel (all-zero IQ: pilot AGC divides by zero, reference agc.h:12-19), 4 = a station
+    whose pilot is 130 Hz off (30 Hz beyond the loop's range: control and integrator on their rails, the loop beats).  The
     affected channels are spread over the batch pseudo-randomly (seeded), as stations are over a band scan."""
     plan = np.zeros(n_ch, np.int8)
     n_bad = int(round(frac * n_ch))
@@ -70,7 +71,7 @@ def unlocked_plan(n_ch: int, frac: float, kind: str, seed: int) -> np.ndarray:
         return plan
     rng = np.random.default_rng(seed)
     idx = rng.choice(n_ch, size=min(n_bad, n_ch), replace=False)
-    kinds = {"nopilot": [1], "noise": [2], "zero": [3], "mix": [1, 2, 3]}[kind]
+    kinds = {"nopilot": [1], "noise": [2], "zero": [3], "detuned": [4], "mix": [1, 2, 3, 4]}[kind]
     plan[idx] = np.array([kinds[i % len(kinds)] for i in range(idx.size)], np.int8)
     return plan
 
@@ -100,11 +101,11 @@ def synth_block_device(torch, n_ch: int, n_total: int, fs: float, seed: int, dev
         sym = torch.stack([lvl, -lvl], dim=2).reshape(m, -1)
         idx = torch.floor(t * 2375.0).to(torch.int64)
         rds = sym[:, idx]
-        p = two_pi * 19000.0 * tt
         kd = kinds[c0:c1, None]
-        stereo = (kd == 0).to(torch.float64)          # pilot, L-R and RDS present
-        carrier = (kd <= 1).to(torch.float64)         # an FM carrier at all (kind 2: noise only; kind 3: nothing)
-        live = (kd <= 2).to(torch.float64)
+        p = two_pi * (19000.0 + 130.0 * (kd == 4).to(torch.float64)) * tt
+        stereo = ((kd == 0) | (kd == 4)).to(torch.float64)   # pilot, L-R and RDS present
+        carrier = ((kd <= 1) | (kd == 4)).to(torch.float64)  # an FM carrier at all (kind 2: noise only; kind 3: nothing)
+        live = (kd != 3).to(torch.float64)
         mpx = 0.40 * (left + right) / 1.6 + stereo * (0.10 * torch.sin(p) + 0.40 * (left - right) / 1.6 * torch.sin(2.0 * p) + 0.06 * rds * torch.sin(3.0 * p))
         phase = two_pi * 75000.0 * torch.cumsum(mpx, dim=1) / fs
         i = carrier * torch.cos(phase) + live * 0.02 * torch.randn((m, n_total), generator=g, device=device, dtype=torch.float64)
@@ -374,7 +375,8 @@ def main() -> None:
                     "(mono stations, empty channels, dead inputs: see --unlocked-kind), spread over the batch")
     ap.add_argument("--unlocked-kind", default="mix", choices=["mix", *UNLOCKED_KINDS],
                     help="nopilot: mono FM station without pilot/L-R/RDS; noise: no carrier, receiver noise only; zero: all-zero IQ "
-                         "(the pilot AGC divides by zero, as in the reference); mix: the three in turn")
+                         "(the pilot AGC divides by zero, as in the reference); detuned: pilot at 19130 Hz, beyond the loop's range; "
+                         "mix: the four in turn")
     ap.add_argument("--deemphasis", type=int, default=0, metavar="US", help="enable the de-emphasis IIR on every channel with this time constant (50 / 75)")
     ap.add_argument("--exact", action="store_true", help="time the exact mode (every output bit-identical to the CPU oracle) as the primary result.  Default: "
                     "FMD_FLAG_FAST_MATH, the tolerance mode — the parity BASELINE.json's north star asks for (audio / L-R within 1e-4 RMS of "

@@ -26,6 +26,8 @@ using namespace fmd;
 // all stages run concurrently on different blocks.
 enum Stage { ST_FRONT = 0, ST_DEEMPH, ST_POWER, ST_PLL, ST_EXTRACT, ST_RDS, ST_PREDECIM, ST_COUNT };
 static const char* const kStageName[ST_COUNT] = {"k_front", "k_deemphasis+k_hilbert", "k_pilot_power", "k_pilot_pll", "k_extract", "k_rds_sync", "k_predecim"};
+// ... and of the tolerance mode's kernels, as they appear in rocprofv3 kernel traces
+static const char* const kStageNameFast[ST_COUNT] = {"k_front_mfma", "k_deemphasis+k_hilbert", "k_pilot_power", "k_pll_span", "k_extract_mfma", "k_rds_sync", "k_predecim"};
 
 struct ProfiledBlock { hipEvent_t t0[ST_COUNT], t1[ST_COUNT]; bool used[ST_COUNT]; };
 
@@ -646,9 +648,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     h->ctx.bytes_cap = h->bytes_cap;
     h->ctx.keep_taps = (cfg->flags & FMD_FLAG_KEEP_TAPS) ? 1 : 0;
     h->ctx.fast = (cfg->flags & FMD_FLAG_FAST_MATH) ? 1 : 0;
-    h->ctx.pll_hold_hz = 2.0f;
     if (const char* e = getenv("FMD_DEBUG_SKIP_STAGES")) h->debug_skip = (unsigned)strtoul(e, nullptr, 0);   // development knob
-    if (const char* e = getenv("FMD_DEBUG_PLL_HOLD_HZ")) h->ctx.pll_hold_hz = (float)atof(e);   // development knob (tools/dbg): 0 = one sample per span
 
     fmd_controls def;
     fmd_default_controls(&def);
@@ -1022,6 +1022,14 @@ int fmd_get_state(fmd_handle h, int channel, void* blob, size_t cap_bytes) {
     const int par = (int)(h->n_blocks & 1);   // the histories the NEXT block reads
     // the two L-R phase fields hold P_k by k & 1 (fmd_kernels.hip: lmr_field); in the blob: PREV = the newest block's offset
     if (par == 1) std::swap(out[S_LMR_PHASE_CUR], out[S_LMR_PHASE_PREV]);
+    // CUR = P_b, the offset the NEXT block is mixed with.  Where the next block's k_extract derives it itself (tolerance mode, small
+    // batches) nothing has written it behind the newest block: materialise it here, so that a blob means the same whichever path
+    // produced it and can be restored into a handle on the other side of that switch
+    if (h->n_blocks > 0) {
+        HIP_TRY(h, launch_lmr_phase_peek(h->ctx, (int)((h->n_blocks + 1) & 1), h->ctx.b.lmr_peek, h->own_stream));
+        HIP_TRY(h, hipStreamSynchronize(h->own_stream));
+        HIP_TRY(h, hipMemcpy(&out[S_LMR_PHASE_CUR], h->ctx.b.lmr_peek + channel, sizeof(float), hipMemcpyDeviceToHost));
+    }
     out += S_NUM_FIELDS;
     for (const StatePart& p : state_parts(h)) {
         HIP_TRY(h, hipMemcpy(out, p.base + (size_t)channel * p.stride, sizeof(float) * p.floats, hipMemcpyDeviceToHost));
@@ -1131,7 +1139,7 @@ int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out) {
             float ms = 0.0f;
             HIP_TRY(h, hipEventElapsedTime(&ms, pm->t0[i], pm->t1[i]));
             int slot = -1;
-            const char* nm = (h->ctx.fast && i == ST_PLL) ? "k_pll_fast" : kStageName[i];
+            const char* nm = h->ctx.fast ? kStageNameFast[i] : kStageName[i];
             for (int j = 0; j < n; j++) if (std::strncmp(out[j].name, nm, sizeof(out[j].name)) == 0) { slot = j; break; }
             if (slot < 0) {
                 if (n >= cap) continue;

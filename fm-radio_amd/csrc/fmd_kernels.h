@@ -47,7 +47,7 @@ enum StateField : int {
     S_NUM_FIELDS
 };
 
-// FMD_FLAG_FAST_MATH: the pilot peak filter y[n] = K x[n-2] + a1 y[n-1] + a0 y[n-2] evaluated as a parallel scan inside k_pll_fast:
+// FMD_FLAG_FAST_MATH: the pilot peak filter y[n] = K x[n-2] + a1 y[n-1] + a0 y[n-2] evaluated as a parallel scan inside k_pll_span:
 // each of a channel's 32 lanes runs kPilotSeg samples from a zero state, the segment end states are combined across the lanes
 // with powers of the transition matrix A = [[a1, a0], [1, 0]], and the homogeneous solution is added back.  Designed on the
 // host in double precision (fmd_api.cpp design_pilot_fast).
@@ -164,7 +164,6 @@ struct LaunchCtx {
     LoopCoeffs loops;
     int keep_taps;
     int fast;                             // FMD_FLAG_FAST_MATH: the tolerance-mode kernels
-    float pll_hold_hz;                    // k_pll_fast: a span ends where the NCO frequency has moved further than this from the held word
     int any_deemph;
     int deemph_in_tile;     // FMD_FLAG_FAST_MATH: the de-emphasis IIR runs inside k_front's tile (every filtering channel's pole <= 0.905, i.e. up to ~79 us)
     int bytes_cap;

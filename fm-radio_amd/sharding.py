@@ -66,7 +66,9 @@ class AudioGather:
         self.depth = depth
 
     def slot(self, k: int) -> int:
-        """Staging slot of step k, free to be refilled (its previous gather has completed)."""
+        """Staging slot of step k, free to be refilled (its previous gather has completed).  On RCCL ("nccl") Work.wait() orders the
+        CURRENT STREAM behind the collective and returns at once — the host is not blocked; on gloo (the CPU plumbing tests) it
+        blocks the calling thread, which is what a host-side collective is."""
         s = k % self.depth
         if self.handles[s] is not None:
             self.handles[s].wait()

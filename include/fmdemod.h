@@ -66,14 +66,21 @@ typedef struct {
 #define FMD_FLAG_PLL_K8           16u  /* time-parallel kernel with 8 (not 16) lanes per channel whatever the batch size (default: effective batches (stations, x 1.5 at 1.024 and 2.048 MSa/s) > 3584) */
 #define FMD_FLAG_PLL_STREAM_ORDER  32u  /* consecutive blocks' pilot-PLL launches ordered by the stream (kernel boundary) instead of handing over per wavefront while both run (A/B and debugging; same results) */
 #define FMD_FLAG_PLL_LOW_WORK      8u  /* force the low-work pilot-PLL kernel (default: larger batches); same results either way */
-/* Tolerance mode.  Default (flag clear): every output is bit-identical to the CPU restatement of the reference (oracle/).
+/* Tolerance mode.  Default (flag clear): every output is bit-identical to the CPU restatement of the reference (oracle/) — the
+ * reference's operation order, libm's atan2f, a pilot PLL advanced sample by sample.  That contract has a price the caller should
+ * know: a station WITHOUT a lockable pilot (mono station, empty channel, dead input) makes its wavefront fall back to the serial
+ * 78-operation iteration, and one such wavefront per SIMD is enough to make a block cost ~4x (0.9 -> 3.7-3.9 ms per 4096-station
+ * block from 1 % unlocked stations on): a band scan, where most channels are empty, wants the tolerance mode.
  * With the flag the chain keeps the reference's signal flow and state variables but uses cheaper arithmetic: minimax arctangent,
  * hardware sine/cosine, the FIRs as bf16 x 3 products on the matrix cores (fp32 accumulation, ~1e-6 relative), the pilot peak filter
- * and its AGC power as a parallel scan, the pilot PLL evaluated 64 samples at a time with its NCO frequency held and corrected to
- * first order, the optional de-emphasis inside the front-end tile (time constants up to ~79 us) — within the parity BASELINE.json's
- * north star asks for: audio / L-R within 1e-4 RMS of the reference, RDS bits identical once the synchroniser is in lock
- * (tests/test_gpu_fast.py, DESIGN.md 3b for the two places where the reference's own decisions are discontinuous).
- * Cost per sample does not depend on whether a station's pilot PLL is in lock.  The FMD_FLAG_PLL_* selectors are ignored. */
+ * on the real rail as a parallel scan, the pilot PLL advanced 128 samples at a time by weight vectors (the NCO frequency held over
+ * the span, the feedback inside it solved exactly on the host), the optional de-emphasis inside the front-end tile (time constants
+ * up to ~79 us).  Parity, as tests/test_gpu_fast.py and tests/test_gpu_long.py assert it: every block of audio / L-R within 1e-4 RMS
+ * of the oracle except where a sign decision of the reference's L-R phase tracker falls on the other side (one estimate in ~300
+ * blocks; bounded by the measured offset difference; two builds of the reference differ the same way,
+ * profiles/round3/reference_flip_evidence.json), whole-run RMS 1e-5 on 64 stations x 30 s, RDS bits identical once the synchroniser
+ * is in lock.  The cost of a block does not depend on the signals: there is no data-dependent path (a station's first 64 ms
+ * after a reset take the Hilbert rail through a second peak filter).  The FMD_FLAG_PLL_* selectors are ignored. */
 #define FMD_FLAG_FAST_MATH        64u
 
 /* reference Broadcast_FM_Demod_Controls (broadcast_fm_demod.h:64-89); defaults in fmd_default_controls */
