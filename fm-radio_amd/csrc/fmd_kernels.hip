@@ -1952,84 +1952,175 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
     const float KTs_pi = (10.0f * Ts) * (2e3f / 16e3f);
     const float half_pi = bits_f32(kHalfPiBits), two_over_pi = bits_f32(kTwoOverPiBits);
 
-    for (; step < steps; step++) {
-        const int ch = one_pass ? step : step - chunks;
-        float2* buf = ring[step & (kRingSlots - 1)];
-        for (int t = 0; t < kChunk; t++) {
-            const float2 xr = buf[lane * kRowC + t];
-            const float p = gain * xr.x, q = gain * xr.y;
-            if (keep_taps) buf[lane * kRowC + t] = make_float2(p, q);
-            // carrier PLL PI controller
-            const float lt0 = fmaf(pll_x1, k.bpsk_b0, pll_y1 * k.bpsk_a0);
-            const float pll_lpf = (0.0f + lt0) + fmaf(pll_err, k.bpsk_b1, 0.0f);
-            pll_x1 = pll_err; pll_y1 = pll_lpf;
-            pll_int = clampf(fmaf(pll_err, KTs_pi, pll_int), -1.0f, 1.0f);
-            const float PI_pll = fmaf(pll_lpf, 0.3f, pll_int);
-            // PLL_Mixer::Update: f_center 0, f_gain 10
-            const float control = clampf(PI_pll * 1.0f, -1.0f, 1.0f);
-            const float freq = fmaf(control, 10.0f, 0.0f);
-            const float yy = fmaf(freq, Ts, mix_t);
-            float ps, pc;
-            if constexpr (FAST) {
-                mix_t = yy - rintf(yy);
-                ps = fast_sin_turns(mix_t); pc = fast_cos_turns(mix_t);
-            } else {
-                mix_t = yy - round_half_away(yy);
-                float dt_cos = mix_t + 0.25f;
-                dt_cos = dt_cos - round_half_away(dt_cos);
-                ps = cheb_sine_scalar(mix_t); pc = cheb_sine_scalar(dt_cos);
-            }
-            const float iq_r = fmaf(pc, p, -(q * ps));
-            const float iq_i = fmaf(p, ps, q * pc);
-            // zero crossing on Q with hold-off
-            bool is_zcd = 0.0f > (iq_i * zcd_xn);
-            zcd_xn = iq_i;
-            if (is_zcd && cooldown == 0) { cooldown = 4; }
-            else { if (cooldown > 0) cooldown--; is_zcd = false; }
-            if (is_zcd) { float e2 = clock + clock; if (clock > 0.5f) e2 = e2 - 2.0f; ted_err = e2; }
-            // TED PI controller
-            const float tt0 = fmaf(ted_x1, k.ted_b0, ted_y1 * k.ted_a0);
-            const float ted_lpf = (0.0f + tt0) + fmaf(ted_err, k.ted_b1, 0.0f);
-            ted_x1 = ted_err; ted_y1 = ted_lpf;
-            ted_int = clampf(fmaf(ted_err, KTs_pi, ted_int), -1.0f, 1.0f);
-            const float PI_ted = fmaf(ted_lpf, 0.3f, ted_int);
-            // integrate and dump
-            dump_r = fmaf(0.25f, iq_r, dump_r);
-            dump_i = fmaf(0.25f, iq_i, dump_i);
-            // TED_Clock::update: fcenter 2000, fgain 1500
-            const float ccontrol = clampf((-PI_ted) * 1.0f, -1.0f, 1.0f);
-            const float cfreq = fmaf(ccontrol, 1.5e3f, 2e3f);
-            const float dd = cfreq * Ts;
-            const float cy = dd + clock;
-            const float thr = fmaf(-dd, 0.5f, 1.0f);
-            if (thr > cy) {
-                clock = cy;
-            } else {
-                clock = 0.0f;
-                const float sr = dump_r, si = dump_i;
-                dump_r = 0.0f; dump_i = 0.0f;
-                const float phs = FAST ? fast_atan2f(si, sr) : fmd_atan2f(si, sr);
-                const float est = (phs > 0.0f) ? (half_pi - phs) : (-half_pi - phs);
-                pll_err = est * two_over_pi;
-                if (live) {
-                    rds_sym[(size_t)c * n + n_sym] = si;
-                    if (keep_taps) rds_raw_sym[(size_t)c * n + n_sym] = make_float2(sr, si);
+    // Tolerance mode: a symbol's phase estimate (arctangent, stores, sign packing: half of the loop's instructions) does not run inside
+    // the sample in which the clock wrapped — with 64 stations per wavefront some lane wraps on almost every sample, so every sample
+    // paid for it — but once per group of four samples: the symbol clock tops out at 3500 Hz of 16 kHz, so a station has at most
+    // one symbol pending per group.  The carrier loop then sees its new phase error up to three samples (0.2 ms) later than the
+    // reference's would: at the end of the group the loop filter, integrator and NCO phase are corrected for that — between two
+    // symbols the carrier loop is linear in its phase error, so what the j samples behind the wrap would have added under the new
+    // error is a constant times the change (dl / di / dm below; the clamps do not act on a loop near lock) — and acquisition runs as
+    // it does when every symbol is handled in its own sample.
+    if constexpr (FAST) {
+        bool pend = false;
+        float psr = 0.0f, psi = 0.0f;
+        int jw = 0;                                          // samples of the group behind the one in which the clock wrapped
+        const float Ts10 = 10.0f * Ts;
+        // response of (loop filter output, integrator, NCO phase) after j = 1, 2, 3 samples to a unit step of the phase error
+        const float dl1 = k.bpsk_b1, dl2 = fmaf(k.bpsk_a0, dl1, k.bpsk_b0 + k.bpsk_b1), dl3 = fmaf(k.bpsk_a0, dl2, k.bpsk_b0 + k.bpsk_b1);
+        const float dm1 = Ts10 * fmaf(0.3f, dl1, KTs_pi), dm2 = dm1 + Ts10 * fmaf(0.3f, dl2, 2.0f * KTs_pi), dm3 = dm2 + Ts10 * fmaf(0.3f, dl3, 3.0f * KTs_pi);
+        for (; step < steps; step++) {
+            const int ch = one_pass ? step : step - chunks;
+            float2* buf = ring[step & (kRingSlots - 1)];
+            for (int t4 = 0; t4 < kChunk; t4 += 4) {
+#pragma unroll
+                for (int u4 = 0; u4 < 4; u4++) {
+                    const int t = t4 + u4;
+                    const float2 xr = buf[lane * kRowC + t];
+                    const float p = gain * xr.x, q = gain * xr.y;
+                    if (keep_taps) buf[lane * kRowC + t] = make_float2(p, q);
+                    // carrier PLL PI controller; PLL_Mixer::Update: f_center 0, f_gain 10
+                    const float pll_lpf = fmaf(pll_x1, k.bpsk_b0, fmaf(pll_y1, k.bpsk_a0, pll_err * k.bpsk_b1));
+                    pll_x1 = pll_err; pll_y1 = pll_lpf;
+                    pll_int = clampf(fmaf(pll_err, KTs_pi, pll_int), -1.0f, 1.0f);
+                    const float control = clampf(fmaf(pll_lpf, 0.3f, pll_int), -1.0f, 1.0f);
+                    const float yy = fmaf(control, Ts10, mix_t);
+                    mix_t = yy - rintf(yy);
+                    const float ps = fast_sin_turns(mix_t), pc = fast_cos_turns(mix_t);
+                    const float iq_r = fmaf(pc, p, -(q * ps));
+                    const float iq_i = fmaf(p, ps, q * pc);
+                    // zero crossing on Q with hold-off
+                    bool is_zcd = 0.0f > (iq_i * zcd_xn);
+                    zcd_xn = iq_i;
+                    if (is_zcd && cooldown == 0) { cooldown = 4; }
+                    else { if (cooldown > 0) cooldown--; is_zcd = false; }
+                    if (is_zcd) { float e2 = clock + clock; if (clock > 0.5f) e2 = e2 - 2.0f; ted_err = e2; }
+                    // TED PI controller
+                    const float ted_lpf = fmaf(ted_x1, k.ted_b0, fmaf(ted_y1, k.ted_a0, ted_err * k.ted_b1));
+                    ted_x1 = ted_err; ted_y1 = ted_lpf;
+                    ted_int = clampf(fmaf(ted_err, KTs_pi, ted_int), -1.0f, 1.0f);
+                    const float PI_ted = fmaf(ted_lpf, 0.3f, ted_int);
+                    // integrate and dump
+                    dump_r = fmaf(0.25f, iq_r, dump_r);
+                    dump_i = fmaf(0.25f, iq_i, dump_i);
+                    // TED_Clock::update: fcenter 2000, fgain 1500
+                    const float cfreq = fmaf(clampf(-PI_ted, -1.0f, 1.0f), 1.5e3f, 2e3f);
+                    const float dd = cfreq * Ts;
+                    const float cy = dd + clock;
+                    const bool wrapped = !(fmaf(-dd, 0.5f, 1.0f) > cy);
+                    clock = wrapped ? 0.0f : cy;
+                    psr = wrapped ? dump_r : psr; psi = wrapped ? dump_i : psi;
+                    dump_r = wrapped ? 0.0f : dump_r; dump_i = wrapped ? 0.0f : dump_i;
+                    jw = wrapped ? 3 - u4 : jw;
+                    pend = pend || wrapped;
                 }
-                // the symbol's sign for the Manchester decoder behind the loop
-                sign_word |= ((si > 0.0f) ? 1u : 0u) << (wsym & 31);
-                if ((wsym & 31) == 31) { sign_bits[lane * kSignWords + (wsym >> 5)] = sign_word; sign_word = 0u; }
-                n_sym++; wsym++;
+                if (pend) {
+                    const float phs = fast_atan2f(psi, psr);
+                    const float est = (phs > 0.0f) ? (half_pi - phs) : (-half_pi - phs);
+                    const float err_new = est * two_over_pi, de = err_new - pll_err;
+                    pll_err = err_new;
+                    // the jw samples behind the wrap ran on the old error
+                    pll_x1 = (jw >= 1) ? err_new : pll_x1;
+                    pll_y1 = fmaf((jw == 1) ? dl1 : ((jw == 2) ? dl2 : ((jw == 3) ? dl3 : 0.0f)), de, pll_y1);
+                    pll_int = fmaf(KTs_pi * (float)jw, de, pll_int);
+                    mix_t = fmaf((jw == 1) ? dm1 : ((jw == 2) ? dm2 : ((jw == 3) ? dm3 : 0.0f)), de, mix_t);
+                    if (live) {
+                        rds_sym[(size_t)c * n + n_sym] = psi;
+                        if (keep_taps) rds_raw_sym[(size_t)c * n + n_sym] = make_float2(psr, psi);
+                    }
+                    sign_word |= ((psi > 0.0f) ? 1u : 0u) << (wsym & 31);
+                    if ((wsym & 31) == 31) { sign_bits[lane * kSignWords + (wsym >> 5)] = sign_word; sign_word = 0u; }
+                    n_sym++; wsym++;
+                    pend = false;
+                }
             }
+            if (__builtin_amdgcn_ballot_w64(wsym > 32 * (kSignWords - 1) - kChunk) != 0ull) decode_buffered();
+            if (keep_taps) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                chunk_flush_c(buf, rds, n, c0, d.C, ch * kChunk);
+            }
+            __syncthreads();
         }
-        // a chunk adds at most kChunk / 4 symbols to a lane's row (3500 Hz of 16 kHz is fewer): decode before any row can overflow
-        if (__builtin_amdgcn_ballot_w64(wsym > 32 * (kSignWords - 1) - kChunk) != 0ull) decode_buffered();
-        if (keep_taps) {
-            // write the post-AGC RDS signal back (reference GetRDSOutput)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            chunk_flush_c(buf, rds, n, c0, d.C, ch * kChunk);
+    } else {
+        for (; step < steps; step++) {
+            const int ch = one_pass ? step : step - chunks;
+            float2* buf = ring[step & (kRingSlots - 1)];
+            for (int t = 0; t < kChunk; t++) {
+                const float2 xr = buf[lane * kRowC + t];
+                const float p = gain * xr.x, q = gain * xr.y;
+                if (keep_taps) buf[lane * kRowC + t] = make_float2(p, q);
+                // carrier PLL PI controller
+                const float lt0 = fmaf(pll_x1, k.bpsk_b0, pll_y1 * k.bpsk_a0);
+                const float pll_lpf = (0.0f + lt0) + fmaf(pll_err, k.bpsk_b1, 0.0f);
+                pll_x1 = pll_err; pll_y1 = pll_lpf;
+                pll_int = clampf(fmaf(pll_err, KTs_pi, pll_int), -1.0f, 1.0f);
+                const float PI_pll = fmaf(pll_lpf, 0.3f, pll_int);
+                // PLL_Mixer::Update: f_center 0, f_gain 10
+                const float control = clampf(PI_pll * 1.0f, -1.0f, 1.0f);
+                const float freq = fmaf(control, 10.0f, 0.0f);
+                const float yy = fmaf(freq, Ts, mix_t);
+                float ps, pc;
+                if constexpr (FAST) {
+                    mix_t = yy - rintf(yy);
+                    ps = fast_sin_turns(mix_t); pc = fast_cos_turns(mix_t);
+                } else {
+                    mix_t = yy - round_half_away(yy);
+                    float dt_cos = mix_t + 0.25f;
+                    dt_cos = dt_cos - round_half_away(dt_cos);
+                    ps = cheb_sine_scalar(mix_t); pc = cheb_sine_scalar(dt_cos);
+                }
+                const float iq_r = fmaf(pc, p, -(q * ps));
+                const float iq_i = fmaf(p, ps, q * pc);
+                // zero crossing on Q with hold-off
+                bool is_zcd = 0.0f > (iq_i * zcd_xn);
+                zcd_xn = iq_i;
+                if (is_zcd && cooldown == 0) { cooldown = 4; }
+                else { if (cooldown > 0) cooldown--; is_zcd = false; }
+                if (is_zcd) { float e2 = clock + clock; if (clock > 0.5f) e2 = e2 - 2.0f; ted_err = e2; }
+                // TED PI controller
+                const float tt0 = fmaf(ted_x1, k.ted_b0, ted_y1 * k.ted_a0);
+                const float ted_lpf = (0.0f + tt0) + fmaf(ted_err, k.ted_b1, 0.0f);
+                ted_x1 = ted_err; ted_y1 = ted_lpf;
+                ted_int = clampf(fmaf(ted_err, KTs_pi, ted_int), -1.0f, 1.0f);
+                const float PI_ted = fmaf(ted_lpf, 0.3f, ted_int);
+                // integrate and dump
+                dump_r = fmaf(0.25f, iq_r, dump_r);
+                dump_i = fmaf(0.25f, iq_i, dump_i);
+                // TED_Clock::update: fcenter 2000, fgain 1500
+                const float ccontrol = clampf((-PI_ted) * 1.0f, -1.0f, 1.0f);
+                const float cfreq = fmaf(ccontrol, 1.5e3f, 2e3f);
+                const float dd = cfreq * Ts;
+                const float cy = dd + clock;
+                const float thr = fmaf(-dd, 0.5f, 1.0f);
+                if (thr > cy) {
+                    clock = cy;
+                } else {
+                    clock = 0.0f;
+                    const float sr = dump_r, si = dump_i;
+                    dump_r = 0.0f; dump_i = 0.0f;
+                    const float phs = FAST ? fast_atan2f(si, sr) : fmd_atan2f(si, sr);
+                    const float est = (phs > 0.0f) ? (half_pi - phs) : (-half_pi - phs);
+                    pll_err = est * two_over_pi;
+                    if (live) {
+                        rds_sym[(size_t)c * n + n_sym] = si;
+                        if (keep_taps) rds_raw_sym[(size_t)c * n + n_sym] = make_float2(sr, si);
+                    }
+                    // the symbol's sign for the Manchester decoder behind the loop
+                    sign_word |= ((si > 0.0f) ? 1u : 0u) << (wsym & 31);
+                    if ((wsym & 31) == 31) { sign_bits[lane * kSignWords + (wsym >> 5)] = sign_word; sign_word = 0u; }
+                    n_sym++; wsym++;
+                }
+            }
+            // a chunk adds at most kChunk / 4 symbols to a lane's row (3500 Hz of 16 kHz is fewer): decode before any row can overflow
+            if (__builtin_amdgcn_ballot_w64(wsym > 32 * (kSignWords - 1) - kChunk) != 0ull) decode_buffered();
+            if (keep_taps) {
+                // write the post-AGC RDS signal back (reference GetRDSOutput)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                chunk_flush_c(buf, rds, n, c0, d.C, ch * kChunk);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     decode_buffered();
     if (live) {
