@@ -48,10 +48,10 @@ enum StateField : int {
 };
 
 // FMD_FLAG_FAST_MATH: the pilot peak filter y[n] = K x[n-2] + a1 y[n-1] + a0 y[n-2] evaluated as a parallel scan inside k_pll_span:
-// each of a channel's 32 lanes runs kPilotSeg samples from a zero state, the segment end states are combined across the lanes
+// each of a channel's 16 lanes runs kPilotSeg samples from a zero state, the segment end states are combined across the lanes
 // with powers of the transition matrix A = [[a1, a0], [1, 0]], and the homogeneous solution is added back.  Designed on the
 // host in double precision (fmd_api.cpp design_pilot_fast).
-static constexpr int kPilotSeg = 4;
+static constexpr int kPilotSeg = 8;       // samples per lane (16 lanes per station)
 struct PilotFastTab {
     float h1[kPilotSeg], h2[kPilotSeg];   // y[k] += h1[k] y[-1] + h2[k] y[-2]: first row of A^(k+1)
     float m[4][4];                        // M^(2^s), M = A^kPilotSeg, as (m00, m01, m10, m11): steps of the cross-lane scan within a row of 16 lanes

@@ -2420,7 +2420,7 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     if (ctx.fast) {
         const int nxt = (r.buf + 1) % kSlots;
         const bool iq = ctx.b.fm_out_iq[r.buf] != nullptr;    // FMD_FLAG_KEEP_TAPS, or audio blocks that are not multiples of 256: the interleaved streams too
-        FMD_LAUNCH(r, true, !iq, k_pll_span, dim3((unsigned)((d.C + 1) / 2)), dim3(kWave), 0, s, d, ctx.b.fo_pl[r.buf], ctx.b.fo_pl[nxt], ctx.b.im_pl[r.buf], ctx.b.im_pl[nxt],
+        FMD_LAUNCH(r, true, !iq, k_pll_span, dim3((unsigned)((d.C + 3) / 4)), dim3(kWave), 0, s, d, ctx.b.fo_pl[r.buf], ctx.b.fo_pl[nxt], ctx.b.im_pl[r.buf], ctx.b.im_pl[nxt],
                    ctx.b.pll_poly[r.buf], ctx.b.pll_poly[nxt], iq ? ctx.b.pll_dt[r.buf] : (float*)nullptr, ctx.b.state, ctx.loops, ctx.b.pilot_tab, ctx.b.span_tab, ctx.b.spec_stats);
         if (iq) FMD_LAUNCH(r, false, true, k_planes_to_iq, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, ctx.b.fo_pl[r.buf], ctx.b.im_pl[r.buf],
                            ctx.b.fm_out_iq[r.buf]);
