@@ -80,6 +80,7 @@ struct FrontGeom {
 // by tools/mfma_bf16_probe.hip) come ready-made from the host (FrontMfmaTab).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+static constexpr f32x4 kZero4 = {0.f, 0.f, 0.f, 0.f};
 template <int TT, int WU>
 struct FrontGeomM {
     static constexpr int T = TT, NF = T + 64 + WU, NW = 2 * NF + 63, TAIL = 191 + 2 * WU;
@@ -301,13 +302,13 @@ __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restric
 #pragma unroll
         for (int r = 0; r < PER; r++) {
             const int i = tid + 256 * r;
-            if (i < NW) theta[i] = fast_atan2f(buf[r].y, buf[r].x);
+            if (i < NW) theta[i] = fast_atan2_turns(buf[r].y, buf[r].x);      // phases in turns: the wrap below is x - rint(x)
         }
     }
     __syncthreads();
     // phase difference, wrap, scale: two samples per thread and step, split into bf16 halves, in place over the phases
     {
-        const float pi = bits_f32(kPiBits), two_pi = bits_f32(kTwoPiBits);
+        const float gain_t = fm_gain * bits_f32(kTwoPiBits);           // the discriminator's gain per turn
         constexpr int NPW = G::NWB / 2;                              // words per half
         constexpr int PERP = (NPW + 255) / 256;
         uint32_t wh[PERP], wl[PERP];
@@ -318,9 +319,8 @@ __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restric
             if (j < NW - 1) {
                 const float t0 = theta[j], t1 = theta[j + 1], t2 = (j + 2 < NW) ? theta[j + 2] : t1;
                 float d0 = t1 - t0, d1 = t2 - t1;
-                d0 = (d0 >= pi) ? d0 - two_pi : ((d0 <= -pi) ? d0 + two_pi : d0);
-                d1 = (d1 >= pi) ? d1 - two_pi : ((d1 <= -pi) ? d1 + two_pi : d1);
-                d0 *= fm_gain; d1 = (j + 1 < NW - 1) ? d1 * fm_gain : 0.0f;
+                d0 = d0 - rintf(d0); d1 = d1 - rintf(d1);           // reference fm_demod.cpp:36-43: the phase difference wrapped to half a turn
+                d0 *= gain_t; d1 = (j + 1 < NW - 1) ? d1 * gain_t : 0.0f;
                 uint32_t h0, l0, h1, l1;
                 split_bf16(d0, h0, l0); split_bf16(d1, h1, l1);
                 wh[r] = pack_hi16(h0, h1); wl[r] = pack_hi16(l0, l1);
@@ -338,15 +338,15 @@ __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restric
     for (int ct = wv; ct * 16 < G::NCOL; ct += 4) {
         const int col = ct * 16 + lrow, colr = col < G::NCOL ? col : G::NCOL - 1;
         // (round 3, PMC: a wavefront of this kernel spent 37 % of its cycles waiting for the previous MFMA of one nine-long chain)
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
+        f32x4 acc, acc1, acc2;   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
 #pragma unroll
         for (int sK = 0; sK < 3; sK++) {
             const int e = 32 * colr + 32 * sK + 8 * lq;              // bf16 element index, a multiple of 8
             const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(dem_hi32 + e / 2));
             const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(dem_lo32 + e / 2));
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bh, acc, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adl[sK], bh, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bl, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bh, sK ? acc : kZero4, 0, 0, 0);      // (the first step starts from the constant 0: no registers to clear)
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adl[sK], bh, sK ? acc1 : kZero4, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bl, sK ? acc2 : kZero4, 0, 0, 0);
         }
         acc = acc + (acc1 + acc2);
         if (col < G::NCOL) *reinterpret_cast<float4*>(fo + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -409,15 +409,15 @@ __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restric
         }
         for (int ct = wv; ct * 256 < T; ct += 4) {
             const int col = ct * 16 + lrow;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
+            f32x4 acc, acc1, acc2;   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
 #pragma unroll
             for (int sK = 0; sK < 3; sK++) {
                 const int e = WU + 16 * col + 32 * sK + 8 * lq;
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fo_hi32 + e / 2));
                 const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fo_lo32 + e / 2));
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahh[sK], bh, acc, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahl[sK], bh, acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahh[sK], bl, acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahh[sK], bh, sK ? acc : kZero4, 0, 0, 0);      // (the first step starts from the constant 0: no registers to clear)
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahl[sK], bh, sK ? acc1 : kZero4, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahh[sK], bl, sK ? acc2 : kZero4, 0, 0, 0);
             }
             acc = acc + (acc1 + acc2);
             // planar: fm_out itself (the consumers delay it by 32 for the real rail) and the Hilbert rail
@@ -1626,7 +1626,7 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
         for (int r = 0; r < PERP; r++) {
             const int u0 = (s_lo + 2 * (tid + 256 * r)) & (kSpan - 1);
             const float ua = (float)u0, ub = (float)(u0 + 1);
-            const float fa_ = (float)((19 * (u0 + 1)) & 127) * (1.0f / 128.0f), fb_ = (float)((19 * (u0 + 2)) & 127) * (1.0f / 128.0f);
+            const float fa_ = __builtin_amdgcn_fractf(ub * (19.0f / 128.0f)), fb_ = __builtin_amdgcn_fractf((ub + 1.0f) * (19.0f / 128.0f));   // exact: multiples of 1/128 below 20
             dv[r] = make_float2(fmaf(fmaf(fmaf(pv[r].w, ua, pv[r].z), ua, pv[r].y), ua, pv[r].x) - fa_,
                                 fmaf(fmaf(fmaf(pv[r].w, ub, pv[r].z), ub, pv[r].y), ub, pv[r].x) - fb_);
         }
@@ -1649,7 +1649,7 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
         for (int r = 0; r < PERP; r++) {
             const int e = 2 * (tid + 256 * r);
             if (e < XSP + 4) {
-                const bool live = e < XS, hist = s_lo + e < 0;       // history samples were mixed with last block's offset
+                const bool hist = s_lo + e < 0;                      // history samples were mixed with last block's offset
                 const float co = hist ? co_prev : co_cur, so = hist ? so_prev : so_cur;
                 float lp[2], m2r[2], m2i[2], m3r[2], m3i[2];
 #pragma unroll
@@ -1659,9 +1659,10 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
                     const float c2 = fmaf(c1, c1, -(s1 * s1)), s2 = (c1 + c1) * s1;
                     const float c2o = fmaf(c2, co, -(s2 * so)), s2o = fmaf(s2, co, c2 * so);
                     const float c3 = fmaf(c2, c1, -(s2 * s1)), s3 = fmaf(s2, c1, c2 * s1);
-                    lp[u] = live ? xr : 0.0f;
-                    m2r[u] = live ? fmaf(c2o, xr, -(xi * s2o)) : 0.0f; m2i[u] = live ? fmaf(c2o, xi, xr * s2o) : 0.0f;
-                    m3r[u] = live ? fmaf(c3, xr, -(xi * s3)) : 0.0f; m3i[u] = live ? fmaf(c3, xi, xr * s3) : 0.0f;
+                    // (pairs past the staged samples were never loaded: xr = xi = 0 and every product below is 0)
+                    lp[u] = xr;
+                    m2r[u] = fmaf(c2o, xr, -(xi * s2o)); m2i[u] = fmaf(c2o, xi, xr * s2o);
+                    m3r[u] = fmaf(c3, xr, -(xi * s3)); m3i[u] = fmaf(c3, xi, xr * s3);
                 }
                 uint32_t h0, l0, h1, l1;
                 if (e < XSP) {
@@ -1688,7 +1689,7 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
         const uint4* img = aud_img + (size_t)(wv ? slot.y : slot.x) * (6 * 2 * kWave);
         const uint32_t* sh = wv ? lmr_h : lpr_h;
         const uint32_t* sl = wv ? lmr_l : lpr_l;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
+        f32x4 acc, acc1, acc2;   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
 #pragma unroll
         for (int sK = 0; sK < 6; sK++) {
             const bf16x8 ah = __builtin_bit_cast(bf16x8, img[(sK * 2 + 0) * kWave + lane]);
@@ -1696,9 +1697,9 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
             const int e = 64 * lrow + 32 * sK + 8 * lq, w4 = (e + 8 * (2 * lrow + sK)) >> 1;
             const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sh + w4));
             const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sl + w4));
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, sK ? acc : kZero4, 0, 0, 0);      // (the first step starts from the constant 0: no registers to clear)
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, sK ? acc1 : kZero4, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, sK ? acc2 : kZero4, 0, 0, 0);
         }
         acc = acc + (acc1 + acc2);
         *reinterpret_cast<float4*>((wv ? res_lmr : res_lpr) + 16 * lrow + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -1707,7 +1708,7 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
         const int rail = lrow >> 3, colr = lrow & 7;
         const uint32_t* sh = rail ? rim_h : rre_h;
         const uint32_t* sl = rail ? rim_l : rre_l;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
+        f32x4 acc, acc1, acc2;   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
 #pragma unroll
         for (int sK = 0; sK < 8; sK++) {
             const bf16x8 ah = __builtin_bit_cast(bf16x8, rds_img[(sK * 2 + 0) * kWave + lane]);
@@ -1715,9 +1716,9 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
             const int e = 128 * colr + 32 * sK + 8 * lq, w8 = (e + 8 * (4 * colr + sK)) >> 1;
             const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sh + w8));
             const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sl + w8));
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, sK ? acc : kZero4, 0, 0, 0);      // (the first step starts from the constant 0: no registers to clear)
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, sK ? acc1 : kZero4, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, sK ? acc2 : kZero4, 0, 0, 0);
         }
         acc = acc + (acc1 + acc2);
 #pragma unroll

@@ -407,6 +407,30 @@ FMD_HD float fast_atan2f(float y, float x) {
     return bits_f32((f32_bits(r) & 0x7fffffffu) | (f32_bits(y) & 0x80000000u));
 }
 
+// The same in TURNS (atan2 / 2 pi, in (-1/2, 1/2]): the polynomial's coefficients carry the 1 / 2 pi, the octant folding uses 1/4 and
+// 1/2.  For phases that are only ever differenced and wrapped (the discriminator: wrap = x - rint(x)) or added to an NCO phase in turns.
+FMD_HD float fast_atan2_turns(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(fmaxf(ax, ay), 1.0e-37f), mn = fminf(ax, ay);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float a = mn * __builtin_amdgcn_rcpf(mx);
+#else
+    const float a = mn / mx;
+#endif
+    const float z = a * a;
+    float p = fmaf(-0.00405453285202384f * 0.15915494309189535f, z, 0.021862823516130447f * 0.15915494309189535f);
+    p = fmaf(p, z, -0.055912118405103683f * 0.15915494309189535f);
+    p = fmaf(p, z, 0.09642180055379868f * 0.15915494309189535f);
+    p = fmaf(p, z, -0.13908621668815613f * 0.15915494309189535f);
+    p = fmaf(p, z, 0.19946563243865967f * 0.15915494309189535f);
+    p = fmaf(p, z, -0.33329859375953674f * 0.15915494309189535f);
+    p = fmaf(p, z, 0.9999993443489075f * 0.15915494309189535f);
+    float r = p * a;
+    r = (ay > ax) ? (0.25f - r) : r;
+    r = (f32_bits(x) >> 31) ? (0.5f - r) : r;
+    return bits_f32((f32_bits(r) & 0x7fffffffu) | (f32_bits(y) & 0x80000000u));
+}
+
 // sin(2 pi t), cos(2 pi t) for t in turns (|t| <= 256: no range reduction needed for the phases of this chain)
 FMD_HD float fast_sin_turns(float t) {
 #if defined(__HIP_DEVICE_COMPILE__)
