@@ -99,7 +99,8 @@ __device__ __forceinline__ void split_bf16(float x, uint32_t& hi, uint32_t& lo) 
     hi = f32_bits(x) & 0xffff0000u;
     lo = f32_bits(x - bits_f32(hi));
 }
-__device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xffff0000u); }   // bf16(a) low, bf16(b) high
+// bf16(a) low, bf16(b) high: one v_perm_b32 (bytes 2, 3 of a and bytes 2, 3 of b) instead of a shift and an and-or
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
 __device__ __forceinline__ float2 load_iq(const float2* p, unsigned i) {
     return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p) + (size_t)(unsigned)(i * 8u));
@@ -1611,8 +1612,6 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
 #pragma unroll
         for (int r = 0; r < PERP; r++) {
             const int e = 2 * (tid + 256 * r);
-            xv[r] = make_float4(0.f, 0.f, 0.f, 0.f); dv[r] = make_float2(0.f, 0.f);
-            pv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < XS) {
                 const int sx = s_lo + e;                     // even, >= -124
                 const float2 re2 = *reinterpret_cast<const float2*>(fo_c + (sx - 32));
@@ -1645,10 +1644,16 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
         }
         const float co_cur = fast_cos_turns(off_cur), so_cur = fast_sin_turns(off_cur);
         const float co_prev = fast_cos_turns(off_prev), so_prev = fast_sin_turns(off_prev);
+        // the zero padding behind the staged samples, up to the reach of the Toeplitz operands
+        if (tid < (XSP + 4 - XS) / 2) {
+            const int e = XS + 2 * tid;
+            if (e < XSP) { const int w4 = G::pad(e) >> 1; lpr_h[w4] = 0u; lpr_l[w4] = 0u; lmr_h[w4] = 0u; lmr_l[w4] = 0u; *reinterpret_cast<float2*>(lmr_re + e) = make_float2(0.f, 0.f); }
+            const int w8 = G::pad(e - 4) >> 1; rre_h[w8] = 0u; rre_l[w8] = 0u; rim_h[w8] = 0u; rim_l[w8] = 0u;
+        }
 #pragma unroll
         for (int r = 0; r < PERP; r++) {
             const int e = 2 * (tid + 256 * r);
-            if (e < XSP + 4) {
+            if (e < XS) {
                 const bool hist = s_lo + e < 0;                      // history samples were mixed with last block's offset
                 const float co = hist ? co_prev : co_cur, so = hist ? so_prev : so_cur;
                 float lp[2], m2r[2], m2i[2], m3r[2], m3i[2];
@@ -1659,7 +1664,6 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
                     const float c2 = fmaf(c1, c1, -(s1 * s1)), s2 = (c1 + c1) * s1;
                     const float c2o = fmaf(c2, co, -(s2 * so)), s2o = fmaf(s2, co, c2 * so);
                     const float c3 = fmaf(c2, c1, -(s2 * s1)), s3 = fmaf(s2, c1, c2 * s1);
-                    // (pairs past the staged samples were never loaded: xr = xi = 0 and every product below is 0)
                     lp[u] = xr;
                     m2r[u] = fmaf(c2o, xr, -(xi * s2o)); m2i[u] = fmaf(c2o, xi, xr * s2o);
                     m3r[u] = fmaf(c3, xr, -(xi * s3)); m3i[u] = fmaf(c3, xi, xr * s3);
