@@ -110,6 +110,11 @@ __device__ __forceinline__ float2 load_iq(const uchar2* p, unsigned i) {
     return make_float2((float)v.x - 127.0f, (float)v.y - 127.0f);  // reference src/app.cpp:56-62
 }
 
+// tolerance mode behind the first decimator: the stream is already the samples' phases in turns (k_predecim<.., true>)
+__device__ __forceinline__ float2 load_iq(const float* p, unsigned i) {
+    return make_float2(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + (size_t)(unsigned)(i * 4u)), 0.0f);
+}
+
 // two consecutive samples with one load
 __device__ __forceinline__ float4 load_iq2(const float2* p, size_t i) { return *reinterpret_cast<const float4*>(p + i); }
 __device__ __forceinline__ float4 load_iq2(const uchar2* p, size_t i) {
@@ -303,7 +308,10 @@ __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restric
 #pragma unroll
         for (int r = 0; r < PER; r++) {
             const int i = tid + 256 * r;
-            if (i < NW) theta[i] = fast_atan2_turns(buf[r].y, buf[r].x);      // phases in turns: the wrap below is x - rint(x)
+            if (i < NW) {   // phases in turns: the wrap below is x - rint(x)
+                if constexpr (sizeof(InT) == 4) theta[i] = buf[r].x;      // (1.024 / 2.048 MSa/s: k_predecim has taken the arctangent)
+                else theta[i] = fast_atan2_turns(buf[r].y, buf[r].x);
+            }
         }
     }
     __syncthreads();
@@ -456,7 +464,9 @@ struct PredecimGeom {
     static constexpr int HIST = 64;                   // input samples of history kept per channel (64 - M are used)
 };
 
-template <int M, typename InT>
+// THETA (tolerance mode): the discriminator's arctangent is taken here and fm_in is the samples' PHASES in turns, 4 bytes instead
+// of 8 — this kernel is bandwidth-bound on cf32 input and has the VALU to spare, and the round trip of fm_in through HBM halves
+template <int M, typename InT, bool THETA = false>
 __global__ __launch_bounds__(256) void k_predecim(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
                                                   float2* __restrict__ tail_out, float2* __restrict__ fm_in, FrontTaps taps) {
     using G = PredecimGeom<M>;
@@ -526,7 +536,10 @@ __global__ __launch_bounds__(256) void k_predecim(Dims d, const InT* __restrict_
         float4 o;
         o.x = (ar[0][0] + ar[0][2]) + (ar[0][1] + ar[0][3]); o.y = (ai[0][0] + ai[0][2]) + (ai[0][1] + ai[0][3]);
         o.z = (ar[1][0] + ar[1][2]) + (ar[1][1] + ar[1][3]); o.w = (ai[1][0] + ai[1][2]) + (ai[1][1] + ai[1][3]);
-        *reinterpret_cast<float4*>(fm_in + (size_t)c * d.n_fm_in + n0 + il) = o;
+        if constexpr (THETA)
+            *reinterpret_cast<float2*>(reinterpret_cast<float*>(fm_in) + (size_t)c * d.n_fm_in + n0 + il) = make_float2(fast_atan2_turns(o.y, o.x), fast_atan2_turns(o.w, o.z));
+        else
+            *reinterpret_cast<float4*>(fm_in + (size_t)c * d.n_fm_in + n0 + il) = o;
     }
     // the last 64 input samples of the block are the next block's history
     if (tile == tiles - 1 && tid < G::HIST) tail_out[(size_t)c * G::HIST + tid] = load_iq(in_c, (unsigned)(d.N - G::HIST + tid));
@@ -2364,8 +2377,12 @@ template <int M, typename InT>
 static hipError_t launch_predecim(const LaunchCtx& ctx, SlotRef r, const InT* d_iq, hipStream_t s) {
     const Dims& d = ctx.d;
     using G = PredecimGeom<M>;
-    FMD_LAUNCH(r, true, true, (k_predecim<M, InT>), dim3((unsigned)(d.n_fm_in / G::TP * d.C)), dim3(256), 0, s, d, d_iq, ctx.b.pre_tail[r.par], ctx.b.pre_tail[r.par ^ 1],
-               ctx.b.fm_in[r.buf], ctx.front);
+    if (ctx.fast)
+        FMD_LAUNCH(r, true, true, (k_predecim<M, InT, true>), dim3((unsigned)(d.n_fm_in / G::TP * d.C)), dim3(256), 0, s, d, d_iq, ctx.b.pre_tail[r.par], ctx.b.pre_tail[r.par ^ 1],
+                   ctx.b.fm_in[r.buf], ctx.front);
+    else
+        FMD_LAUNCH(r, true, true, (k_predecim<M, InT, false>), dim3((unsigned)(d.n_fm_in / G::TP * d.C)), dim3(256), 0, s, d, d_iq, ctx.b.pre_tail[r.par], ctx.b.pre_tail[r.par ^ 1],
+                   ctx.b.fm_in[r.buf], ctx.front);
     return hipGetLastError();
 }
 
@@ -2385,6 +2402,7 @@ hipError_t launch_stage_front(const LaunchCtx& ctx, SlotRef r, const void* d_iq,
     if (ctx.d.m > 1) {
         LaunchCtx c1 = ctx;
         c1.d.N = ctx.d.n_fm_in; c1.d.m = 1;
+        if (ctx.fast) return launch_front<float>(c1, r, reinterpret_cast<const float*>(ctx.b.fm_in[r.buf]), s);   // (phases: k_predecim<.., true>)
         return launch_front<float2>(c1, r, ctx.b.fm_in[r.buf], s);
     }
     if (u8) return launch_front<uchar2>(ctx, r, static_cast<const uchar2*>(d_iq), s);
@@ -2529,6 +2547,8 @@ hipError_t prepare_kernels() {
     if ((e = prepare_front<float2, 1024>()) != hipSuccess) return e;
     if ((e = prepare_front<uchar2>()) != hipSuccess) return e;
     if ((e = prepare_front<uchar2, 1024>()) != hipSuccess) return e;
+    if ((e = prepare_front<float>()) != hipSuccess) return e;
+    if ((e = prepare_front<float, 1024>()) != hipSuccess) return e;
     return hipSuccess;
 }
 
