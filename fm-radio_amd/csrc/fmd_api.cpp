@@ -27,7 +27,7 @@ using namespace fmd;
 enum Stage { ST_FRONT = 0, ST_DEEMPH, ST_POWER, ST_PLL, ST_EXTRACT, ST_RDS, ST_PREDECIM, ST_COUNT };
 static const char* const kStageName[ST_COUNT] = {"k_front", "k_deemphasis+k_hilbert", "k_pilot_power", "k_pilot_pll", "k_extract", "k_rds_sync", "k_predecim"};
 // ... and of the tolerance mode's kernels, as they appear in rocprofv3 kernel traces
-static const char* const kStageNameFast[ST_COUNT] = {"k_front_mfma", "k_deemphasis+k_hilbert", "k_pilot_power", "k_pll_span", "k_extract_mfma", "k_rds_sync", "k_predecim"};
+static const char* const kStageNameFast[ST_COUNT] = {"k_front_mfma", "k_deemphasis", "k_pilot_power", "k_pll_span", "k_extract_mfma", "k_rds_sync", "k_predecim"};
 
 struct ProfiledBlock { hipEvent_t t0[ST_COUNT], t1[ST_COUNT]; bool used[ST_COUNT]; };
 
@@ -306,6 +306,7 @@ void design_pll_span(const fmd_coeffs& k, PllSpanTab* t) {
     for (int i = 0; i < 65; i++) { hr += k.b_hilbert[i] * std::cos(w0 * i); hi += k.b_hilbert[i] * std::sin(w0 * i); }
     t->quad = (float)(std::sqrt(hr * hr + hi * hi) / (2.0 * std::sin(w0)));
     t->kappa = (float)(-19000.0 * Ts + 19.0 / 128.0);
+    for (int i = 0; i < 32; i++) t->hil[i] = k.b_hilbert[2 * i + 1];
 }
 
 void design_front_mfma(const fmd_coeffs& k, std::vector<uint16_t>& img) {
@@ -342,7 +343,6 @@ int zero_history(fmd_handle h, hipStream_t s) {
     for (int p = 0; p < kSlots; p++) {
         if (b.fo_pl[p]) {   // the history in front of the planes' rows (and the rows themselves)
             HIP_TRY(h, hipMemsetAsync(b.fo_pl[p], 0, sizeof(float) * (size_t)d.C * ((size_t)kFoPad + d.n_fm_out), s));
-            HIP_TRY(h, hipMemsetAsync(b.im_pl[p], 0, sizeof(float) * (size_t)d.C * ((size_t)kImPad + d.n_fm_out), s));
             HIP_TRY(h, hipMemsetAsync(b.pll_poly[p], 0, sizeof(float4) * (size_t)d.C * ((size_t)1 + d.n_fm_out / kSpan), s));
         }
         HIP_TRY(h, hipMemsetAsync(b.rds_count[p], 0, sizeof(int) * (size_t)d.C, s));
@@ -677,7 +677,6 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
         if (!rc && !fast) rc = dev_alloc(h, &b.pilot[p], C * d.n_fm_out);   // (fast mode never materialises the pilot stream)
         if (!rc && streams) rc = dev_alloc(h, &b.pll_dt[p], C * d.n_fm_out);
         if (!rc && fast) rc = dev_alloc(h, &b.fo_pl[p], C * ((size_t)kFoPad + d.n_fm_out));
-        if (!rc && fast) rc = dev_alloc(h, &b.im_pl[p], C * ((size_t)kImPad + d.n_fm_out));
         if (!rc && fast) rc = dev_alloc(h, &b.pll_poly[p], C * ((size_t)1 + d.n_fm_out / kSpan));
         if (!rc && fast) rc = dev_alloc(h, &b.rds_pow[p], C * (size_t)(2 * (d.n_audio / 256) + 2));
         if (!rc) rc = dev_alloc(h, &b.audio[p], C * d.n_audio * 2);
@@ -991,7 +990,6 @@ std::vector<StatePart> state_parts(fmd_handle h) {
     { void* p[2] = {b.lmr_est[0], b.lmr_est[1]}; by_par(p, (size_t)d.n_est, 1); }   // the newest block's L-R phase estimates (the next k_extract integrates them)
     if (b.fo_pl[0]) {       // tolerance mode: the previous block's tails in front of the next slot's rows (k_pll_span)
         v.push_back({b.fo_pl[slot], (size_t)kFoPad, (size_t)kFoPad + d.n_fm_out});
-        v.push_back({b.im_pl[slot], (size_t)kImPad, (size_t)kImPad + d.n_fm_out});
         v.push_back({reinterpret_cast<float*>(b.pll_poly[slot]), 4, 4 * ((size_t)1 + d.n_fm_out / kSpan)});
     }
     return v;

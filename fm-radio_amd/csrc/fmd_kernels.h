@@ -78,11 +78,11 @@ struct PllSpanTab {
     float quad;                      // quadrature of the filtered pilot's real rail P: im[n] = quad (P[n-1] - P[n+1]) (Hilbert FIR gain at 19 kHz / (2 sin w0))
     float kappa;                     // -19000 Ts + 19/128 with Ts = (float)(1 / 128000) as the reference's NCO has it: 7e-9 turns per sample, 9e-4 Hz
     float pad[2];
+    float hil[32];                   // the Hilbert FIR's non-zero taps b[1], b[3], ... (a station's warm-up makes that rail for itself)
 };
 // rows of the fast-mode planes carry the previous block's last samples in front (written by k_pll_span of that block), so the
 // consumers address history and block uniformly
-static constexpr int kFoPad = 160;   // fm_out: k_extract_mfma reaches back 124 + 32 samples, k_pll_span 33
-static constexpr int kImPad = 128;   // Hilbert rail: 124
+static constexpr int kFoPad = 192;   // fm_out: k_extract_mfma reaches back 124 + 64 samples (its Hilbert FIR), k_pll_span 33 (65 while a station warms up)
 
 struct Dims {
     int C;          // channels
@@ -139,7 +139,6 @@ struct Buffers {
     float*  state;          // [S_NUM_FIELDS][C]
     // FMD_FLAG_FAST_MATH (round 3): planar analytic signal and the PLL's span polynomials
     float*  fo_pl[kSlots];           // [C][kFoPad + n_fm_out]  fm_out (the analytic signal's real rail is this delayed by 32)
-    float*  im_pl[kSlots];           // [C][kImPad + n_fm_out]  Hilbert rail, aligned with the delayed real rail
     float4* pll_poly[kSlots];        // [C][1 + n_fm_out / kSpan]  NCO phase of a span: c0 + c1 u + c2 u^2 + c3 u^3 - frac(19 (u + 1) / 128), u = sample in span
     float*  rds_pow[kSlots];         // [C][2 n_audio / 256]  partial sums of |rds|^2 (k_extract_mfma -> k_rds_sync's AGC)
     PllSpanTab* span_tab;

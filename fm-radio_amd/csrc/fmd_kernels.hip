@@ -83,16 +83,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static constexpr f32x4 kZero4 = {0.f, 0.f, 0.f, 0.f};
 template <int TT, int WU>
 struct FrontGeomM {
-    static constexpr int T = TT, NF = T + 64 + WU, NW = 2 * NF + 63, TAIL = 191 + 2 * WU;
+    static constexpr int T = TT, NF = T + WU, NW = 2 * NF + 63, TAIL = 63 + 2 * WU;   // (no Hilbert history: k_extract_mfma takes that FIR)
     static constexpr int NWB = (NW + 8 + 7) & ~7;        // bf16 elements per half (hi / lo) of the discriminator output, zero padded
-    static constexpr int NFB = NF + 16;                  // ... of fm_out
     static constexpr int OFF_THETA = 0;                  // [NW] floats; then, in place: dem_hi [NWB] bf16, dem_lo [NWB] bf16
-    static constexpr int OFF_FO = NWB;                   // fm_out fp32 [NF]
-    static constexpr int OFF_FOB = OFF_FO + NF;          // fo_hi [NFB] bf16, fo_lo [NFB] bf16
-    static constexpr int OFF_ZS = OFF_FOB + NFB;         // WU > 0: segment end states of the de-emphasis IIR
-    static constexpr int LDS_FLOATS = OFF_ZS + (WU > 0 ? NF / 8 + 16 : 0);
+    static constexpr int OFF_FO = NWB;                   // WU > 0: fm_out fp32 [NF], and the segment end states of the de-emphasis IIR
+    static constexpr int OFF_ZS = OFF_FO + NF;
+    static constexpr int LDS_FLOATS = WU > 0 ? OFF_ZS + NF / 8 + 16 : NWB;
     static constexpr int NCOL = NF / 16;
-    static_assert(NF % 16 == 0 && NWB % 8 == 0 && OFF_FO % 4 == 0 && OFF_FOB % 4 == 0 && NWB >= NW + 1, "alignment");
+    static_assert(NF % 16 == 0 && NWB % 8 == 0 && OFF_FO % 4 == 0 && NWB >= NW + 1, "alignment");
 };
 // x = hi + lo (+ O(2^-16 x)), both halves as bf16 bit patterns in the upper 16 bits of a float
 __device__ __forceinline__ void split_bf16(float x, uint32_t& hi, uint32_t& lo) {
@@ -252,14 +250,14 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
 }
 
 // =============================================================================================
-// k_front_mfma — FMD_FLAG_FAST_MATH form of k_front: same stages, same tiles, same history; the minimax arctangent, and both FIRs
-// as bf16 x 3 matrix products (FrontGeomM above).  WU > 0: with the de-emphasis IIR inside the tile (see k_front).
+// k_front_mfma — FMD_FLAG_FAST_MATH form of k_front up to fm_out: the minimax arctangent (in turns), the decimating FIR as a
+// bf16 x 3 matrix product (FrontGeomM above); WU > 0: with the de-emphasis IIR inside the tile (see k_front).  The Hilbert FIR is
+// k_extract_mfma's: the analytic signal never goes through HBM, only fm_out does (4 bytes per sample instead of 8).
 // =============================================================================================
 template <typename InT, int TT, int WU>
 __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
-                                                    float2* __restrict__ tail_out, float* __restrict__ fo_pl, float* __restrict__ im_pl,
-                                                    float* __restrict__ fo_tail_out, float fm_gain,
-                                                    int deemph_path, const float* __restrict__ deemph, const uint4* __restrict__ tab) {
+                                                    float2* __restrict__ tail_out, float* __restrict__ fo_pl, float fm_gain,
+                                                    const float* __restrict__ deemph, const uint4* __restrict__ tab) {
     using G = FrontGeomM<TT, WU>;
     constexpr int T = G::T, NW = G::NW, NF = G::NF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -267,8 +265,6 @@ __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restric
     uint32_t* dem_hi32 = reinterpret_cast<uint32_t*>(smem);                        // two bf16 per word
     uint32_t* dem_lo32 = dem_hi32 + G::NWB / 2;
     float* fo = smem + G::OFF_FO;
-    uint32_t* fo_hi32 = reinterpret_cast<uint32_t*>(smem + G::OFF_FOB);
-    uint32_t* fo_lo32 = fo_hi32 + G::NFB / 2;
 
     const int tiles = d.n_fm_out / T;
     const int c = blockIdx.x / tiles, tile = blockIdx.x % tiles, o0 = tile * T, tid = threadIdx.x;
@@ -277,7 +273,7 @@ __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restric
     const InT* in_c = in + (size_t)c * d.N;
     const float2* tail_c = tail_in + (size_t)c * d.tail_base + (d.tail_base - G::TAIL);
 
-    // the Toeplitz operands of the decimating FIR (the Hilbert FIR's are fetched when its turn comes)
+    // the Toeplitz operands of the decimating FIR
     bf16x8 adh[3], adl[3];
 #pragma unroll
     for (int sK = 0; sK < 3; sK++) {
@@ -343,7 +339,10 @@ __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restric
         }
     }
     __syncthreads();
-    // a3: decimate-by-2 FIR: wavefront w takes the 16-column tiles w, w + 4, ... (a column = 16 consecutive outputs)
+    // a3: decimate-by-2 FIR: wavefront w takes the 16-column tiles w, w + 4, ... (a column = 16 consecutive outputs).
+    // fm_out goes to its plane undelayed (the rows start with the previous block's tail, k_pll_span); the consumers delay it by 32
+    // for the real rail and k_extract_mfma makes the Hilbert rail from it.
+    float* fo_row = fo_pl + (size_t)c * (kFoPad + d.n_fm_out) + kFoPad + o0;
     for (int ct = wv; ct * 16 < G::NCOL; ct += 4) {
         const int col = ct * 16 + lrow, colr = col < G::NCOL ? col : G::NCOL - 1;
         // (round 3, PMC: a wavefront of this kernel spent 37 % of its cycles waiting for the previous MFMA of one nine-long chain)
@@ -358,17 +357,13 @@ __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restric
             acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bl, sK ? acc2 : kZero4, 0, 0, 0);
         }
         acc = acc + (acc1 + acc2);
-        if (col < G::NCOL) *reinterpret_cast<float4*>(fo + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    }
-    __syncthreads();
-    float* fo_row = fo_pl + (size_t)c * (kFoPad + d.n_fm_out) + kFoPad + o0;   // the planes' rows start with the previous block's tail (k_pll_span)
-    if constexpr (WU == 0) {
-        if (deemph_path) {   // a time constant beyond the in-tile form: hand fm_out to the k_deemphasis + k_hilbert_plane stage
-            for (int uu = 64 + 4 * tid; uu < NF; uu += 1024)
-                *reinterpret_cast<float4*>(fo_row + (uu - 64)) = *reinterpret_cast<const float4*>(fo + uu);
+        if (col < G::NCOL) {
+            if constexpr (WU == 0) *reinterpret_cast<float4*>(fo_row + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);   // a wavefront: 4 KB in a row
+            else *reinterpret_cast<float4*>(fo + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
     }
     if constexpr (WU > 0) {
+        __syncthreads();
         // a4 in the tile (see k_front): 8 samples per thread from a zero state, end states through LDS, 16 segments of history
         const float b0 = deemph[4 * c + 0], b1 = deemph[4 * c + 1], a0 = deemph[4 * c + 2];
         if (deemph[4 * c + 3] != 0.0f) {
@@ -398,47 +393,11 @@ __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restric
             }
             __syncthreads();
         }
-    }
-    // fm_out into bf16 halves for the Hilbert FIR (zero padded behind the tile)
-    for (int q4 = tid; q4 < G::NFB / 4; q4 += 256) {
-        const float4 v = (4 * q4 < NF) ? *reinterpret_cast<const float4*>(fo + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        uint32_t h0, l0, h1, l1, h2, l2, h3, l3;
-        split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
-        *reinterpret_cast<uint2*>(fo_hi32 + 2 * q4) = make_uint2(pack_hi16(h0, h1), pack_hi16(h2, h3));
-        *reinterpret_cast<uint2*>(fo_lo32 + 2 * q4) = make_uint2(pack_hi16(l0, l1), pack_hi16(l2, l3));
-    }
-    __syncthreads();
-    // a5: Hilbert FIR, same form; the real rail is fm_out delayed by 32
-    if (WU > 0 || !deemph_path) {
-        bf16x8 ahh[3], ahl[3];
-#pragma unroll
-        for (int sK = 0; sK < 3; sK++) {
-            ahh[sK] = __builtin_bit_cast(bf16x8, tab[(6 + sK * 2 + 0) * kWave + lane]);
-            ahl[sK] = __builtin_bit_cast(bf16x8, tab[(6 + sK * 2 + 1) * kWave + lane]);
-        }
-        for (int ct = wv; ct * 256 < T; ct += 4) {
-            const int col = ct * 16 + lrow;
-            f32x4 acc, acc1, acc2;   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
-#pragma unroll
-            for (int sK = 0; sK < 3; sK++) {
-                const int e = WU + 16 * col + 32 * sK + 8 * lq;
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fo_hi32 + e / 2));
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fo_lo32 + e / 2));
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahh[sK], bh, sK ? acc : kZero4, 0, 0, 0);      // (the first step starts from the constant 0: no registers to clear)
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahl[sK], bh, sK ? acc1 : kZero4, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahh[sK], bl, sK ? acc2 : kZero4, 0, 0, 0);
-            }
-            acc = acc + (acc1 + acc2);
-            // planar: fm_out itself (the consumers delay it by 32 for the real rail) and the Hilbert rail
-            const int oo = 16 * col + 4 * lq;
-            *reinterpret_cast<float4*>(fo_row + oo) = *reinterpret_cast<const float4*>(fo + WU + 64 + oo);
-            *reinterpret_cast<float4*>(im_pl + (size_t)c * (kImPad + d.n_fm_out) + kImPad + o0 + oo) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        }
+        for (int q4 = tid; q4 < T / 4; q4 += 256) *reinterpret_cast<float4*>(fo_row + 4 * q4) = *reinterpret_cast<const float4*>(fo + WU + 4 * q4);
     }
     if (tile == tiles - 1) {
         float2* tout = tail_out + (size_t)c * d.tail_base;
         for (int idx = tid; idx < d.tail_base; idx += 256) tout[idx] = load_iq(in_c, (unsigned)(d.N - d.tail_base + idx));
-        if (WU == 0 && !deemph_path && tid < 64) fo_tail_out[(size_t)c * 64 + tid] = fo[T + tid];
     }
 }
 
@@ -1573,13 +1532,17 @@ __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict
 // Wavefront 0: L+R, 1: L-R, 2: RDS, 3: the real rail of every 10th L-R output for the phase estimate (VALU, as before).
 // =============================================================================================
 struct ExtractGeomM {
-    static constexpr int TA = 256, XS = 4 * TA + 124, XSP = 1152;         // staged samples, padded with zeros to the operands' reach
+    static constexpr int TA = 256, XS = 4 * TA + 124, XSP = 1152;         // staged analytic samples, padded with zeros to the operands' reach
     static constexpr int NB = XSP + 8 * (XSP >> 5);                       // bf16 elements per half-array with the padding
     static constexpr int NEST = TA / 10 + 2;
+    // fm_out window W[i] = fm_out[s_lo - 64 + i]: the Hilbert FIR's reach in front of the first staged sample, zero padded to the
+    // reach of the dummy columns of its fifth tile (16 * 79 + 64 + 24 + 8)
+    static constexpr int WN = XS + 64, WNP = 1376, NBWW = (WNP + 8 * (WNP >> 5)) / 2;   // words per bf16 half-array of W
     __device__ static __forceinline__ int pad(int i) { return i + 8 * (i >> 5); }
+    static_assert(WNP % 32 == 0 && WNP >= 16 * 79 + 64 + 24 + 8, "reach of the Hilbert operand");
 };
 
-__global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __restrict__ fo_pl, const float* __restrict__ im_pl,
+__global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __restrict__ fo_pl, const uint4* __restrict__ hil_img,
                                                       const float4* __restrict__ pll_poly,
                                                       const uint4* __restrict__ aud_img, const int2* __restrict__ aud_idx, const uint4* __restrict__ rds_img,
                                                       const float* __restrict__ b_lmr, const float* __restrict__ mixctl, float* __restrict__ state,
@@ -1588,103 +1551,147 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
                                                       const float* __restrict__ lmr_est_prev, int field_cur, int field_prev, float* __restrict__ rds_pow) {
     using G = ExtractGeomM;
     constexpr int TA = G::TA, XS = G::XS, XSP = G::XSP, NBW = G::NB / 2;
-    __shared__ __attribute__((aligned(16))) uint32_t lpr_h[NBW], lpr_l[NBW], lmr_h[NBW], lmr_l[NBW];   // Re fm_out_iq; imaginary rail of the x2-mixed signal
+    // 31.9 KB: five workgroups per CU (at four the kernel alone takes 13 % longer: tools/r3_ab_alone.sh)
+    __shared__ __attribute__((aligned(16))) uint32_t fow_h[G::NBWW], fow_l[G::NBWW];                   // fm_out window: Hilbert operand, and (32 on) the L+R FIR's
+    __shared__ __attribute__((aligned(16))) float im_f[XSP];                                           // Hilbert rail; the mixers leave the x2-mixed signal's real rail in its place
+    __shared__ __attribute__((aligned(16))) uint32_t lmr_h[NBW], lmr_l[NBW];                           // imaginary rail of the x2-mixed signal
     __shared__ __attribute__((aligned(16))) uint32_t rre_h[NBW], rre_l[NBW], rim_h[NBW], rim_l[NBW];   // x3-mixed signal
-    __shared__ __attribute__((aligned(16))) float lmr_re[XSP];                                           // real rail of the x2-mixed signal (phase estimate)
     __shared__ __attribute__((aligned(16))) float res_lpr[TA];
     __shared__ __attribute__((aligned(16))) float res_lmr[TA];
     __shared__ __attribute__((aligned(16))) float res_rds[TA];        // [TA/2][2]
     __shared__ float res_est_re[G::NEST];
     __shared__ float off_s;
+    float* lmr_re = im_f;                        // (phase estimate's FIR input)
 
     const int tiles = d.n_audio / TA;
     const int c = blockIdx.x / tiles, tile = blockIdx.x % tiles;
     const int i0 = tile * TA, tid = threadIdx.x;
     const int lane = tid & (kWave - 1), wv = tid >> 6, lrow = lane & 15, lq = lane >> 4;
-    const int s_lo = 4 * i0 - 124;               // first fm_out sample staged (block relative), even
+    const int s_lo = 4 * i0 - 124;               // first analytic sample staged (block relative), even
     const int n = d.n_fm_out;
-    // the planes' rows carry the previous block's tail in front (k_pll_span): history and block are addressed alike.
-    // Analytic signal: re[s] = fm_out[s - 32], im[s] = the Hilbert rail; NCO phase: the span's cubic (PllSpanTab)
+    // the plane's rows carry the previous block's tail in front (k_pll_span): history and block are addressed alike.
+    // Analytic signal: re[s] = fm_out[s - 32], im[s] = sum_k b[k] fm_out[s - 64 + k] (reference hilbert FIR, broadcast_fm_demod.cpp:261-275
+    // as k_front makes it in exact mode); NCO phase: the span's cubic (PllSpanTab)
     const float* fo_c = fo_pl + (size_t)c * (kFoPad + n) + kFoPad;
-    const float* im_c = im_pl + (size_t)c * (kImPad + n) + kImPad;
     const float4* po_c = pll_poly + (size_t)c * (1 + n / kSpan) + 1;
     const float off_prev = st(state, field_prev, d.C, c);
     float off_cur = lmr_est_prev ? 0.0f : st(state, field_cur, d.C, c);
 
-    // stage + mix, two consecutive samples per thread and step: all loads first, then the arithmetic
+    constexpr int NPAIR = (XSP + 4) / 2 + 0;           // pairs e = 0, 2, ... up to the zero padding of the RDS arrays (e - 4 < XSP)
+    constexpr int PERP = (NPAIR + 255) / 256;
+    float4 pv[PERP];
+    float ev[kLmrInlineMax / kWave];
+    // all loads first: the fm_out window, the spans' cubics, last block's phase estimates.  A thread loads the window pairs 32 samples
+    // behind its analytic pairs — the real-rail samples it mixes later stay in its registers in fp32 — and 16 threads the window's first 32.
+    float2 wv2[PERP], wh2;
     {
-        constexpr int NPAIR = (XSP + 4) / 2 + 0;           // pairs e = 0, 2, ... up to the zero padding of the RDS arrays (e - 4 < XSP)
-        constexpr int PERP = (NPAIR + 255) / 256;
-        float4 xv[PERP]; float2 dv[PERP]; float4 pv[PERP];
-        float ev[kLmrInlineMax / kWave];
+#pragma unroll
+        for (int r = 0; r < PERP; r++) {
+            const int e = 2 * (tid + 256 * r);
+            if (e + 32 < G::WN) wv2[r] = *reinterpret_cast<const float2*>(fo_c + (s_lo - 32 + e));
+        }
+        if (tid < 16) wh2 = *reinterpret_cast<const float2*>(fo_c + (s_lo - 64 + 2 * tid));
+#pragma unroll
+        for (int r = 0; r < PERP; r++) {
+            const int e = 2 * (tid + 256 * r);
+            if (e < XS) pv[r] = po_c[(s_lo + e) >> 7];          // (span -1: the previous block's last)
+        }
         if (lmr_est_prev && tid < kWave) {
 #pragma unroll
             for (int k = 0; k < kLmrInlineMax / kWave; k++)
                 ev[k] = (tid + kWave * k < d.n_est) ? lmr_est_prev[(size_t)c * d.n_est + tid + kWave * k] : 0.0f;
         }
+        uint32_t h0, l0, h1, l1;
 #pragma unroll
         for (int r = 0; r < PERP; r++) {
             const int e = 2 * (tid + 256 * r);
-            if (e < XS) {
-                const int sx = s_lo + e;                     // even, >= -124
-                const float2 re2 = *reinterpret_cast<const float2*>(fo_c + (sx - 32));
-                const float2 im2 = *reinterpret_cast<const float2*>(im_c + sx);
-                xv[r] = make_float4(re2.x, im2.x, re2.y, im2.y);
-                pv[r] = po_c[sx >> 7];                       // (span -1: the previous block's last)
+            if (e + 32 < G::WN) {
+                split_bf16(wv2[r].x, h0, l0); split_bf16(wv2[r].y, h1, l1);
+                const int w = G::pad(e + 32) >> 1;
+                fow_h[w] = pack_hi16(h0, h1); fow_l[w] = pack_hi16(l0, l1);
             }
         }
-        // NCO phases of the pairs: c0 + c1 u + c2 u^2 + c3 u^3 - frac(19 (u + 1) / 128), u = sample within its span (both samples of a pair share one)
+        if (tid < 16) { split_bf16(wh2.x, h0, l0); split_bf16(wh2.y, h1, l1); fow_h[tid] = pack_hi16(h0, h1); fow_l[tid] = pack_hi16(l0, l1); }
+        // zeros behind the window, up to the reach of the Toeplitz operands
+        if (tid < (G::WNP - G::WN) / 2) { const int w = G::pad(G::WN + 2 * tid) >> 1; fow_h[w] = 0u; fow_l[w] = 0u; }
+    }
+    __syncthreads();
+    // the Hilbert FIR (FrontGeomM's form: Y[m][col] = im[16 col + m] = sum_t A[m][t] W[16 col + t], t < 80): 72 columns, five 16-column tiles
+    {
+        bf16x8 ahh[3], ahl[3];
 #pragma unroll
-        for (int r = 0; r < PERP; r++) {
-            const int u0 = (s_lo + 2 * (tid + 256 * r)) & (kSpan - 1);
-            const float ua = (float)u0, ub = (float)(u0 + 1);
-            const float fa_ = __builtin_amdgcn_fractf(ub * (19.0f / 128.0f)), fb_ = __builtin_amdgcn_fractf((ub + 1.0f) * (19.0f / 128.0f));   // exact: multiples of 1/128 below 20
-            dv[r] = make_float2(fmaf(fmaf(fmaf(pv[r].w, ua, pv[r].z), ua, pv[r].y), ua, pv[r].x) - fa_,
-                                fmaf(fmaf(fmaf(pv[r].w, ub, pv[r].z), ub, pv[r].y), ub, pv[r].x) - fb_);
+        for (int sK = 0; sK < 3; sK++) {
+            ahh[sK] = __builtin_bit_cast(bf16x8, hil_img[(sK * 2 + 0) * kWave + lane]);
+            ahl[sK] = __builtin_bit_cast(bf16x8, hil_img[(sK * 2 + 1) * kWave + lane]);
         }
-        if (lmr_est_prev) {
-            if (tid < kWave) {
-                float part = 0.0f;
+        for (int ct = wv; ct < 5; ct += 4) {
+            const int col = ct * 16 + lrow;
+            f32x4 acc, acc1, acc2;
 #pragma unroll
-                for (int k = 0; k < kLmrInlineMax / kWave; k++) part += ev[k];
-                float nxt = fmaf(wave_sum_f32(part) * __builtin_amdgcn_rcpf((float)d.n_est), 0.1f, off_prev);
-                const float two_pi = bits_f32(kTwoPiBits);
-                nxt = (nxt >= two_pi) ? nxt - two_pi : ((nxt <= -two_pi) ? nxt + two_pi : nxt);
-                if (tid == 0) { off_s = nxt; if (tile == 0) st(state, field_cur, d.C, c) = nxt; }
+            for (int sK = 0; sK < 3; sK++) {
+                const int e = 16 * col + 32 * sK + 8 * lq, w = G::pad(e) >> 1;
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fow_h + w));
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fow_l + w));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahh[sK], bh, sK ? acc : kZero4, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahl[sK], bh, sK ? acc1 : kZero4, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahh[sK], bl, sK ? acc2 : kZero4, 0, 0, 0);
             }
-            __syncthreads();
-            off_cur = off_s;
+            acc = acc + (acc1 + acc2);
+            if (col < XSP / 16) *reinterpret_cast<float4*>(im_f + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
+    }
+    // NCO phases of the pairs: c0 + c1 u + c2 u^2 + c3 u^3 - frac(19 (u + 1) / 128), u = sample within its span (both samples of a pair share one)
+    float2 dv[PERP];
+#pragma unroll
+    for (int r = 0; r < PERP; r++) {
+        const int u0 = (s_lo + 2 * (tid + 256 * r)) & (kSpan - 1);
+        const float ua = (float)u0, ub = (float)(u0 + 1);
+        const float fa_ = __builtin_amdgcn_fractf(ub * (19.0f / 128.0f)), fb_ = __builtin_amdgcn_fractf((ub + 1.0f) * (19.0f / 128.0f));   // exact: multiples of 1/128 below 20
+        dv[r] = make_float2(fmaf(fmaf(fmaf(pv[r].w, ua, pv[r].z), ua, pv[r].y), ua, pv[r].x) - fa_,
+                            fmaf(fmaf(fmaf(pv[r].w, ub, pv[r].z), ub, pv[r].y), ub, pv[r].x) - fb_);
+    }
+    if (lmr_est_prev && tid < kWave) {
+        float part = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kLmrInlineMax / kWave; k++) part += ev[k];
+        float nxt = fmaf(wave_sum_f32(part) * __builtin_amdgcn_rcpf((float)d.n_est), 0.1f, off_prev);
+        const float two_pi = bits_f32(kTwoPiBits);
+        nxt = (nxt >= two_pi) ? nxt - two_pi : ((nxt <= -two_pi) ? nxt + two_pi : nxt);
+        if (tid == 0) { off_s = nxt; if (tile == 0) st(state, field_cur, d.C, c) = nxt; }
+    }
+    __syncthreads();
+    if (lmr_est_prev) off_cur = off_s;
+    // the zero padding behind the staged samples, up to the reach of the Toeplitz operands
+    if (tid < (XSP + 4 - XS) / 2) {
+        const int e = XS + 2 * tid;
+        if (e < XSP) { const int w4 = G::pad(e) >> 1; lmr_h[w4] = 0u; lmr_l[w4] = 0u; *reinterpret_cast<float2*>(lmr_re + e) = make_float2(0.f, 0.f); }
+        const int w8 = G::pad(e - 4) >> 1; rre_h[w8] = 0u; rre_l[w8] = 0u; rim_h[w8] = 0u; rim_l[w8] = 0u;
+    }
+    // mix, two consecutive samples per thread and step
+    {
         const float co_cur = fast_cos_turns(off_cur), so_cur = fast_sin_turns(off_cur);
         const float co_prev = fast_cos_turns(off_prev), so_prev = fast_sin_turns(off_prev);
-        // the zero padding behind the staged samples, up to the reach of the Toeplitz operands
-        if (tid < (XSP + 4 - XS) / 2) {
-            const int e = XS + 2 * tid;
-            if (e < XSP) { const int w4 = G::pad(e) >> 1; lpr_h[w4] = 0u; lpr_l[w4] = 0u; lmr_h[w4] = 0u; lmr_l[w4] = 0u; *reinterpret_cast<float2*>(lmr_re + e) = make_float2(0.f, 0.f); }
-            const int w8 = G::pad(e - 4) >> 1; rre_h[w8] = 0u; rre_l[w8] = 0u; rim_h[w8] = 0u; rim_l[w8] = 0u;
-        }
 #pragma unroll
         for (int r = 0; r < PERP; r++) {
             const int e = 2 * (tid + 256 * r);
             if (e < XS) {
                 const bool hist = s_lo + e < 0;                      // history samples were mixed with last block's offset
                 const float co = hist ? co_prev : co_cur, so = hist ? so_prev : so_cur;
-                float lp[2], m2r[2], m2i[2], m3r[2], m3i[2];
+                const float2 re2 = wv2[r], im2 = *reinterpret_cast<const float2*>(im_f + e);
+                float m2r[2], m2i[2], m3r[2], m3i[2];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    const float xr = u ? xv[r].z : xv[r].x, xi = u ? xv[r].w : xv[r].y, t = u ? dv[r].y : dv[r].x;
+                    const float xr = u ? re2.y : re2.x, xi = u ? im2.y : im2.x, t = u ? dv[r].y : dv[r].x;
                     const float c1 = fast_cos_turns(t), s1 = fast_sin_turns(t);
                     const float c2 = fmaf(c1, c1, -(s1 * s1)), s2 = (c1 + c1) * s1;
                     const float c2o = fmaf(c2, co, -(s2 * so)), s2o = fmaf(s2, co, c2 * so);
                     const float c3 = fmaf(c2, c1, -(s2 * s1)), s3 = fmaf(s2, c1, c2 * s1);
-                    lp[u] = xr;
                     m2r[u] = fmaf(c2o, xr, -(xi * s2o)); m2i[u] = fmaf(c2o, xi, xr * s2o);
                     m3r[u] = fmaf(c3, xr, -(xi * s3)); m3i[u] = fmaf(c3, xi, xr * s3);
                 }
                 uint32_t h0, l0, h1, l1;
                 if (e < XSP) {
                     const int w4 = G::pad(e) >> 1;
-                    split_bf16(lp[0], h0, l0); split_bf16(lp[1], h1, l1); lpr_h[w4] = pack_hi16(h0, h1); lpr_l[w4] = pack_hi16(l0, l1);
                     split_bf16(m2i[0], h0, l0); split_bf16(m2i[1], h1, l1); lmr_h[w4] = pack_hi16(h0, h1); lmr_l[w4] = pack_hi16(l0, l1);
                     *reinterpret_cast<float2*>(lmr_re + e) = make_float2(m2r[0], m2r[1]);
                 }
@@ -1704,8 +1711,9 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
         // L+R / L-R: one 16 x 16 tile = the 256 outputs of the workgroup
         const int2 slot = aud_idx[c];
         const uint4* img = aud_img + (size_t)(wv ? slot.y : slot.x) * (6 * 2 * kWave);
-        const uint32_t* sh = wv ? lmr_h : lpr_h;
-        const uint32_t* sl = wv ? lmr_l : lpr_l;
+        // (L+R is the real rail itself: the fm_out window 32 samples on, i.e. one padded group of 40 elements)
+        const uint32_t* sh = wv ? lmr_h : fow_h + 20;
+        const uint32_t* sl = wv ? lmr_l : fow_l + 20;
         f32x4 acc, acc1, acc2;   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
 #pragma unroll
         for (int sK = 0; sK < 6; sK++) {
@@ -1786,11 +1794,21 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
 }
 
 // Tolerance mode, FMD_FLAG_KEEP_TAPS (the "fm_out_iq" getter) and block lengths whose audio blocks are not multiples of 256 (those run
-// k_extract<128, true> on the interleaved stream, with the history tails it keeps for itself): the analytic signal assembled from the planes.
-__global__ __launch_bounds__(256) void k_planes_to_iq(Dims d, const float* __restrict__ fo_pl, const float* __restrict__ im_pl, float2* __restrict__ fm_out_iq) {
+// k_extract<128, true> on the interleaved stream, with the history tails it keeps for itself): the analytic signal from the fm_out plane,
+// Hilbert rail as k_hilbert makes it.
+__global__ __launch_bounds__(256) void k_planes_to_iq(Dims d, const float* __restrict__ fo_pl, float2* __restrict__ fm_out_iq, FrontTaps taps) {
     const int n = d.n_fm_out, tiles = n / 256, c = blockIdx.x / tiles;     // (n_fm_out is a multiple of 512)
     const int s_ = (blockIdx.x % tiles) * 256 + threadIdx.x;
-    fm_out_iq[(size_t)c * n + s_] = make_float2(fo_pl[(size_t)c * (kFoPad + n) + kFoPad + s_ - 32], im_pl[(size_t)c * (kImPad + n) + kImPad + s_]);
+    const float* x = fo_pl + (size_t)c * (kFoPad + n) + kFoPad + s_ - 64;  // im[s] = sum_k b[k] fm_out[s - 64 + k], k odd
+    float l1 = 0.f, l3 = 0.f, l5 = 0.f, l7 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        l1 = fmaf(x[1 + 8 * k], taps.b_hilbert_odd[4 * k + 0], l1);
+        l3 = fmaf(x[3 + 8 * k], taps.b_hilbert_odd[4 * k + 1], l3);
+        l5 = fmaf(x[5 + 8 * k], taps.b_hilbert_odd[4 * k + 2], l5);
+        l7 = fmaf(x[7 + 8 * k], taps.b_hilbert_odd[4 * k + 3], l7);
+    }
+    fm_out_iq[(size_t)c * n + s_] = make_float2(x[32], (l1 + l5) + (l3 + l7));
 }
 
 // a11 — reference ExtractComponents :511-516: integrate the mean L-R phase error of the block (sequential sum in sample order).
@@ -2248,15 +2266,13 @@ __global__ __launch_bounds__(2 * kWave) void k_deemphasis(Dims d, float* __restr
     if (live && on) { st(state, S_DE_X1, d.C, c) = x1; st(state, S_DE_Y1, d.C, c) = y1; }
 }
 
-// PLANE (tolerance mode): fm_out lives in the padded rows of fo_pl and the output is the Hilbert plane im_pl
-template <bool PLANE>
 __global__ __launch_bounds__(256) void k_hilbert(Dims d, const float* __restrict__ fm_out, const float* __restrict__ fo_tail_in,
-                                                 float* __restrict__ fo_tail_out, float2* __restrict__ fm_out_iq, float* __restrict__ im_pl, FrontTaps taps) {
+                                                 float* __restrict__ fo_tail_out, float2* __restrict__ fm_out_iq, FrontTaps taps) {
     constexpr int T = 256;
     __shared__ float fo[T + 64];
     const int tiles = d.n_fm_out / T;
     const int c = blockIdx.x / tiles, tile = blockIdx.x % tiles, o0 = tile * T, tid = threadIdx.x;
-    const float* row = PLANE ? fm_out + (size_t)c * (kFoPad + d.n_fm_out) + kFoPad : fm_out + (size_t)c * d.n_fm_out;
+    const float* row = fm_out + (size_t)c * d.n_fm_out;
     for (int uu = tid; uu < T + 64; uu += 256) {
         const int u = o0 - 64 + uu;
         fo[uu] = (u < 0) ? fo_tail_in[(size_t)c * 64 + 64 + u] : row[u];
@@ -2272,8 +2288,7 @@ __global__ __launch_bounds__(256) void k_hilbert(Dims d, const float* __restrict
         l7 = fmaf(fo[oo + 7 + 8 * k], taps.b_hilbert_odd[4 * k + 3], l7);
     }
     const float im = (0.0f + ((l1 + l5) + (l3 + l7))) + 0.0f;
-    if constexpr (PLANE) im_pl[(size_t)c * (kImPad + d.n_fm_out) + kImPad + o0 + oo] = im;
-    else fm_out_iq[(size_t)c * d.n_fm_out + o0 + oo] = make_float2(fo[oo + 32], im);
+    fm_out_iq[(size_t)c * d.n_fm_out + o0 + oo] = make_float2(fo[oo + 32], im);
     if (tile == tiles - 1 && tid < 64) fo_tail_out[(size_t)c * 64 + tid] = row[d.n_fm_out - 64 + tid];
 }
 
@@ -2355,14 +2370,12 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
             auto kern = k_front_mfma<InT, TT, kDeemphWarmup>;
             using GM = FrontGeomM<TT, kDeemphWarmup>;
             FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
-                       ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.b.im_pl[r.buf], ctx.b.fo_tail[r.par ^ 1],
-                       ctx.front.fm_gain, 0, ctx.b.deemph, ctx.b.front_mfma);
+                       ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma);
         } else {
             auto kern = k_front_mfma<InT, TT, 0>;
             using GM = FrontGeomM<TT, 0>;
             FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
-                       ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.b.im_pl[r.buf], ctx.b.fo_tail[r.par ^ 1],
-                       ctx.front.fm_gain, ctx.any_deemph, ctx.b.deemph, ctx.b.front_mfma);
+                       ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma);
         }
         return hipGetLastError();
     }
@@ -2414,15 +2427,13 @@ static unsigned serial_waves(const Dims& d) { return (unsigned)((d.C + kWave - 1
 hipError_t launch_stage_deemph(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
-    if (ctx.fast) {   // the planes' rows: kFoPad samples of history in front of the block
-        FMD_LAUNCH(r, true, false, k_deemphasis, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.fo_pl[r.buf] + kFoPad, b.deemph, b.state, kFoPad + d.n_fm_out);
-        FMD_LAUNCH(r, false, true, k_hilbert<true>, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, b.fo_pl[r.buf], b.fo_tail[r.par],
-                   b.fo_tail[r.par ^ 1], (float2*)nullptr, b.im_pl[r.buf], ctx.front);
+    if (ctx.fast) {   // a time constant beyond the in-tile form: in place on the plane (rows: kFoPad samples of history in front of the block)
+        FMD_LAUNCH(r, true, true, k_deemphasis, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.fo_pl[r.buf] + kFoPad, b.deemph, b.state, kFoPad + d.n_fm_out);
         return hipGetLastError();
     }
     FMD_LAUNCH(r, true, false, k_deemphasis, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.fm_out[r.buf], b.deemph, b.state, d.n_fm_out);
-    FMD_LAUNCH(r, false, true, k_hilbert<false>, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, b.fm_out[r.buf], b.fo_tail[r.par],
-                       b.fo_tail[r.par ^ 1], b.fm_out_iq[r.buf], (float*)nullptr, ctx.front);
+    FMD_LAUNCH(r, false, true, k_hilbert, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, b.fm_out[r.buf], b.fo_tail[r.par],
+                       b.fo_tail[r.par ^ 1], b.fm_out_iq[r.buf], ctx.front);
     return hipGetLastError();
 }
 
@@ -2443,10 +2454,9 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     if (ctx.fast) {
         const int nxt = (r.buf + 1) % kSlots;
         const bool iq = ctx.b.fm_out_iq[r.buf] != nullptr;    // FMD_FLAG_KEEP_TAPS, or audio blocks that are not multiples of 256: the interleaved streams too
-        FMD_LAUNCH(r, true, !iq, k_pll_span, dim3((unsigned)((d.C + 3) / 4)), dim3(kWave), 0, s, d, ctx.b.fo_pl[r.buf], ctx.b.fo_pl[nxt], ctx.b.im_pl[r.buf], ctx.b.im_pl[nxt],
+        FMD_LAUNCH(r, true, !iq, k_pll_span, dim3((unsigned)((d.C + 3) / 4)), dim3(kWave), 0, s, d, ctx.b.fo_pl[r.buf], ctx.b.fo_pl[nxt],
                    ctx.b.pll_poly[r.buf], ctx.b.pll_poly[nxt], iq ? ctx.b.pll_dt[r.buf] : (float*)nullptr, ctx.b.state, ctx.loops, ctx.b.pilot_tab, ctx.b.span_tab, ctx.b.spec_stats);
-        if (iq) FMD_LAUNCH(r, false, true, k_planes_to_iq, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, ctx.b.fo_pl[r.buf], ctx.b.im_pl[r.buf],
-                           ctx.b.fm_out_iq[r.buf]);
+        if (iq) FMD_LAUNCH(r, false, true, k_planes_to_iq, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, ctx.b.fo_pl[r.buf], ctx.b.fm_out_iq[r.buf], ctx.front);
         return hipGetLastError();
     }
     if (d.C > ctx.pll_time_parallel_max_channels) {
@@ -2479,7 +2489,7 @@ static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
         if (ctx.fast) return launch_extract_ta<TA, true>(ctx, r, s);
     }
     if constexpr (FAST && TA == 256) {   // tolerance mode: the FIRs on the matrix cores
-        FMD_LAUNCH(r, true, true, k_extract_mfma, dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fo_pl[r.buf], b.im_pl[r.buf], b.pll_poly[r.buf],
+        FMD_LAUNCH(r, true, true, k_extract_mfma, dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fo_pl[r.buf], b.front_mfma + 6 * kWave, b.pll_poly[r.buf],
                    b.aud_img, b.aud_idx, b.rds_img, b.b_lmr, b.mix,
                    b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est[r.par], b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps,
                    lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr, lmr_field(r.par), lmr_field(r.par ^ 1), b.rds_pow[r.buf]);
