@@ -446,12 +446,15 @@ def main() -> None:
         gather = pkg.AudioGather(dist, torch, C, dm.rates.n_audio, world, device, mode=args.gather,
                                  dtype=torch.int16 if pcm16 else torch.float32)
         gstream = torch.cuda.Stream(device)   # consumes outputs; the submitting stream never waits on them
+        dm.set_output_lag(True)
 
     def step(k: int):
         # the resident blocks are never rewritten: submitted without ordering the caller's stream behind the demodulator's reads
         # (fmd_submit_cf32_dev; with fmd_process_cf32_dev consecutive front-end launches are two cross-queue hand-overs apart)
         dm.submit(x[k % n_blocks_resident])
-        if do_gather:
+        # (the gather takes every block's audio one submission later — fmd_set_output_lag: the newest QUEUED outputs, block k - 1's behind
+        #  the submission of block k — so the demodulator keeps the schedule of the free-running case; one gather per step all the same)
+        if do_gather and k >= 1:
             with torch.cuda.stream(gstream):
                 s = gather.slot(k)
                 if pcm16:
@@ -623,9 +626,10 @@ def main() -> None:
             measure_config(torch, pkg, device, "4096 ch @ 1.024 MSa/s cf32 (the reference's native rate)", 4096, 1_024_000, False, True),
             measure_config(torch, pkg, device, "4096 ch @ 1.024 MSa/s u8 (the reference's capture format)", 4096, 1_024_000, True, True),
             measure_config(torch, pkg, device, "configs[1]: 1 ch @ 2.048 MSa/s, tolerance mode", 1, 2_048_000, False, True, steps=60),
-            measure_config(torch, pkg, device, "configs[1]: 1 ch @ 2.048 MSa/s, exact mode", 1, 2_048_000, False, False, steps=60),
+            measure_config(torch, pkg, device, "configs[1]: 1 ch @ 2.048 MSa/s, exact mode", 1, 2_048_000, False, False, steps=60, preroll=24),
             measure_config(torch, pkg, device, "configs[3] per-GPU shard: 8192 ch @ 256 kSa/s", 8192, 256_000, False, True),
-            measure_config(torch, pkg, device, "configs[2] in the exact mode: 4096 ch @ 256 kSa/s", 4096, 256_000, False, False, steps=20),
+            # (exact mode: the pilot loop's speculation runs at full length only once every station is in lock: ~20 blocks)
+            measure_config(torch, pkg, device, "configs[2] in the exact mode: 4096 ch @ 256 kSa/s", 4096, 256_000, False, False, steps=20, preroll=24),
         ]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         x = None

@@ -131,6 +131,7 @@ def load_library():
         getattr(L, name).argtypes = [H, C.c_void_p, C.c_int, C.c_int]
     L.fmd_synchronize.argtypes = [H]
     L.fmd_wait_outputs.argtypes = [H, C.c_void_p]
+    L.fmd_set_output_lag.argtypes = [H, C.c_int]
     L.fmd_wait_input.argtypes = [H, C.c_void_p]
     L.fmd_release_outputs.argtypes = [H, C.c_void_p]
     L.fmd_output_lifetime_blocks.restype = C.c_int
@@ -185,11 +186,11 @@ def selftest_atan2(y: np.ndarray, x: np.ndarray, table_form: bool = False) -> np
 
 
 def selftest_fast_math(kind: str, a: np.ndarray, b: np.ndarray | None = None) -> np.ndarray:
-    """The tolerance mode's primitives on the device: kind in {"atan2", "sin_turns", "cos_turns"}."""
+    """The tolerance mode's primitives on the device: kind in {"atan2", "sin_turns", "cos_turns", "atan2_turns"}."""
     a = np.ascontiguousarray(a, np.float32)
     b = a if b is None else np.ascontiguousarray(b, np.float32)
     out = np.empty_like(a)
-    rc = load_library().fmd_selftest_fast_math({"atan2": 0, "sin_turns": 1, "cos_turns": 2}[kind], a.ctypes.data_as(C.c_void_p),
+    rc = load_library().fmd_selftest_fast_math({"atan2": 0, "sin_turns": 1, "cos_turns": 2, "atan2_turns": 3}[kind], a.ctypes.data_as(C.c_void_p),
                                                b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), a.size)
     if rc != FMD_OK:
         raise FmdError(rc, load_library().fmd_last_error(None).decode())
@@ -315,6 +316,12 @@ class BatchDemod:
 
     def synchronize(self):
         self._check(self.L.fmd_synchronize(self.h))
+
+    def set_output_lag(self, on: bool) -> None:
+        """fmd_set_output_lag: with on=True the device-side output calls (wait_outputs, release_outputs, audio_tensor, audio_pcm16_into,
+        ...) refer to the newest block whose output stages are QUEUED — behind submit() of block k that is block k - 1 in the
+        tolerance mode — and never force a put-off stage."""
+        self._check(self.L.fmd_set_output_lag(self.h, 1 if on else 0))
 
     def wait_outputs(self, stream=None):
         """Make `stream` (torch stream or raw handle; default: torch current stream) wait for the newest block's outputs."""

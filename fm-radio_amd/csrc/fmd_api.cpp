@@ -57,8 +57,17 @@ struct fmd_handle_s {
     bool last_block_deemph = false;          // the previous block went through the de-emphasis stage (stream sD)
     bool poisoned = false;                   // a block failed part-way: state is not the state after a whole number of blocks
     bool pipelined = true;
+    // Tolerance mode, fmd_submit_*: k_extract_mfma shares k_front_mfma's stream and a block's extract + RDS stages are queued when the
+    // NEXT block is submitted (behind that block's front end) or when somebody asks for the outputs — see process_dev
+    bool lazy_extract = false, lazy_capable = false;
+    struct Deferred { bool active = false; SlotRef ref{}; hipEvent_t pll_dep = nullptr; int slot = 0; ProfiledBlock* pm = nullptr; bool prof_x = false, prof_r = false; } deferred;
+    hipStream_t last_x_stream = nullptr;     // where the newest extract stage was queued, and the event behind it: consecutive blocks'
+    hipEvent_t last_x_event = nullptr;       // extract stages are ordered (L-R phase estimate), whichever of the two streams they take
     long n_blocks = 0;                       // blocks submitted since create/reset; slot = n_blocks % kSlots
-    int out_slot = 0;                        // slot holding the newest block's outputs
+    int out_slot = 0;                        // slot holding the newest outputs (the newest block's; under fmd_set_output_lag: the newest QUEUED outputs)
+    int sub_slot = 0;                        // slot of the newest submitted block
+    bool have_out = false;                   // some block's output stages have been queued since create / reset
+    bool lag_outputs = false;                // fmd_set_output_lag
     hipEvent_t ev_consumed = nullptr;        // fires when the newest block's input buffer has been read (fmd_wait_input)
     int device = 0;
     int bytes_cap = 0;
@@ -353,17 +362,73 @@ int zero_history(fmd_handle h, hipStream_t s) {
     if (b.pll_chain) HIP_TRY(h, hipMemsetAsync(b.pll_chain, 0, sizeof(unsigned) * ((size_t)h->pll_waves + 1), s));
     h->pll_seq = 0;
     h->n_blocks = 0;
+    h->deferred.active = false; h->last_x_event = nullptr;
     h->ev_consumed = nullptr;
-    h->out_slot = 0;
+    h->out_slot = 0; h->sub_slot = 0; h->have_out = false;
     for (bool& u : h->slot_used) u = false;
     for (bool& u : h->consumer_pending) u = false;
     h->poisoned = false;
     return FMD_OK;
 }
 
+// The extract + RDS stages of the block whose launch fmd_submit_* put off (tolerance mode).
+// behind_front (the next block has just been submitted): k_extract_mfma goes on the FRONT END's stream.  The two throughput kernels
+// gain nothing from running side by side — together they took longer than one after the other (tools/r3_timeline.sh: 0.37 ms a block for
+// the pair against 0.14 + 0.17 ms alone; they share a CU's LDS and wave slots, and every hop between queues costs ~50 us) — so they take
+// turns on one queue, in the order front(k + 1), extract(k), front(k + 2), ...; by the time extract(k) is reached, the pilot loop of
+// block k has run on its own queue, as the RDS stages do.  Otherwise (somebody asks for the block's outputs before the next block is
+// there: fmd_wait_outputs, a getter, fmd_synchronize) it goes on the extract stream as in the exact mode, beside the next front end.
+int launch_deferred(fmd_handle h, bool behind_front) {
+    auto& q = h->deferred;
+    if (!q.active) return FMD_OK;
+    q.active = false;
+    hipStream_t sXq = behind_front ? h->sF : h->sX, sR = h->sR;
+    if (h->consumer_pending[q.slot]) {       // fmd_release_outputs: a consumer still reads this slot's old outputs
+        HIP_TRY(h, hipStreamWaitEvent(sXq, h->ev_C[q.slot], 0));
+        HIP_TRY(h, hipStreamWaitEvent(sR, h->ev_C[q.slot], 0));
+        h->consumer_pending[q.slot] = false;
+    }
+    if (h->last_x_event && h->last_x_stream != sXq) HIP_TRY(h, hipStreamWaitEvent(sXq, h->last_x_event, 0));
+    HIP_TRY(h, hipStreamWaitEvent(sXq, q.pll_dep, 0));
+    hipEvent_t dep;
+    {
+        SlotRef r = q.ref;
+        if (q.pm && q.prof_x) { r.t0 = q.pm->t0[ST_EXTRACT]; r.t1 = q.pm->t1[ST_EXTRACT]; q.pm->used[ST_EXTRACT] = true; }
+        if (!r.t1) r.done = h->ev_E[q.slot];
+        dep = r.t1 ? r.t1 : h->ev_E[q.slot];
+        hipError_t e = (h->debug_skip & (1u << ST_EXTRACT)) ? hipEventRecord(dep, sXq) : launch_stage_extract(h->ctx, r, sXq);
+        if (e != hipSuccess) { h->poisoned = true; return fail(h, FMD_ERR_DEVICE, "k_extract launch: %s", hipGetErrorString(e)); }
+        h->last_x_stream = sXq; h->last_x_event = dep;
+    }
+    HIP_TRY(h, hipStreamWaitEvent(sR, dep, 0));
+    {
+        SlotRef r = q.ref;
+        if (q.pm && q.prof_r) { r.t0 = q.pm->t0[ST_RDS]; r.t1 = q.pm->t1[ST_RDS]; q.pm->used[ST_RDS] = true; }
+        if (!r.t1) r.done = h->ev_X[q.slot];
+        dep = r.t1 ? r.t1 : h->ev_X[q.slot];
+        hipError_t e = (h->debug_skip & (1u << ST_RDS)) ? hipEventRecord(dep, sR) : launch_stage_rds(h->ctx, r, sR);
+        if (e != hipSuccess) { h->poisoned = true; return fail(h, FMD_ERR_DEVICE, "k_rds_sync launch: %s", hipGetErrorString(e)); }
+    }
+    if (dep != h->ev_X[q.slot]) HIP_TRY(h, hipEventRecord(h->ev_X[q.slot], sR));
+    h->out_slot = q.slot; h->have_out = true;
+    return FMD_OK;
+}
+
+// A caller is about to use the device views of the newest outputs (fmd_wait_outputs, fmd_release_outputs, the *_dev getters).
+// Default: they are the newest BLOCK's — if its extract stage is still put off it is queued now, on the extract stream, and from here on
+// the handle queues every block's stages at once (such a caller asks after every block: taking turns on the front end's queue would
+// stall that queue for the length of the pilot loop each time).  fmd_set_output_lag: nothing is forced, the views are the newest queued ones.
+int outputs_wanted(fmd_handle h) {
+    if (h->lag_outputs || !h->deferred.active) return FMD_OK;
+    h->lazy_extract = false;
+    return launch_deferred(h, false);
+}
+
 int sync_all(fmd_handle h) {
     HIP_TRY(h, hipSetDevice(h->device));
+    { int rc = launch_deferred(h, true); if (rc) return rc; }    // (everything drains: the front end's queue is as good as any)
     for (hipStream_t st : {h->sF, h->sD, h->sA, h->sB, h->sB2, h->sX, h->sR, h->own_stream}) if (st) HIP_TRY(h, hipStreamSynchronize(st));
+    h->last_x_event = nullptr;        // (everything has run: no order left to keep; a timed block's events are about to be freed)
     if (!h->pipelined && h->n_blocks > 0) HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     if (h->pll_chained && h->pll_seq) {   // the hand-over watchdog of k_pilot_pll
         unsigned timed_out = 0;
@@ -400,6 +465,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     const bool pipe = h->pipelined;
     if (!pipe) ordered = true;                     // every stage runs on `s` itself
     hipStream_t sF = pipe ? h->sF : s, sA = pipe ? h->sA : s, sX = pipe ? h->sX : s, sR = pipe ? h->sR : s;
+    const bool lazy = pipe && h->lazy_extract && !ordered;
     // consecutive blocks' PLL launches alternate between two streams when they hand over per wavefront (fmd_kernels.hip)
     const bool chained = pipe && h->pll_chained;
     hipStream_t sB = pipe ? ((chained && (h->n_blocks & 1)) ? h->sB2 : h->sB) : s;
@@ -432,7 +498,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     // from here on kernels are queued and host-side counters advance: a failure leaves the state between two blocks
     struct Poison { fmd_handle h; bool armed = true; ~Poison() { if (armed) h->poisoned = true; } } poison{h};
     // fmd_release_outputs: the writers of this slot's output views wait for the consumer that still reads the old contents
-    if (h->consumer_pending[slot]) {
+    if (h->consumer_pending[slot] && !lazy) {
         HIP_TRY(h, hipStreamWaitEvent(sX, h->ev_C[slot], 0));
         if (sR != sX) HIP_TRY(h, hipStreamWaitEvent(sR, h->ev_C[slot], 0));
         h->consumer_pending[slot] = false;
@@ -456,7 +522,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     }
     // the block after the last de-emphasised one: k_front maintains the Hilbert history (fo_tail) again and must not overwrite
     // what the previous block's k_hilbert, on its own stream, is still reading
-    if (pipe && !h->ctx.any_deemph && h->last_block_deemph) HIP_TRY(h, hipStreamWaitEvent(sF, h->ev_F[h->out_slot], 0));
+    if (pipe && !h->ctx.any_deemph && h->last_block_deemph) HIP_TRY(h, hipStreamWaitEvent(sF, h->ev_F[h->sub_slot], 0));
     hipEvent_t input_done = nullptr;               // fires when the caller's buffer has been consumed
     if (predecim) {
         SlotRef r = ref;
@@ -499,16 +565,26 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     }
     if (pipe) HIP_TRY(h, hipStreamWaitEvent(sB, dep, 0));
     if ((e = run(ST_PLL, sB, launch_stage_pll, h->ev_B[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_pilot_pll launch: %s", hipGetErrorString(e));
-    if (pipe) HIP_TRY(h, hipStreamWaitEvent(sX, dep, 0));
-    // the extract stage's event fires behind k_extract itself: k_rds_sync does not need k_lmr_phase (same stream, behind it)
-    if ((e = run(ST_EXTRACT, sX, launch_stage_extract, h->ev_E[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_extract launch: %s", hipGetErrorString(e));
-    if (pipe) HIP_TRY(h, hipStreamWaitEvent(sR, dep, 0));
-    if ((e = run(ST_RDS, sR, launch_stage_rds, h->ev_X[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_rds_sync launch: %s", hipGetErrorString(e));
-    // ev_X outlives this call (slot reuse, fmd_wait_outputs): when the dispatch carried a timing event instead, record it
-    if (pipe && dep != h->ev_X[slot]) HIP_TRY(h, hipEventRecord(h->ev_X[slot], sR));
+    // the previous block's extract + RDS stages, if fmd_submit_* put them off: behind this block's front end (launch_deferred)
+    { int rc = launch_deferred(h, true); if (rc) return rc; }
+    if (lazy) {
+        h->deferred.active = true; h->deferred.ref = ref; h->deferred.pll_dep = dep; h->deferred.slot = slot; h->deferred.pm = pm;
+        h->deferred.prof_x = pm && prof_stage(ST_EXTRACT); h->deferred.prof_r = pm && prof_stage(ST_RDS);
+    } else {
+        if (pipe) HIP_TRY(h, hipStreamWaitEvent(sX, dep, 0));
+        if (pipe && h->last_x_event && h->last_x_stream != sX) HIP_TRY(h, hipStreamWaitEvent(sX, h->last_x_event, 0));
+        // the extract stage's event fires behind k_extract itself: k_rds_sync does not need k_lmr_phase (same stream, behind it)
+        if ((e = run(ST_EXTRACT, sX, launch_stage_extract, h->ev_E[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_extract launch: %s", hipGetErrorString(e));
+        if (pipe) { h->last_x_stream = sX; h->last_x_event = dep; }
+        if (pipe) HIP_TRY(h, hipStreamWaitEvent(sR, dep, 0));
+        if ((e = run(ST_RDS, sR, launch_stage_rds, h->ev_X[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_rds_sync launch: %s", hipGetErrorString(e));
+        // ev_X outlives this call (slot reuse, fmd_wait_outputs): when the dispatch carried a timing event instead, record it
+        if (pipe && dep != h->ev_X[slot]) HIP_TRY(h, hipEventRecord(h->ev_X[slot], sR));
+    }
     h->last_block_deemph = h->ctx.any_deemph != 0;
     h->slot_used[slot] = true;
-    h->out_slot = slot;
+    h->sub_slot = slot;
+    if (!lazy) { h->out_slot = slot; h->have_out = true; }
     h->n_blocks++;
     if (h->deemph_linger) { h->deemph_linger = false; h->ctx.any_deemph = 0; }
     h->last_stream = s;
@@ -619,9 +695,19 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     // (the second PLL stream is own_stream: one more stream would be the ninth on the device with the caller's and would share a
     //  hardware queue with another stage; everything else own_stream does is preceded by a full synchronisation)
     h->sB2 = h->own_stream;
-    for (hipStream_t* st : {&h->sF, &h->sD, &h->sA, &h->sB, &h->sX, &h->sR}) {
-        hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-        if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e)));
+    {
+        // experiment hook: FMD_STREAM_PRIORITIES="f,b,x,r" — priorities of the front / PLL / extract / RDS streams (0 = default, negative = higher)
+        int prio[6] = {0, 0, 0, 0, 0, 0};       // sF, sD, sA, sB, sX, sR
+        if (const char* e = std::getenv("FMD_STREAM_PRIORITIES")) { int f = 0, b = 0, x = 0, r = 0; if (std::sscanf(e, "%d,%d,%d,%d", &f, &b, &x, &r) == 4) { prio[0] = f; prio[1] = f; prio[3] = b; prio[4] = x; prio[5] = r; } }
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        int i = 0;
+        for (hipStream_t* st : {&h->sF, &h->sD, &h->sA, &h->sB, &h->sX, &h->sR}) {
+            const int p = std::min(least, std::max(greatest, prio[i++]));
+            hipError_t e = p ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, p) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+            if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e)));
+        }
+        if (std::getenv("FMD_STREAM_PRIORITIES")) std::fprintf(stderr, "fmdemod: stream priority range [%d (least) .. %d (greatest)]\n", least, greatest);
     }
     {
         std::vector<hipEvent_t*> evs = {&h->ev_in};
@@ -649,6 +735,11 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     h->ctx.keep_taps = (cfg->flags & FMD_FLAG_KEEP_TAPS) ? 1 : 0;
     h->ctx.fast = (cfg->flags & FMD_FLAG_FAST_MATH) ? 1 : 0;
     if (const char* e = getenv("FMD_DEBUG_SKIP_STAGES")) h->debug_skip = (unsigned)strtoul(e, nullptr, 0);   // development knob
+    // fmd_submit_* puts a block's extract stage off until the next block's front end is queued (launch_deferred) where the kernels are
+    // large enough to fill the chip on their own: 3072 stations' worth of 256 kSa/s blocks and up (same-box A/B at 4096 / 8192
+    // stations: 6 % on the step; at 1024 / 2048, where the stages' latency is what matters, 1-3 % the other way)
+    h->lazy_capable = h->pipelined && h->ctx.fast && (size_t)d.C * d.n_fm_out >= (size_t)3072 * 8192 && !std::getenv("FMD_NO_LAZY_EXTRACT");
+    h->lazy_extract = h->lazy_capable;
 
     fmd_controls def;
     fmd_default_controls(&def);
@@ -837,6 +928,15 @@ int fmd_process_u8_host(fmd_handle h, const uint8_t* iq, int n_channels, int n_s
     return process_host<uchar2>(h, reinterpret_cast<const uchar2*>(iq), n_channels, n_samples);
 }
 
+int fmd_set_output_lag(fmd_handle h, int on) {
+    if (!h) return FMD_ERR_ARG;
+    int rc = sync_all(h);
+    if (rc) return rc;
+    h->lag_outputs = on != 0;
+    h->lazy_extract = h->lazy_capable;        // (a caller that asked for every block's outputs at once had switched it off)
+    return FMD_OK;
+}
+
 int fmd_synchronize(fmd_handle h) {
     if (!h) return FMD_ERR_ARG;
     return sync_all(h);
@@ -846,6 +946,8 @@ int fmd_wait_outputs(fmd_handle h, void* stream) {
     if (!h) return FMD_ERR_ARG;
     if (!h->pipelined || h->n_blocks == 0) return FMD_OK;   // unpipelined: the outputs are already ordered on the caller's stream
     HIP_TRY(h, hipSetDevice(h->device));
+    { int rc = outputs_wanted(h); if (rc) return rc; }
+    if (!h->have_out) return FMD_OK;                        // (fmd_set_output_lag before the second block: nothing queued yet)
     HIP_TRY(h, hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->ev_X[h->out_slot], 0));
     return FMD_OK;
 }
@@ -854,6 +956,8 @@ int fmd_release_outputs(fmd_handle h, void* stream) {
     if (!h) return FMD_ERR_ARG;
     if (h->n_blocks == 0) return FMD_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    { int rc = outputs_wanted(h); if (rc) return rc; }
+    if (!h->have_out) return FMD_OK;
     HIP_TRY(h, hipEventRecord(h->ev_C[h->out_slot], static_cast<hipStream_t>(stream)));
     h->consumer_pending[h->out_slot] = true;
     return FMD_OK;
@@ -861,6 +965,7 @@ int fmd_release_outputs(fmd_handle h, void* stream) {
 
 int fmd_audio_dev(fmd_handle h, const float** d_audio) {
     if (!h || !d_audio) return FMD_ERR_ARG;
+    { int rc = outputs_wanted(h); if (rc) return rc; }
     *d_audio = h->ctx.b.audio[h->out_slot];
     return FMD_OK;
 }
@@ -869,6 +974,7 @@ int fmd_audio_pcm16_dev(fmd_handle h, int16_t* d_pcm, void* stream) {
     if (!h || !d_pcm) return FMD_ERR_ARG;
     if (h->n_blocks == 0) return fail(h, FMD_ERR_ARG, "no block has been processed");
     int rc = fmd_wait_outputs(h, stream);
+    if (!rc && !h->have_out) return fail(h, FMD_ERR_ARG, "no block's outputs are queued yet (fmd_set_output_lag: from the second fmd_submit_* on)");
     if (rc) return rc;
     const Dims& d = h->ctx.d;
     hipError_t e = launch_audio_pcm16(h->ctx.b.audio[h->out_slot], d_pcm, (size_t)d.C * d.n_audio * 2, static_cast<hipStream_t>(stream));
@@ -878,6 +984,7 @@ int fmd_audio_pcm16_dev(fmd_handle h, int16_t* d_pcm, void* stream) {
 
 int fmd_rds_dev(fmd_handle h, const float** d_syms, const int** d_counts) {
     if (!h || !d_syms || !d_counts) return FMD_ERR_ARG;
+    { int rc = outputs_wanted(h); if (rc) return rc; }
     *d_syms = h->ctx.b.rds_sym[h->out_slot];
     *d_counts = h->ctx.b.rds_count[h->out_slot];
     return FMD_OK;
@@ -919,6 +1026,7 @@ int fmd_get_rds_bytes(fmd_handle h, uint8_t* bytes, int cap_bytes_per_channel, i
 
 int fmd_rds_bytes_dev(fmd_handle h, const uint8_t** d_bytes, const int** d_counts, int* cap_bytes_per_channel) {
     if (!h || !d_bytes || !d_counts || !cap_bytes_per_channel) return FMD_ERR_ARG;
+    { int rc = outputs_wanted(h); if (rc) return rc; }
     *d_bytes = h->ctx.b.rds_bytes[h->out_slot];
     *d_counts = h->ctx.b.rds_bytes_count[h->out_slot];
     *cap_bytes_per_channel = h->bytes_cap;
@@ -1088,7 +1196,7 @@ int fmd_selftest_atan2_table(const float* y, const float* x, float* out, size_t 
 int fmd_selftest_atan2_table_u8(const float* y, const float* x, float* out, size_t n) { return selftest_atan2_host(y, x, out, nullptr, n, 2); }
 
 int fmd_selftest_fast_math(int kind, const float* a, const float* b, float* out, size_t n) {
-    if (kind < 0 || kind > 2) return FMD_ERR_ARG;
+    if (kind < 0 || kind > 3) return FMD_ERR_ARG;
     return selftest_atan2_host(a, b ? b : a, out, nullptr, n, 10 + kind);
 }
 

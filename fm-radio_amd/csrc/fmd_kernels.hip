@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restric
 
     const int tiles = d.n_fm_out / T;
     const int c = blockIdx.x / tiles, tile = blockIdx.x % tiles, o0 = tile * T, tid = threadIdx.x;
+    __builtin_assume(tid >= 0 && tid < 256);     // (the bounds of the unrolled staging loops are tested against it)
     const int lane = tid & (kWave - 1), wv = tid >> 6, lrow = lane & 15, lq = lane >> 4;
     const int g_lo = 2 * o0 - G::TAIL;                            // first input index of the tile (block relative)
     const InT* in_c = in + (size_t)c * d.N;
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(256) void k_predecim(Dims d, const InT* __restrict_
     const int tiles = d.n_fm_in / TP;
     const int c = blockIdx.x / tiles, tile = blockIdx.x % tiles;
     const int n0 = tile * TP, tid = threadIdx.x;
+    __builtin_assume(tid >= 0 && tid < 256);     // (the bounds of the unrolled staging loops are tested against it)
     const long g_lo = (long)M * n0 + M - 64;          // first input sample of the tile's first output (block relative)
     const InT* in_c = in + (size_t)c * d.N;
     const float2* tail_c = tail_in + (size_t)c * G::HIST;
@@ -1566,6 +1568,7 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
     const int tiles = d.n_audio / TA;
     const int c = blockIdx.x / tiles, tile = blockIdx.x % tiles;
     const int i0 = tile * TA, tid = threadIdx.x;
+    __builtin_assume(tid >= 0 && tid < 256);     // (the bounds of the unrolled staging loops are tested against it)
     const int lane = tid & (kWave - 1), wv = tid >> 6, lrow = lane & 15, lq = lane >> 4;
     const int s_lo = 4 * i0 - 124;               // first analytic sample staged (block relative), even
     const int n = d.n_fm_out;
@@ -1583,6 +1586,9 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
     float ev[kLmrInlineMax / kWave];
     // all loads first: the fm_out window, the spans' cubics, last block's phase estimates.  A thread loads the window pairs 32 samples
     // behind its analytic pairs — the real-rail samples it mixes later stay in its registers in fp32 — and 16 threads the window's first 32.
+    // LDS word indices of the thread's pairs e = 2 (tid + 256 r): pad(e) / 2 = w4b + 320 r (512 samples = 16 padded groups of 40 elements),
+    // the RDS arrays' pad(e - 4) / 2 = w8b + 320 r (floor shifts: also right where 2 tid - 4 < 0 and r > 0)
+    const int w4b = G::pad(2 * tid) >> 1, w8b = ((2 * tid - 4) + 8 * ((2 * tid - 4) >> 5)) >> 1;
     float2 wv2[PERP], wh2;
     {
 #pragma unroll
@@ -1607,7 +1613,7 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
             const int e = 2 * (tid + 256 * r);
             if (e + 32 < G::WN) {
                 split_bf16(wv2[r].x, h0, l0); split_bf16(wv2[r].y, h1, l1);
-                const int w = G::pad(e + 32) >> 1;
+                const int w = w4b + 20 + 320 * r;           // pad(e + 32) / 2
                 fow_h[w] = pack_hi16(h0, h1); fow_l[w] = pack_hi16(l0, l1);
             }
         }
@@ -1691,12 +1697,12 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
                 }
                 uint32_t h0, l0, h1, l1;
                 if (e < XSP) {
-                    const int w4 = G::pad(e) >> 1;
+                    const int w4 = w4b + 320 * r;
                     split_bf16(m2i[0], h0, l0); split_bf16(m2i[1], h1, l1); lmr_h[w4] = pack_hi16(h0, h1); lmr_l[w4] = pack_hi16(l0, l1);
                     *reinterpret_cast<float2*>(lmr_re + e) = make_float2(m2r[0], m2r[1]);
                 }
                 if (e >= 4) {
-                    const int w8 = G::pad(e - 4) >> 1;
+                    const int w8 = w8b + 320 * r;
                     split_bf16(m3r[0], h0, l0); split_bf16(m3r[1], h1, l1); rre_h[w8] = pack_hi16(h0, h1); rre_l[w8] = pack_hi16(l0, l1);
                     split_bf16(m3i[0], h0, l0); split_bf16(m3i[1], h1, l1); rim_h[w8] = pack_hi16(h0, h1); rim_l[w8] = pack_hi16(l0, l1);
                 }
@@ -2302,6 +2308,7 @@ __global__ void k_selftest_atan2(const float* __restrict__ y, const float* __res
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (table_form == 10) { out[i] = fast_atan2f(y[i], x[i]); }                  // FMD_FLAG_FAST_MATH primitives
+    else if (table_form == 13) { out[i] = fast_atan2_turns(y[i], x[i]); }
     else if (table_form == 11) { out[i] = fast_sin_turns(y[i]); }
     else if (table_form == 12) { out[i] = fast_cos_turns(y[i]); }
     else if (table_form == 2) {   // k_front's discriminator on u8 IQ (operands are small integers)
@@ -2366,6 +2373,23 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
     }
     const int tiles = d.n_fm_out / G::T;
     if constexpr (FAST) {   // tolerance mode: k_front_mfma; with the de-emphasis IIR inside the tile when a channel asks for it
+        if constexpr (TT == 1024) {
+            static const bool big = std::getenv("FMD_FRONT_T2048") != nullptr;
+            if (big && d.n_fm_out % 2048 == 0) {
+                if (ctx.deemph_in_tile) {
+                    auto kern = k_front_mfma<InT, 2048, kDeemphWarmup>;
+                    using GM = FrontGeomM<2048, kDeemphWarmup>;
+                    FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(d.n_fm_out / 2048 * d.C)), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
+                               ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma);
+                } else {
+                    auto kern = k_front_mfma<InT, 2048, 0>;
+                    using GM = FrontGeomM<2048, 0>;
+                    FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(d.n_fm_out / 2048 * d.C)), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
+                               ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma);
+                }
+                return hipGetLastError();
+            }
+        }
         if (ctx.deemph_in_tile) {
             auto kern = k_front_mfma<InT, TT, kDeemphWarmup>;
             using GM = FrontGeomM<TT, kDeemphWarmup>;
@@ -2374,7 +2398,8 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
         } else {
             auto kern = k_front_mfma<InT, TT, 0>;
             using GM = FrontGeomM<TT, 0>;
-            FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
+            static const size_t lds_pad = std::getenv("FMD_FRONT_LDS_PAD") ? (size_t)std::atoi(std::getenv("FMD_FRONT_LDS_PAD")) : 0;   // experiment: occupancy
+            FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), sizeof(float) * GM::LDS_FLOATS + lds_pad, s, d, d_iq,
                        ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma);
         }
         return hipGetLastError();
@@ -2545,10 +2570,19 @@ static hipError_t prepare_front() {
                                        (int)(sizeof(float) * FrontGeom<TT>::LDS_FLOATS));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(float) * FrontGeomM<TT, 0>::LDS_FLOATS));
+                            (int)(sizeof(float) * FrontGeomM<TT, 0>::LDS_FLOATS) + 65536);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, kDeemphWarmup>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(sizeof(float) * FrontGeomM<TT, kDeemphWarmup>::LDS_FLOATS));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, kDeemphWarmup>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(float) * FrontGeomM<TT, kDeemphWarmup>::LDS_FLOATS));
+    if (e != hipSuccess) return e;
+    if constexpr (TT == 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, 2048, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(float) * FrontGeomM<2048, 0>::LDS_FLOATS));
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, 2048, kDeemphWarmup>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(float) * FrontGeomM<2048, kDeemphWarmup>::LDS_FLOATS));
+    }
+    return e;
 }
 
 hipError_t prepare_kernels() {

@@ -166,6 +166,19 @@ int fmd_wait_input(fmd_handle h, void* stream);
 int fmd_synchronize(fmd_handle h);
 /* make `stream` wait (on the device, no host block) until the newest block's outputs are complete */
 int fmd_wait_outputs(fmd_handle h, void* stream);
+/* Which outputs the device-side calls (fmd_wait_outputs, fmd_release_outputs, fmd_audio_dev, fmd_audio_pcm16_dev, fmd_rds_dev,
+ * fmd_rds_bytes_dev) refer to behind fmd_submit_*_dev in the tolerance mode.
+ * Background: there, with 3072 stations' worth of 256 kSa/s blocks or more, a block's extract and RDS stages are queued when the NEXT
+ * block is submitted — behind that block's front end, on the same hardware queue: the two large kernels take turns instead of sharing
+ * the CUs (6 % on the step, DESIGN.md "Schedule") — or as soon as somebody needs them.
+ *   on = 0 (default): the NEWEST block's outputs.  A device-side call that wants them while they are still put off queues them at
+ *       once, and from then on the handle queues every block's stages at submission (a consumer that asks after every block would
+ *       otherwise stall the front end's queue each time).
+ *   on = 1: the newest QUEUED outputs, never forcing anything: after fmd_submit_*_dev of block k those are block k - 1's (nothing
+ *       before the second block: fmd_wait_outputs / fmd_release_outputs do nothing then, fmd_audio_pcm16_dev fails with FMD_ERR_ARG).
+ *       A consumer that takes every block's outputs one submission later (bench.py's per-step gather does) keeps the faster schedule.
+ * fmd_synchronize, the host getters and fmd_process_* always complete the newest block.  Synchronises; call it between blocks. */
+int fmd_set_output_lag(fmd_handle h, int on);
 /* The consumer's side of the lifetime rule: everything queued on `stream` so far (the kernels / copies that read the newest
  * block's output views) must finish before the library overwrites those views, however many blocks are submitted meanwhile.
  * Records an event on `stream`; the library's writers of that buffer slot wait for it on the device.  Never blocks the host. */

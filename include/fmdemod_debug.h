@@ -34,7 +34,8 @@ int fmd_selftest_atan2_table_u8(const float* y, const float* x, float* out, size
 int fmd_selftest_atan2_small(const float* y, const float* x, float* out, uint8_t* ok, size_t n);
 
 /* The FMD_FLAG_FAST_MATH primitives evaluated on the device, for accuracy checks against float64 on the host:
- * kind 0: out = fast atan2(a, b); kind 1: out = sin(2 pi a) (hardware, argument in turns); kind 2: out = cos(2 pi a). */
+ * kind 0: out = fast atan2(a, b); kind 1: out = sin(2 pi a) (hardware, argument in turns); kind 2: out = cos(2 pi a);
+ * kind 3: out = atan2(a, b) / 2 pi, the six-coefficient form of the discriminator and the pilot loop's phase detector. */
 int fmd_selftest_fast_math(int kind, const float* a, const float* b, float* out, size_t n);
 
 /* Host-only (no GPU needed): the tables of the tolerance mode's span-wise pilot PLL (fm-radio_amd/csrc/fmd_kernels.h PllSpanTab) as

@@ -49,6 +49,12 @@ def test_fast_math_primitives(pkg):
     err = np.minimum(err, np.abs(err - 2 * np.pi))          # -pi and +pi are the same angle
     assert err[~both_zero].max() < 5e-7, err[~both_zero].max()
     assert np.all(got[both_zero] == 0.0)                     # atan2(+0, +0) = 0, as libm
+    # the discriminator's / pilot phase detector's form: in turns, six coefficients (2.8e-7 turns by design)
+    got_t = pkg.selftest_fast_math("atan2_turns", y, x)
+    err_t = np.abs(got_t.astype(np.float64) - want / (2 * np.pi))
+    err_t = np.minimum(err_t, np.abs(err_t - 1.0))
+    assert err_t[~both_zero].max() < 3.5e-7, err_t[~both_zero].max()
+    assert np.all(got_t[both_zero] == 0.0)
     t = np.concatenate([rng.uniform(-0.5, 0.5, n), rng.uniform(-2.0, 2.0, n), np.array([0.0, 0.25, -0.25, 0.5, -0.5, 1e-6, -1e-6])]).astype(np.float32)
     for kind, f in (("sin_turns", np.sin), ("cos_turns", np.cos)):
         got = pkg.selftest_fast_math(kind, t)

@@ -198,6 +198,73 @@ def test_release_outputs_holds_a_slot_for_a_slow_consumer(pkg):
     dm.close()
 
 
+def test_submit_schedule_and_output_lag_in_the_tolerance_mode(pkg):
+    """fmd_submit_*_dev on a batch large enough for the deferred schedule (the extract stage of block k queued behind the front end of
+    block k + 1, include/fmdemod.h fmd_set_output_lag): every block's outputs equal those of the block-by-block run, whichever way the
+    caller asks for them —
+      default: wait_outputs right after submit(k) gives block k (and switches the handle to queue-at-submission);
+      a free-running caller gets the last block after synchronize();
+      fmd_set_output_lag(1): the device views after submit(k) are block k - 1's, block k's after synchronize()."""
+    import torch
+    n_ch, bs, nb = 3072, 16384, 9
+    base = _caps(4, nb * bs, 256_000.0, seed=6300)
+    idx = torch.from_numpy(np.arange(n_ch) % 4).cuda()
+    dbase = torch.from_numpy(base).cuda()
+    blocks = [dbase[:, b * bs:(b + 1) * bs][idx].contiguous() for b in range(nb)]
+    ref = pkg.BatchDemod(n_ch, bs, 256_000, pipelined=False, fast_math=True)
+    want, want_bytes = [], []
+    for b in range(nb):
+        ref.process(blocks[b])
+        want.append(ref.audio().copy())
+        want_bytes.append(ref.rds_bytes())
+    ref.close()
+    side = torch.cuda.Stream()
+
+    def same(t, b):
+        return np.array_equal(t.cpu().numpy().view(np.uint32), want[b].view(np.uint32))
+
+    # free-running: nothing asked for until the end
+    dm = pkg.BatchDemod(n_ch, bs, 256_000, fast_math=True)
+    for b in range(nb):
+        dm.submit(blocks[b])
+    dm.synchronize()
+    assert np.array_equal(dm.audio().view(np.uint32), want[-1].view(np.uint32))
+    by, cnt = dm.rds_bytes()
+    assert np.array_equal(cnt, want_bytes[-1][1]) and np.array_equal(by, want_bytes[-1][0])
+    dm.close()
+    # default: the newest block's outputs on request
+    dm = pkg.BatchDemod(n_ch, bs, 256_000, fast_math=True)
+    kept = {}
+    for b in range(nb):
+        dm.submit(blocks[b])
+        if b in (0, 3, 4, nb - 1):
+            with torch.cuda.stream(side):
+                dm.wait_outputs(side)
+                kept[b] = dm.audio_tensor().clone()
+                dm.release_outputs(side)
+    dm.synchronize(); side.synchronize()
+    for b, t in kept.items():
+        assert same(t, b), b
+    dm.close()
+    # lag: the newest queued outputs, never forcing
+    dm = pkg.BatchDemod(n_ch, bs, 256_000, fast_math=True)
+    dm.set_output_lag(True)
+    kept = {}
+    for b in range(nb):
+        dm.submit(blocks[b])
+        with torch.cuda.stream(side):
+            dm.wait_outputs(side)                    # (a no-op behind the first block: nothing is queued yet)
+            if b >= 1:
+                kept[b - 1] = dm.audio_tensor().clone()
+                dm.release_outputs(side)
+    dm.synchronize(); side.synchronize()
+    for b, t in kept.items():
+        assert same(t, b), b
+    assert len(kept) == nb - 1
+    assert np.array_equal(dm.audio().view(np.uint32), want[-1].view(np.uint32))
+    dm.close()
+
+
 @pytest.mark.parametrize("fs,fast", [(256_000, False), (1_024_000, False), (256_000, True), (1_024_000, True)])
 def test_state_snapshot_moves_a_station_between_handles(pkg, fs, fast):
     """fmd_get_state / fmd_set_state: a station's state taken from channel 1 of one handle after 3 blocks and restored into
