@@ -132,6 +132,7 @@ def load_library():
     L.fmd_synchronize.argtypes = [H]
     L.fmd_wait_outputs.argtypes = [H, C.c_void_p]
     L.fmd_set_output_lag.argtypes = [H, C.c_int]
+    L.fmd_outputs_block.argtypes = [H, C.POINTER(C.c_long)]
     L.fmd_wait_input.argtypes = [H, C.c_void_p]
     L.fmd_release_outputs.argtypes = [H, C.c_void_p]
     L.fmd_output_lifetime_blocks.restype = C.c_int
@@ -322,6 +323,12 @@ class BatchDemod:
         ...) refer to the newest block whose output stages are QUEUED — behind submit() of block k that is block k - 1 in the
         tolerance mode — and never force a put-off stage."""
         self._check(self.L.fmd_set_output_lag(self.h, 1 if on else 0))
+
+    def outputs_block(self) -> int:
+        """fmd_outputs_block: index (0 = first since create / reset) of the block the device-side output calls refer to, -1 = none yet."""
+        b = C.c_long(-1)
+        self._check(self.L.fmd_outputs_block(self.h, C.byref(b)))
+        return int(b.value)
 
     def wait_outputs(self, stream=None):
         """Make `stream` (torch stream or raw handle; default: torch current stream) wait for the newest block's outputs."""

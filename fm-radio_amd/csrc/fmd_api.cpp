@@ -60,13 +60,14 @@ struct fmd_handle_s {
     // Tolerance mode, fmd_submit_*: k_extract_mfma shares k_front_mfma's stream and a block's extract + RDS stages are queued when the
     // NEXT block is submitted (behind that block's front end) or when somebody asks for the outputs — see process_dev
     bool lazy_extract = false, lazy_capable = false;
-    struct Deferred { bool active = false; SlotRef ref{}; hipEvent_t pll_dep = nullptr; int slot = 0; ProfiledBlock* pm = nullptr; bool prof_x = false, prof_r = false; } deferred;
+    struct Deferred { bool active = false; SlotRef ref{}; hipEvent_t pll_dep = nullptr; int slot = 0; long block = 0; ProfiledBlock* pm = nullptr; bool prof_x = false, prof_r = false; } deferred;
     hipStream_t last_x_stream = nullptr;     // where the newest extract stage was queued, and the event behind it: consecutive blocks'
     hipEvent_t last_x_event = nullptr;       // extract stages are ordered (L-R phase estimate), whichever of the two streams they take
     long n_blocks = 0;                       // blocks submitted since create/reset; slot = n_blocks % kSlots
     int out_slot = 0;                        // slot holding the newest outputs (the newest block's; under fmd_set_output_lag: the newest QUEUED outputs)
     int sub_slot = 0;                        // slot of the newest submitted block
     bool have_out = false;                   // some block's output stages have been queued since create / reset
+    long out_block = -1;                     // ... and which block's (0 = the first since create / reset) the output views are
     bool lag_outputs = false;                // fmd_set_output_lag
     hipEvent_t ev_consumed = nullptr;        // fires when the newest block's input buffer has been read (fmd_wait_input)
     int device = 0;
@@ -364,7 +365,7 @@ int zero_history(fmd_handle h, hipStream_t s) {
     h->n_blocks = 0;
     h->deferred.active = false; h->last_x_event = nullptr;
     h->ev_consumed = nullptr;
-    h->out_slot = 0; h->sub_slot = 0; h->have_out = false;
+    h->out_slot = 0; h->sub_slot = 0; h->have_out = false; h->out_block = -1;
     for (bool& u : h->slot_used) u = false;
     for (bool& u : h->consumer_pending) u = false;
     h->poisoned = false;
@@ -410,7 +411,7 @@ int launch_deferred(fmd_handle h, bool behind_front) {
         if (e != hipSuccess) { h->poisoned = true; return fail(h, FMD_ERR_DEVICE, "k_rds_sync launch: %s", hipGetErrorString(e)); }
     }
     if (dep != h->ev_X[q.slot]) HIP_TRY(h, hipEventRecord(h->ev_X[q.slot], sR));
-    h->out_slot = q.slot; h->have_out = true;
+    h->out_slot = q.slot; h->have_out = true; h->out_block = q.block;
     return FMD_OK;
 }
 
@@ -568,7 +569,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     // the previous block's extract + RDS stages, if fmd_submit_* put them off: behind this block's front end (launch_deferred)
     { int rc = launch_deferred(h, true); if (rc) return rc; }
     if (lazy) {
-        h->deferred.active = true; h->deferred.ref = ref; h->deferred.pll_dep = dep; h->deferred.slot = slot; h->deferred.pm = pm;
+        h->deferred.active = true; h->deferred.ref = ref; h->deferred.pll_dep = dep; h->deferred.slot = slot; h->deferred.block = h->n_blocks; h->deferred.pm = pm;
         h->deferred.prof_x = pm && prof_stage(ST_EXTRACT); h->deferred.prof_r = pm && prof_stage(ST_RDS);
     } else {
         if (pipe) HIP_TRY(h, hipStreamWaitEvent(sX, dep, 0));
@@ -584,7 +585,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     h->last_block_deemph = h->ctx.any_deemph != 0;
     h->slot_used[slot] = true;
     h->sub_slot = slot;
-    if (!lazy) { h->out_slot = slot; h->have_out = true; }
+    if (!lazy) { h->out_slot = slot; h->have_out = true; h->out_block = h->n_blocks; }
     h->n_blocks++;
     if (h->deemph_linger) { h->deemph_linger = false; h->ctx.any_deemph = 0; }
     h->last_stream = s;
@@ -934,6 +935,14 @@ int fmd_set_output_lag(fmd_handle h, int on) {
     if (rc) return rc;
     h->lag_outputs = on != 0;
     h->lazy_extract = h->lazy_capable;        // (a caller that asked for every block's outputs at once had switched it off)
+    return FMD_OK;
+}
+
+int fmd_outputs_block(fmd_handle h, long* block) {
+    if (!h || !block) return FMD_ERR_ARG;
+    int rc = outputs_wanted(h);
+    if (rc) return rc;
+    *block = h->have_out ? h->out_block : -1;
     return FMD_OK;
 }
 

@@ -174,11 +174,15 @@ int fmd_wait_outputs(fmd_handle h, void* stream);
  *   on = 0 (default): the NEWEST block's outputs.  A device-side call that wants them while they are still put off queues them at
  *       once, and from then on the handle queues every block's stages at submission (a consumer that asks after every block would
  *       otherwise stall the front end's queue each time).
- *   on = 1: the newest QUEUED outputs, never forcing anything: after fmd_submit_*_dev of block k those are block k - 1's (nothing
- *       before the second block: fmd_wait_outputs / fmd_release_outputs do nothing then, fmd_audio_pcm16_dev fails with FMD_ERR_ARG).
+ *   on = 1: the newest QUEUED outputs, never forcing anything: after fmd_submit_*_dev of block k those are block k - 1's where the
+ *       stages are put off, block k's otherwise — fmd_outputs_block says which (nothing before the second block at most: fmd_wait_outputs / fmd_release_outputs do nothing then, fmd_audio_pcm16_dev fails with FMD_ERR_ARG).
  *       A consumer that takes every block's outputs one submission later (bench.py's per-step gather does) keeps the faster schedule.
  * fmd_synchronize, the host getters and fmd_process_* always complete the newest block.  Synchronises; call it between blocks. */
 int fmd_set_output_lag(fmd_handle h, int on);
+/* which block the device-side output calls refer to right now: 0 = the first block since fmd_create / fmd_reset, -1 = none yet.
+ * (Under fmd_set_output_lag(h, 1) a consumer needs it to tell k from k - 1: batches below the size named above, and the exact mode,
+ * queue every block's stages at submission.) */
+int fmd_outputs_block(fmd_handle h, long* block);
 /* The consumer's side of the lifetime rule: everything queued on `stream` so far (the kernels / copies that read the newest
  * block's output views) must finish before the library overwrites those views, however many blocks are submitted meanwhile.
  * Records an event on `stream`; the library's writers of that buffer slot wait for it on the device.  Never blocks the host. */

@@ -254,6 +254,7 @@ def test_submit_schedule_and_output_lag_in_the_tolerance_mode(pkg):
         dm.submit(blocks[b])
         with torch.cuda.stream(side):
             dm.wait_outputs(side)                    # (a no-op behind the first block: nothing is queued yet)
+            assert dm.outputs_block() == b - 1
             if b >= 1:
                 kept[b - 1] = dm.audio_tensor().clone()
                 dm.release_outputs(side)
