@@ -28,7 +28,7 @@ from pathlib import Path
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before HIP initialises: one hardware queue per pipeline stream
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before HIP initialises: one hardware queue per pipeline stream
 
 ROOT = Path(__file__).resolve().parent
 for p in (ROOT, ROOT / "tests", ROOT / "oracle"):

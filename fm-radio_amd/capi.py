@@ -104,7 +104,7 @@ def load_library():
     if not p.exists():
         raise FileNotFoundError(f"{p} missing: run __graft_entry__.build() / make -C {CSRC}")
     # the pipeline uses 5 streams beside the caller's: give them their own hardware queues (default is 4 per process)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     try:
         # torch bundles its own HIP runtime; load it FIRST so this process ends up with a single libamdhip64
         # (two runtimes in one process do not see each other's devices, streams or allocations)

@@ -96,8 +96,9 @@ void warn_hw_queues_once() {
     if (n >= 7) return;
     const char* q = getenv("FMD_QUIET");
     if (q && *q && *q != '0') return;
-    fprintf(stderr, "libfmdemod: GPU_MAX_HW_QUEUES=%s: the pipelined demodulator uses 7 streams and loses its overlap on fewer hardware "
-                    "queues; set GPU_MAX_HW_QUEUES=8 in the environment before the HIP runtime initialises (see INTEGRATION.md)\n", v ? v : "(unset, default 4)");
+    fprintf(stderr, "libfmdemod: GPU_MAX_HW_QUEUES=%s: the pipelined demodulator uses up to 7 streams and loses its overlap on fewer hardware "
+                    "queues; set GPU_MAX_HW_QUEUES=16 in the environment before the HIP runtime initialises (8 if nothing else in the process "
+                    "creates streams; see INTEGRATION.md)\n", v ? v : "(unset, default 4)");
 }
 
 thread_local std::string g_create_error;

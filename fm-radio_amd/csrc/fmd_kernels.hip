@@ -13,10 +13,19 @@
 //   k_lmr_phase    [tiny]      a11 phase integrate (the next block's k_extract needs it)
 //   k_rds_sync     [serial]    a13 AGC, a14 BPSK synchroniser, Manchester decode   (own stream)
 //
-// Arithmetic contract: this file is compiled with -ffp-contract=off; every fused multiply-add is an
+// Tolerance mode (FMD_FLAG_FAST_MATH) — the same path on four kernels:
+//
+//   k_front_mfma   [parallel]  a0-a3 (arctangent in turns, decimating FIR on the matrix cores), optional a4 inside the tile -> fm_out plane
+//   k_pll_span     [serial]    a6 peak filter as a scan on the real rail, a7 AGC state, a8 the loop 128 samples at a time
+//                              (fmd_kernels_fast.inc)                                          -> one cubic per span (pll_poly)
+//   k_extract_mfma [parallel]  a5 Hilbert FIR, a9 mixers, a10 / a12 decimating FIRs (matrix cores), a11, a15, the RDS AGC's
+//                              block power as per-tile partial sums                            -> audio, rds, lmr_est, rds_pow
+//   k_rds_sync<1>  [serial]    a13, a14, Manchester decode
+//
+// Arithmetic contract of the EXACT mode: this file is compiled with -ffp-contract=off; every fused multiply-add is an
 // explicit fmaf() and every sum is associated exactly as the reference's AVX2+FMA build associates it
 // (8 / 4 lane accumulators per dot product, horizontal sums in the x86 order), so results are
-// bit-identical to the CPU path.  No MFMA: the FIRs are VALU work staged through LDS.
+// bit-identical to the CPU path; no MFMA there: the FIRs are VALU work staged through LDS.
 #include "fmd_kernels.h"
 #include <hip/hip_ext.h>
 #include "fmd_math.h"
