@@ -2382,23 +2382,6 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
     }
     const int tiles = d.n_fm_out / G::T;
     if constexpr (FAST) {   // tolerance mode: k_front_mfma; with the de-emphasis IIR inside the tile when a channel asks for it
-        if constexpr (TT == 1024) {
-            static const bool big = std::getenv("FMD_FRONT_T2048") != nullptr;
-            if (big && d.n_fm_out % 2048 == 0) {
-                if (ctx.deemph_in_tile) {
-                    auto kern = k_front_mfma<InT, 2048, kDeemphWarmup>;
-                    using GM = FrontGeomM<2048, kDeemphWarmup>;
-                    FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(d.n_fm_out / 2048 * d.C)), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
-                               ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma);
-                } else {
-                    auto kern = k_front_mfma<InT, 2048, 0>;
-                    using GM = FrontGeomM<2048, 0>;
-                    FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(d.n_fm_out / 2048 * d.C)), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
-                               ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma);
-                }
-                return hipGetLastError();
-            }
-        }
         if (ctx.deemph_in_tile) {
             auto kern = k_front_mfma<InT, TT, kDeemphWarmup>;
             using GM = FrontGeomM<TT, kDeemphWarmup>;
@@ -2407,8 +2390,7 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
         } else {
             auto kern = k_front_mfma<InT, TT, 0>;
             using GM = FrontGeomM<TT, 0>;
-            static const size_t lds_pad = std::getenv("FMD_FRONT_LDS_PAD") ? (size_t)std::atoi(std::getenv("FMD_FRONT_LDS_PAD")) : 0;   // experiment: occupancy
-            FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), sizeof(float) * GM::LDS_FLOATS + lds_pad, s, d, d_iq,
+            FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
                        ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma);
         }
         return hipGetLastError();
@@ -2579,18 +2561,11 @@ static hipError_t prepare_front() {
                                        (int)(sizeof(float) * FrontGeom<TT>::LDS_FLOATS));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(float) * FrontGeomM<TT, 0>::LDS_FLOATS) + 65536);
+                            (int)(sizeof(float) * FrontGeomM<TT, 0>::LDS_FLOATS));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, kDeemphWarmup>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(float) * FrontGeomM<TT, kDeemphWarmup>::LDS_FLOATS));
     if (e != hipSuccess) return e;
-    if constexpr (TT == 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, 2048, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(float) * FrontGeomM<2048, 0>::LDS_FLOATS));
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, 2048, kDeemphWarmup>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(float) * FrontGeomM<2048, kDeemphWarmup>::LDS_FLOATS));
-    }
     return e;
 }
 
