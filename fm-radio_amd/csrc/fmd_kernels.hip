@@ -2023,6 +2023,13 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
             const int ch = one_pass ? step : step - chunks;
             float2* buf = ring[step & (kRingSlots - 1)];
             for (int t4 = 0; t4 < kChunk; t4 += 4) {
+                // (this wavefront is alone on its SIMD and issue-bound at ~5 cycles per instruction, whatever the instruction: what counts
+                //  is their number.  Within a group the phase error is constant: the loop filter's input term is computed once per group —
+                //  the first sample may still see the previous error in x1 —, the integrator steps by a constant, and the NCO phase is
+                //  wrapped once per group: v_sin / v_cos take arguments up to 256 turns, the phase moves < 1e-3 turns per sample.)
+                const float lpf_in = pll_err * (k.bpsk_b0 + k.bpsk_b1), lpf_in0 = fmaf(pll_x1, k.bpsk_b0, pll_err * k.bpsk_b1), int_step = pll_err * KTs_pi;
+                pll_x1 = pll_err;
+                mix_t = mix_t - rintf(mix_t);
 #pragma unroll
                 for (int u4 = 0; u4 < 4; u4++) {
                     const int t = t4 + u4;
@@ -2030,12 +2037,11 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
                     const float p = gain * xr.x, q = gain * xr.y;
                     if (keep_taps) buf[lane * kRowC + t] = make_float2(p, q);
                     // carrier PLL PI controller; PLL_Mixer::Update: f_center 0, f_gain 10
-                    const float pll_lpf = fmaf(pll_x1, k.bpsk_b0, fmaf(pll_y1, k.bpsk_a0, pll_err * k.bpsk_b1));
-                    pll_x1 = pll_err; pll_y1 = pll_lpf;
-                    pll_int = clampf(fmaf(pll_err, KTs_pi, pll_int), -1.0f, 1.0f);
+                    const float pll_lpf = fmaf(pll_y1, k.bpsk_a0, u4 ? lpf_in : lpf_in0);
+                    pll_y1 = pll_lpf;
+                    pll_int = clampf(pll_int + int_step, -1.0f, 1.0f);
                     const float control = clampf(fmaf(pll_lpf, 0.3f, pll_int), -1.0f, 1.0f);
-                    const float yy = fmaf(control, Ts10, mix_t);
-                    mix_t = yy - rintf(yy);
+                    mix_t = fmaf(control, Ts10, mix_t);
                     const float ps = fast_sin_turns(mix_t), pc = fast_cos_turns(mix_t);
                     const float iq_r = fmaf(pc, p, -(q * ps));
                     const float iq_i = fmaf(p, ps, q * pc);
@@ -2054,8 +2060,7 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
                     dump_r = fmaf(0.25f, iq_r, dump_r);
                     dump_i = fmaf(0.25f, iq_i, dump_i);
                     // TED_Clock::update: fcenter 2000, fgain 1500
-                    const float cfreq = fmaf(clampf(-PI_ted, -1.0f, 1.0f), 1.5e3f, 2e3f);
-                    const float dd = cfreq * Ts;
+                    const float dd = fmaf(clampf(-PI_ted, -1.0f, 1.0f), 1.5e3f * Ts, 2e3f * Ts);     // (cfreq Ts in one step)
                     const float cy = dd + clock;
                     const bool wrapped = !(fmaf(-dd, 0.5f, 1.0f) > cy);
                     clock = wrapped ? 0.0f : cy;
