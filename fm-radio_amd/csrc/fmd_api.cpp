@@ -759,7 +759,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
         if (!rc) rc = dev_alloc(h, &b.dt_tail[p], C * 128);
         if (!rc) rc = dev_alloc(h, &b.fo_tail[p], C * 64);
     }
-    // Tolerance mode: the analytic signal as two planes and the NCO phase as span polynomials; the interleaved / per-sample streams
+    // Tolerance mode: fm_out as a plane (rows with the previous block's tail in front) and the NCO phase as span polynomials; the interleaved / per-sample streams
     // only for FMD_FLAG_KEEP_TAPS (the getters) and for block lengths that run k_extract<128> (audio blocks not multiples of 256)
     const bool fast = h->ctx.fast != 0;
     const bool streams = !fast || h->ctx.keep_taps || (d.n_audio % 256) != 0;

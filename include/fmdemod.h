@@ -206,8 +206,8 @@ int fmd_get_rds_symbols(fmd_handle h, float* syms /* [C][n_rds] */, int* counts 
  *   "lmr" GetLMRAudioOutput [C][n_audio] | "rds" GetRDSOutput (post-AGC) [C][n_rds][2]
  *   "rds_raw_sym" GetRDSRawSymbols [C][n_rds][2] | "lmr_phase" GetAudioLMRPhaseError [C]
  *   "agc_pilot_gain" [C] | "agc_rds_gain" [C]
- *   FMD_FLAG_FAST_MATH keeps the analytic signal as two planes and the NCO phase as one cubic per 128 samples: "fm_out_iq" and
- *   "pll_dt" then need FMD_FLAG_KEEP_TAPS too; "pll_poly" [C][1 + n_fm_out / 128][4] (tolerance mode only) is always there
+ *   FMD_FLAG_FAST_MATH keeps fm_out alone (the kernels that need the Hilbert rail make it for themselves) and the NCO phase as one
+ *   cubic per 128 samples: "fm_out_iq" and "pll_dt" then need FMD_FLAG_KEEP_TAPS too; "pll_poly" [C][1 + n_fm_out / 128][4] (tolerance mode only) is always there
  * Copies the current block's values to `out` (host); *n_floats receives the float count.  Needs
  * FMD_FLAG_KEEP_TAPS for the streams a fused pipeline would not otherwise materialise. */
 int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats, size_t* n_floats);
