@@ -264,6 +264,23 @@ def test_submit_schedule_and_output_lag_in_the_tolerance_mode(pkg):
     assert len(kept) == nb - 1
     assert np.array_equal(dm.audio().view(np.uint32), want[-1].view(np.uint32))
     dm.close()
+    # fmd_submit_* and fmd_process_* mixed, a control change and a state snapshot in between: the put-off stages are queued first
+    dm = pkg.BatchDemod(n_ch, bs, 256_000, fast_math=True)
+    for b in range(nb):
+        if b in (2, 5, 6):
+            dm.process(blocks[b])
+            assert np.array_equal(dm.audio().view(np.uint32), want[b].view(np.uint32)), b
+        else:
+            dm.submit(blocks[b])
+        if b == 3:
+            blob = dm.get_state(17)                  # (synchronises: block 3 completes)
+            assert np.array_equal(dm.audio().view(np.uint32), want[3].view(np.uint32))
+            dm.set_state(17, blob)
+        if b == 4:
+            dm.set_controls(pkg.default_controls())  # same values: applied at the next block boundary, behind a full drain
+    dm.synchronize()
+    assert np.array_equal(dm.audio().view(np.uint32), want[-1].view(np.uint32))
+    dm.close()
 
 
 @pytest.mark.parametrize("fs,fast", [(256_000, False), (1_024_000, False), (256_000, True), (1_024_000, True)])
