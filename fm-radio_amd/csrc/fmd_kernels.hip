@@ -1887,7 +1887,10 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
                                                         float2* __restrict__ rds_raw_sym, int* __restrict__ rds_count,
                                                         uint8_t* __restrict__ rds_bytes, int* __restrict__ rds_bytes_count,
                                                         int bytes_cap, int keep_taps, const float* __restrict__ rds_pow, int n_pow) {
-    constexpr int kRingSlots = 4;
+    // Tolerance mode: two ring slots instead of four (the loader keeps two chunks in registers beyond the one it stores: 7 us of
+    // look-ahead are enough): 43 KB of LDS instead of 78 on the 64 CUs this kernel's workgroups sit on for most of a block's time —
+    // k_extract_mfma gets three workgroups beside it there instead of two
+    constexpr int kRingSlots = FAST ? 2 : 4;
     constexpr int kSignWords = 33;                                       // 1024 symbols per lane between two runs of the decoder (+1: odd stride, no bank conflicts)
     __shared__ __attribute__((aligned(16))) float2 ring[kRingSlots][kWave * kRowC];
     __shared__ unsigned sign_bits[kWave * kSignWords];
@@ -1903,6 +1906,20 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
         auto at = [&](int i) { return (i < steps ? i % chunks : chunks - 1) * kChunk; };
         ChunkRegsC ra = chunk_load_c(rds, n, c0, d.C, at(0));
         ChunkRegsC rb = chunk_load_c(rds, n, c0, d.C, at(1));
+        if constexpr (FAST) {
+            chunk_store_c(ra, ring[0]);
+            ra = chunk_load_c(rds, n, c0, d.C, at(2));
+            __syncthreads();                                             // step 0 is in the ring
+            for (int i = 0; i < steps; i += 2) {                         // while wave 0 works on step i: step i + 1 into the other slot
+                chunk_store_c(rb, ring[(i + 1) & 1]);
+                rb = chunk_load_c(rds, n, c0, d.C, at(i + 3));
+                __syncthreads();
+                chunk_store_c(ra, ring[i & 1]);                          // (step i + 2, while wave 0 works on step i + 1)
+                ra = chunk_load_c(rds, n, c0, d.C, at(i + 4));
+                __syncthreads();
+            }
+            return;
+        }
         chunk_store_c(ra, ring[0]);
         ra = chunk_load_c(rds, n, c0, d.C, at(2));
         chunk_store_c(rb, ring[1]);
