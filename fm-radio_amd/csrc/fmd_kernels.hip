@@ -291,7 +291,60 @@ __global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restric
         adl[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 1) * kWave + lane]);
     }
     // a0-a2: staging, arctangent (all loads first)
-    {
+    bool staged = false;
+    if constexpr (sizeof(InT) == 8) {
+        // cf32 input away from the block's start: 16 bytes per lane (two samples).  The tile starts at an odd sample (TAIL is odd): the
+        // pairs start one sample earlier, pair q = samples 2 q - 1 and 2 q of the tile; what is left behind the full rounds, one per thread.
+        if (tile != 0) {
+            constexpr int NQF = ((NW + 1) / 2) / 256 * 256, PERQ = NQF / 256, REST0 = 2 * NQF - 1, PERR = (NW - REST0 + 255) / 256;
+            const float4* src = reinterpret_cast<const float4*>(in_c + (g_lo - 1));
+            float4 qb[PERQ]; float2 rb[PERR];
+#pragma unroll
+            for (int r = 0; r < PERQ; r++) qb[r] = src[tid + 256 * r];
+#pragma unroll
+            for (int r = 0; r < PERR; r++) { const int i = REST0 + tid + 256 * r; if (i < NW) rb[r] = load_iq(in_c, (unsigned)(g_lo + i)); }
+#pragma unroll
+            for (int r = 0; r < PERQ; r++) {
+                const int q = tid + 256 * r;
+                const float t1 = fast_atan2_turns(qb[r].w, qb[r].z);
+                if (q > 0) theta[2 * q - 1] = fast_atan2_turns(qb[r].y, qb[r].x);
+                theta[2 * q] = t1;
+            }
+#pragma unroll
+            for (int r = 0; r < PERR; r++) { const int i = REST0 + tid + 256 * r; if (i < NW) theta[i] = fast_atan2_turns(rb[r].y, rb[r].x); }
+            staged = true;
+        }
+    }
+    if constexpr (sizeof(InT) == 2 && (NW + 1) / 8 >= 256) {
+        // u8 input away from the block's start: 16 bytes per lane are eight samples (the tile starts at sample 1 of such a group:
+        // octet o = samples 8 o - 1 .. 8 o + 6 of the tile); one full round, the rest one sample per thread.
+        if (tile != 0) {
+            constexpr int NOF = ((NW + 1) / 8) / 256 * 256, PERO = NOF / 256, REST0 = 8 * NOF - 1, PERR = (NW - REST0 + 255) / 256;
+            static_assert((G::TAIL & 7) == 7, "the tile starts at sample 1 (mod 8) of the row");
+            const uint4* src = reinterpret_cast<const uint4*>(in_c + (g_lo - 1));
+            uint4 ob[PERO]; float2 rb[PERR];
+#pragma unroll
+            for (int r = 0; r < PERO; r++) ob[r] = src[tid + 256 * r];
+#pragma unroll
+            for (int r = 0; r < PERR; r++) { const int i = REST0 + tid + 256 * r; if (i < NW) rb[r] = load_iq(in_c, (unsigned)(g_lo + i)); }
+#pragma unroll
+            for (int r = 0; r < PERO; r++) {
+                const int o = tid + 256 * r;
+                const uint32_t w[4] = {ob[r].x, ob[r].y, ob[r].z, ob[r].w};
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t ww = w[u >> 1] >> (16 * (u & 1));
+                    const float re = (float)(ww & 0xffu) - 127.0f, im = (float)((ww >> 8) & 0xffu) - 127.0f;   // reference src/app.cpp:56-62
+                    const float t = fast_atan2_turns(im, re);
+                    if (u > 0 || o > 0) theta[8 * o - 1 + u] = t;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < PERR; r++) { const int i = REST0 + tid + 256 * r; if (i < NW) theta[i] = fast_atan2_turns(rb[r].y, rb[r].x); }
+            staged = true;
+        }
+    }
+    if (!staged) {
         constexpr int PER = (NW + 255) / 256;
         float2 buf[PER];
         if (tile != 0) {
