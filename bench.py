@@ -466,6 +466,7 @@ def main() -> None:
         dm.set_controls(ctl)
 
     do_gather = world > 1 and not args.no_gather and args.gather != "none"
+    dm_n_audio = dm.rates.n_audio
     pcm16 = args.gather_format == "pcm16"
     if do_gather:
         gather = pkg.AudioGather(dist, torch, C, dm.rates.n_audio, world, device, mode=args.gather,
@@ -616,6 +617,12 @@ def main() -> None:
                    "deemphasis_us": args.deemphasis or None,
                    "parallelism": f"channel-sharded x{world}" + gather_note},
         "gather_verified": gather_verified,
+        # what the per-step gather asks of the collector's xGMI links (one direct link per peer): at throughput-mode rates this, not the
+        # demodulation, can bound the multi-GPU step
+        "gather": None if not do_gather else {
+            "format": args.gather_format, "bytes_per_rank_per_step": C * dm_n_audio * 2 * (2 if pcm16 else 4),
+            "gb_per_s_per_link_at_this_rate": C * dm_n_audio * 2 * (2 if pcm16 else 4) * K / el / 1e9,
+            "collector_ingress_gb_per_s": (world - 1) * C * dm_n_audio * 2 * (2 if pcm16 else 4) * K / el / 1e9 if args.gather == "root" else None},
         "channels_at_realtime": value * 1e6 / fs,
         "msa_per_gpu": value / world,
         "roofline": roofline,
