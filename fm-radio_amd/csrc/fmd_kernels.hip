@@ -28,6 +28,7 @@
 // bit-identical to the CPU path; no MFMA there: the FIRs are VALU work staged through LDS.
 #include "fmd_kernels.h"
 #include <hip/hip_ext.h>
+#include <cstdlib>
 #include "fmd_math.h"
 
 // launch with the stage's timing events attached to the dispatch packet when the caller asked for them
@@ -2620,6 +2621,13 @@ hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Buffers& b = ctx.b;
     if (ctx.fast) {
         const bool partials = d.n_audio % 256 == 0;       // k_extract_mfma ran and left the block's power as 2 partial sums per tile
+        static const bool two_waves = std::getenv("FMD_RDS_TWO_WAVES") != nullptr;      // (A/B hook: the two-wavefront form)
+        if (partials && !two_waves) {      // the loop split over a mixer and a clock wavefront (fmd_kernels_fast.inc)
+            FMD_LAUNCH(r, true, true, k_rds_sync3, dim3(serial_waves(d)), dim3(3 * kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
+                       b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps,
+                       b.rds_pow[r.buf], 2 * (d.n_audio / 256));
+            return hipGetLastError();
+        }
         FMD_LAUNCH(r, true, true, k_rds_sync<true>, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
                    b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps,
                    partials ? b.rds_pow[r.buf] : (const float*)nullptr, 2 * (d.n_audio / 256));

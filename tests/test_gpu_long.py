@@ -103,3 +103,59 @@ def test_tolerance_mode_rds_bits_post_lock_20_stations_with_known_pi(pkg):
         groups = decode_groups(rds_g[c])
         pi = (0x1234 + c) & 0xFFFF                   # synth.fm_capture: the station's PI code
         assert len(groups) >= 12 and sum(1 for w in groups if w[0] == pi) >= len(groups) - 1, (c, len(groups))
+
+
+def _oracle_rds(args):
+    n_blocks, seed, c, coeff_bytes = args
+    import oraclelib as O
+    k = O.Coeffs.from_buffer_copy(coeff_bytes)
+    cap = _capture_u8(n_blocks, seed, c)
+    o = O.run_chain(cap, BS, FS, u8=True, coeffs=k, streams=["rds_sym"])
+    return c, cap, o["rds_bytes"], o["rds_sym"], o["rds_count"]
+
+
+def test_tolerance_mode_rds_stage_on_three_wavefronts(pkg):
+    """The tolerance mode's RDS stage, k_rds_sync3 (mixer and clock wavefronts one group of four samples apart, fmd_kernels_fast.inc), with
+    and without FMD_FLAG_KEEP_TAPS (the post-AGC write-back and the raw symbols are extra paths in it), against the oracle: bits identical
+    from lock on with the known PI codes, soft symbols within the mode's bound wherever the symbol counts agree; and against each other."""
+    import test_gpu_fast as F
+    from rds_groups import decode_groups
+    n_st, n_blocks, seed = 24, 32, 6600                # 2 s
+    out = {}
+    for keep in (False, True):
+        dm = pkg.BatchDemod(n_st, BS, FS, keep_taps=keep, fast_math=True)
+        coeff = bytes(dm.get_coeffs(0))
+        if not out:
+            with ProcessPoolExecutor(min(n_st, max(1, (os.cpu_count() or 8) // 2))) as ex:
+                res = sorted(ex.map(_oracle_rds, [(n_blocks, seed, c, coeff) for c in range(n_st)]), key=lambda r: r[0])
+            caps = np.stack([r[1] for r in res])
+        rds = [b"" for _ in range(n_st)]
+        syms = [[] for _ in range(n_st)]
+        counts = np.zeros((n_st, n_blocks), np.int64)
+        for b in range(n_blocks):
+            assert dm.process(np.ascontiguousarray(caps[:, b * BS:(b + 1) * BS])) == 0
+            by, bc = dm.rds_bytes()
+            sy, sc = dm.rds_symbols()
+            for c in range(n_st):
+                rds[c] += by[c, :bc[c]].tobytes()
+                syms[c].append(sy[c, :sc[c]].copy())
+                counts[c, b] = sc[c]
+        dm.close()
+        out[keep] = ([np.frombuffer(x, np.uint8) for x in rds], [np.concatenate(x) for x in syms], counts)
+    worst = 0.0
+    for keep in (False, True):
+        rds_g, sym_g, cnt_g = out[keep]
+        for c in range(n_st):
+            assert F.same_bits_once_in_lock(rds_g[c], res[c][2], skip_bits=5 * 76), (keep, c)
+            groups = decode_groups(rds_g[c])
+            pi = (0x1234 + c) & 0xFFFF
+            assert len(groups) >= 12 and sum(1 for w in groups if w[0] == pi) >= len(groups) - 1, (keep, c, len(groups))
+            o_cnt = np.asarray(res[c][4]).reshape(-1)[:n_blocks]
+            if np.array_equal(cnt_g[c], o_cnt):            # same symbol clock from the first block on: compare the soft symbols in lock
+                lo = int(o_cnt[:8].sum())
+                e = float(np.percentile(np.abs(sym_g[c][lo:].astype(np.float64) - np.asarray(res[c][3], np.float64).reshape(-1)[lo:lo + len(sym_g[c]) - lo]), 99))
+                worst = max(worst, e)
+    print(f"RDS soft symbols, 99th percentile of |difference| to the oracle in lock: {worst:.2e}")
+    assert worst <= 2e-3 * 0.7
+    same = sum(int(np.array_equal(out[False][0][c], out[True][0][c])) for c in range(n_st))
+    assert same == n_st                                     # (the flag changes nothing the demodulator computes)
