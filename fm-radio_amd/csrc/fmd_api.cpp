@@ -737,10 +737,10 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     h->ctx.keep_taps = (cfg->flags & FMD_FLAG_KEEP_TAPS) ? 1 : 0;
     h->ctx.fast = (cfg->flags & FMD_FLAG_FAST_MATH) ? 1 : 0;
     if (const char* e = getenv("FMD_DEBUG_SKIP_STAGES")) h->debug_skip = (unsigned)strtoul(e, nullptr, 0);   // development knob
-    // fmd_submit_* puts a block's extract stage off until the next block's front end is queued (launch_deferred) where the kernels are
-    // large enough to fill the chip on their own: 3072 stations' worth of 256 kSa/s blocks and up (same-box A/B at 4096 / 8192
-    // stations: 6 % on the step; at 1024 / 2048, where the stages' latency is what matters, 1-3 % the other way)
-    h->lazy_capable = h->pipelined && h->ctx.fast && (size_t)d.C * d.n_fm_out >= (size_t)3072 * 8192 && !std::getenv("FMD_NO_LAZY_EXTRACT");
+    // fmd_submit_* puts a block's extract stage off until the next block's front end is queued (launch_deferred) from 1024 stations'
+    // worth of 256 kSa/s blocks on (same-box A/B with the three-wavefront RDS stage: +-0 at 1024 stations, +1 % at 1536, +6 % at 2048,
+    // +10 % at 2560, +6-7 % from 3072 on; smaller batches are pure stage latency and keep every stage on a queue of its own)
+    h->lazy_capable = h->pipelined && h->ctx.fast && (size_t)d.C * d.n_fm_out >= (size_t)1024 * 8192 && !std::getenv("FMD_NO_LAZY_EXTRACT");
     h->lazy_extract = h->lazy_capable;
 
     fmd_controls def;

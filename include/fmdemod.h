@@ -168,7 +168,7 @@ int fmd_synchronize(fmd_handle h);
 int fmd_wait_outputs(fmd_handle h, void* stream);
 /* Which outputs the device-side calls (fmd_wait_outputs, fmd_release_outputs, fmd_audio_dev, fmd_audio_pcm16_dev, fmd_rds_dev,
  * fmd_rds_bytes_dev) refer to behind fmd_submit_*_dev in the tolerance mode.
- * Background: there, with 3072 stations' worth of 256 kSa/s blocks or more, a block's extract and RDS stages are queued when the NEXT
+ * Background: there, with 1024 stations' worth of 256 kSa/s blocks or more, a block's extract and RDS stages are queued when the NEXT
  * block is submitted — behind that block's front end, on the same hardware queue: the two large kernels take turns instead of sharing
  * the CUs (6 % on the step, DESIGN.md "Schedule") — or as soon as somebody needs them.
  *   on = 0 (default): the NEWEST block's outputs.  A device-side call that wants them while they are still put off queues them at
