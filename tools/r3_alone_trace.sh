@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 export GPU_MAX_HW_QUEUES=8
-for s in 56 41 49; do
+for s in 56 41 49 31; do
   export FMD_DEBUG_SKIP_STAGES=$s
   rm -rf /tmp/alone_$s
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/alone_$s -- python3 bench.py $1 --no-kernel-times --no-cpu-baseline --no-other-mode --no-configs --no-host-fed > /dev/null 2>&1
