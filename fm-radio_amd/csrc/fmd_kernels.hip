@@ -2622,8 +2622,8 @@ hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     if (ctx.fast) {
         const bool partials = d.n_audio % 256 == 0;       // k_extract_mfma ran and left the block's power as 2 partial sums per tile
         static const bool two_waves = std::getenv("FMD_RDS_TWO_WAVES") != nullptr;      // (A/B hook: the two-wavefront form)
-        if (partials && !two_waves) {      // the loop split over a mixer and a clock wavefront (fmd_kernels_fast.inc)
-            FMD_LAUNCH(r, true, true, k_rds_sync3, dim3(serial_waves(d)), dim3(3 * kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
+        if (partials && !two_waves) {      // the loop split over mixer, clock and dump wavefronts (fmd_kernels_fast.inc)
+            FMD_LAUNCH(r, true, true, k_rds_sync3, dim3(serial_waves(d)), dim3(4 * kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
                        b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps,
                        b.rds_pow[r.buf], 2 * (d.n_audio / 256));
             return hipGetLastError();

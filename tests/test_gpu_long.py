@@ -114,8 +114,8 @@ def _oracle_rds(args):
     return c, cap, o["rds_bytes"], o["rds_sym"], o["rds_count"]
 
 
-def test_tolerance_mode_rds_stage_on_three_wavefronts(pkg):
-    """The tolerance mode's RDS stage, k_rds_sync3 (mixer and clock wavefronts one group of four samples apart, fmd_kernels_fast.inc), with
+def test_tolerance_mode_rds_stage_on_pipelined_wavefronts(pkg):
+    """The tolerance mode's RDS stage, k_rds_sync3 (mixer, clock and dump wavefronts one group of four samples apart each, fmd_kernels_fast.inc), with
     and without FMD_FLAG_KEEP_TAPS (the post-AGC write-back and the raw symbols are extra paths in it), against the oracle: bits identical
     from lock on with the known PI codes, soft symbols within the mode's bound wherever the symbol counts agree; and against each other."""
     import test_gpu_fast as F
