@@ -152,12 +152,12 @@ static uint16_t bf16_rne(float x) {
     return (uint16_t)(u >> 16);
 }
 static float bf16_to_f32(uint16_t h) { const uint32_t u = (uint32_t)h << 16; float x; std::memcpy(&x, &u, 4); return x; }
-// one FIR's image: A[m][t] = taps[t - stride m], t < 32 ksteps; [k-step][hi / lo][lane][8]
-void toeplitz_image(const float* taps, int n_taps, int stride, int ksteps, uint16_t* img) {
+// one FIR's image: A[m][t] = taps[t - shift - stride m], t < 32 ksteps; [k-step][hi / lo][lane][8]
+void toeplitz_image(const float* taps, int n_taps, int stride, int ksteps, uint16_t* img, int shift = 0) {
     for (int sK = 0; sK < ksteps; sK++)
         for (int l = 0; l < 64; l++)
             for (int i = 0; i < 8; i++) {
-                const int t = 32 * sK + 8 * (l / 16) + i, idx = t - stride * (l % 16);
+                const int t = 32 * sK + 8 * (l / 16) + i, idx = t - shift - stride * (l % 16);
                 const float v = (idx >= 0 && idx < n_taps) ? taps[idx] : 0.0f;
                 const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
                 img[(((size_t)sK * 2 + 0) * 64 + l) * 8 + i] = hi;
@@ -320,10 +320,12 @@ void design_pll_span(const fmd_coeffs& k, PllSpanTab* t) {
     for (int i = 0; i < 32; i++) t->hil[i] = k.b_hilbert[2 * i + 1];
 }
 
-void design_front_mfma(const fmd_coeffs& k, std::vector<uint16_t>& img) {
-    img.assign((size_t)2 * 3 * 2 * 64 * 8, 0);
+void design_front_mfma(const fmd_coeffs& k, int m, std::vector<uint16_t>& img) {
+    const int ks_pre = m > 1 ? (64 + (8 - m) + 15 * m + 31) / 32 : 0;      // k_predecim_mfma (PredecimGeomM::KS, ::SH)
+    img.assign((size_t)kFrontImgU4 * 8 + (size_t)ks_pre * 2 * 64 * 8, 0);
     toeplitz_image(k.b_fm_out, 64, 2, 3, img.data());
     toeplitz_image(k.b_hilbert, 65, 1, 3, img.data() + (size_t)3 * 2 * 64 * 8);
+    if (m > 1) toeplitz_image(k.b_fm_in, 64, m, ks_pre, img.data() + (size_t)kFrontImgU4 * 8, 8 - m);
 }
 
 void fill_ctx_coeffs(fmd_handle h) {
@@ -794,7 +796,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
         rc = dev_alloc(h, &b.pilot_tab, 1);
         if (!rc) {
             std::vector<uint16_t> img;
-            design_front_mfma(h->base, img);
+            design_front_mfma(h->base, m, img);
             rc = dev_alloc(h, &b.front_mfma, img.size() * 2 / sizeof(uint4));
             if (!rc && (hipMemcpyAsync(b.front_mfma, img.data(), img.size() * 2, hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
                         hipStreamSynchronize(h->own_stream) != hipSuccess)) rc = fail(h, FMD_ERR_DEVICE, "operand table upload failed");

@@ -82,6 +82,7 @@ struct PllSpanTab {
 };
 // rows of the fast-mode planes carry the previous block's last samples in front (written by k_pll_span of that block), so the
 // consumers address history and block uniformly
+static constexpr int kFrontImgU4 = 2 * 3 * 2 * 64;   // uint4s of k_front_mfma's two operand images in Buffers::front_mfma; k_predecim_mfma's image follows them
 static constexpr int kFoPad = 192;   // fm_out: k_extract_mfma reaches back 124 + 64 samples (its Hilbert FIR), k_pll_span 33 (65 while a station warms up)
 
 struct Dims {
@@ -146,7 +147,7 @@ struct Buffers {
     uint4*  aud_img;                 // ... of k_extract_mfma's audio FIRs, one per distinct cut-off: [slot][k-step][hi/lo][lane]
     int2*   aud_idx;                 // [C] slots of a station's L+R and L-R images
     uint4*  rds_img;                 // ... of the RDS FIR
-    uint4*  front_mfma;              // FMD_FLAG_FAST_MATH only: Toeplitz operand images of k_front_mfma's two FIRs, [fir][k-step][hi/lo][lane]
+    uint4*  front_mfma;              // FMD_FLAG_FAST_MATH only: Toeplitz operand images of k_front_mfma's two FIRs, [fir][k-step][hi/lo][lane]; m > 1: then k_predecim_mfma's
     unsigned int* pll_chain;         // [wavefronts of k_pilot_pll + 1] last block number each wavefront completed; [last] = watchdog flag
     unsigned long long* spec_stats;  // [8] speculation counters: pll {chunks, general, replayed, -}, rds {chunks, general, replayed, -}
 };

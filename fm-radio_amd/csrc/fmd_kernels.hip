@@ -570,6 +570,144 @@ __global__ __launch_bounds__(256) void k_predecim(Dims d, const InT* __restrict_
 }
 
 // =============================================================================================
+// k_predecim_mfma — FMD_FLAG_FAST_MATH form of k_predecim: the decimate-by-M FIR of both rails as bf16 x 3 matrix products
+// (the scheme of FrontGeomM), the discriminator's arctangent taken on the accumulators; fm_in = phases in turns.
+//   Y[m][col] = y[16 col + m] = sum_t A[m][t] w[16 M col + t],   A[m][t] = b[t - SH - M m]   (t < 64 + SH + 15 M: 4 / 6 K-steps of 32)
+// k_predecim spends 128 VALU FMAs per output and is VALU-bound on u8 input and co-limited on cf32; here the VALU only splits the
+// samples into bf16 halves (u8 samples ARE bf16 numbers: one half, two MFMAs per K-step instead of three) and the kernel streams.
+// LDS: one bf16 array per rail and half, 8 elements of padding per column stride (16 M elements) so that the 16 lanes of a
+// ds_read_b128 pass (one per column) hit 16 different 16-byte bank groups.
+// =============================================================================================
+template <int M, int TPX>
+struct PredecimGeomM {
+    static constexpr int TP = TPX;                    // outputs per workgroup
+    static constexpr int NT = TP / 256;               // 16 x 16 output tiles
+    static constexpr int SH = 8 - M;                  // the staged window starts SH samples early, on a multiple of 8 samples: 16-byte loads of u8 captures
+    static constexpr int NB = M * TP + 64;            // input samples staged: w[j] = s[M n0 + M - 64 - SH + j];  A[m][t] = b[t - SH - M m]
+    static constexpr int KS = (64 + SH + 15 * M + 31) / 32;
+    static constexpr int SEG = 16 * M;                // elements between two columns' windows
+    static constexpr int NEP = NB + 8 * (NB / SEG + 1);   // padded elements per array
+    static constexpr int HIST = 64;
+    static_assert(NB % 8 == 0 && SEG * (TP / 16 - 1) + 32 * KS <= NB, "every operand read stays inside the staged samples");
+};
+// x = hi + lo + O(2^-17 x): both halves rounded (half up) to bf16, as bit patterns in the upper 16 bits
+__device__ __forceinline__ void split_bf16_rn(float x, uint32_t& hi, uint32_t& lo) {
+    hi = (f32_bits(x) + 0x8000u) & 0xffff0000u;
+    lo = f32_bits(x - bits_f32(hi)) + 0x8000u;
+}
+template <int M, typename InT, int TPX>
+__global__ __launch_bounds__(256) void k_predecim_mfma(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
+                                                       float2* __restrict__ tail_out, float* __restrict__ fm_in, const uint4* __restrict__ tab) {
+    using G = PredecimGeomM<M, TPX>;
+    constexpr int TP = G::TP, NB = G::NB, KS = G::KS, SEG = G::SEG;
+    constexpr bool U8 = sizeof(InT) == 2;
+    constexpr int NH = U8 ? 1 : 2;                                    // halves kept per rail
+    constexpr int NWD = G::NEP / 2;                                   // words per array
+    __shared__ __attribute__((aligned(16))) uint32_t arr[2 * NH * NWD];   // [rail][half]
+    const int tiles = d.n_fm_in / TP;
+    const int c = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int n0 = tile * TP, tid = threadIdx.x;
+    __builtin_assume(tid >= 0 && tid < 256);
+    const int lane = tid & (kWave - 1), wv = tid >> 6, lrow = lane & 15, lq = lane >> 4;
+    const int g_lo = M * n0 + M - 64 - G::SH;                         // first input sample staged (block relative), a multiple of 8
+    const InT* in_c = in + (size_t)c * d.N;
+    const float2* tail_c = tail_in + (size_t)c * G::HIST;
+    auto word_of = [](int pair) { return pair + 4 * (pair / (SEG / 2)); };      // pair p = elements 2 p, 2 p + 1 -> word of the padded array
+    if constexpr (!U8) {
+        constexpr int ITEMS = NB / 2, PER = (ITEMS + 255) / 256;      // two samples (16 bytes) per lane and round; all loads first
+        float4 buf[PER];
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int j = tid + 256 * r;
+            if (j < ITEMS) {
+                int g = g_lo + 2 * j;
+                g = g < d.N - 2 ? g : d.N - 2;                       // the last tile's overhang (M samples under zero taps): read inside the row
+                buf[r] = (g < 0) ? *reinterpret_cast<const float4*>(tail_c + (G::HIST + g)) : *reinterpret_cast<const float4*>(in_c + g);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int j = tid + 256 * r;
+            if (j < ITEMS) {
+                uint32_t h0, l0, h1, l1;
+                const int w = word_of(j);
+                split_bf16_rn(buf[r].x, h0, l0); split_bf16_rn(buf[r].z, h1, l1);
+                arr[0 * NWD + w] = pack_hi16(h0, h1); arr[1 * NWD + w] = pack_hi16(l0, l1);
+                split_bf16_rn(buf[r].y, h0, l0); split_bf16_rn(buf[r].w, h1, l1);
+                arr[2 * NWD + w] = pack_hi16(h0, h1); arr[3 * NWD + w] = pack_hi16(l0, l1);
+            }
+        }
+    } else {
+        constexpr int ITEMS = NB / 8, PER = (ITEMS + 255) / 256;      // eight samples (16 bytes) per lane and round
+        uint4 buf[PER];
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int j = tid + 256 * r, g = g_lo + 8 * j;
+            if (j < ITEMS && g >= 0) buf[r] = *reinterpret_cast<const uint4*>(in_c + (g < d.N - 8 ? g : d.N - 8));      // (the last tile's overhang: inside the row)
+        }
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int j = tid + 256 * r, g = g_lo + 8 * j;
+            if (j < ITEMS) {
+                uint32_t re[8], im[8];
+                if (g < 0) {        // the block's first tile: history, kept as cf32 (u8 captures: integers; after a cf32 block: rounded to bf16)
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const float2 v = tail_c[G::HIST + g + u]; re[u] = f32_bits(v.x) + 0x8000u; im[u] = f32_bits(v.y) + 0x8000u; }
+                } else {
+                    const uint32_t w4[4] = {buf[r].x, buf[r].y, buf[r].z, buf[r].w};
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const uint32_t ww = w4[u >> 1] >> (16 * (u & 1));
+                        re[u] = f32_bits((float)(ww & 0xffu) - 127.0f); im[u] = f32_bits((float)((ww >> 8) & 0xffu) - 127.0f);      // reference src/app.cpp:56-62
+                    }
+                }
+                // (integers of at most 8 bits: exact in bf16)
+                const int w = word_of(4 * j);
+                *reinterpret_cast<uint4*>(arr + 0 * NWD + w) = make_uint4(pack_hi16(re[0], re[1]), pack_hi16(re[2], re[3]), pack_hi16(re[4], re[5]), pack_hi16(re[6], re[7]));
+                *reinterpret_cast<uint4*>(arr + 1 * NWD + w) = make_uint4(pack_hi16(im[0], im[1]), pack_hi16(im[2], im[3]), pack_hi16(im[4], im[5]), pack_hi16(im[6], im[7]));
+            }
+        }
+    }
+    // the Toeplitz operands (not before the staging: its load buffers are the register peak)
+    bf16x8 adh[KS], adl[KS];
+    if (wv < G::NT) {
+#pragma unroll
+        for (int sK = 0; sK < KS; sK++) {
+            adh[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 0) * kWave + lane]);
+            adl[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 1) * kWave + lane]);
+        }
+    }
+    __syncthreads();
+    float* out_c = fm_in + (size_t)c * d.n_fm_in + n0;
+    for (int ct = wv; ct < G::NT; ct += 4) {
+        const int col = 16 * ct + lrow;
+        f32x4 acc[2][3];
+#pragma unroll
+        for (int sK = 0; sK < KS; sK++) {
+            const int e = SEG * col + 32 * sK + 8 * lq;              // element index, a multiple of 8
+            const int w = (e + 8 * (e / SEG)) / 2;
+#pragma unroll
+            for (int rail = 0; rail < 2; rail++) {
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(arr + (rail * NH) * NWD + w));
+                acc[rail][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bh, sK ? acc[rail][0] : kZero4, 0, 0, 0);
+                acc[rail][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adl[sK], bh, sK ? acc[rail][1] : kZero4, 0, 0, 0);
+                if constexpr (!U8) {
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(arr + (rail * NH + 1) * NWD + w));
+                    acc[rail][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bl, sK ? acc[rail][2] : kZero4, 0, 0, 0);
+                }
+            }
+        }
+        f32x4 yr, yi;
+        if constexpr (U8) { yr = acc[0][0] + acc[0][1]; yi = acc[1][0] + acc[1][1]; }
+        else { yr = acc[0][0] + (acc[0][1] + acc[0][2]); yi = acc[1][0] + (acc[1][1] + acc[1][2]); }
+        *reinterpret_cast<float4*>(out_c + 16 * col + 4 * lq) = make_float4(fast_atan2_turns(yi[0], yr[0]), fast_atan2_turns(yi[1], yr[1]),
+                                                                            fast_atan2_turns(yi[2], yr[2]), fast_atan2_turns(yi[3], yr[3]));
+    }
+    // the last 64 input samples of the block are the next block's history
+    if (tile == tiles - 1 && tid < G::HIST) tail_out[(size_t)c * G::HIST + tid] = load_iq(in_c, (unsigned)(d.N - G::HIST + tid));
+}
+
+// =============================================================================================
 // Lane-per-channel serial kernels.  A wavefront owns 64 adjacent channels; time runs in chunks of
 // 32 samples that are loaded row-wise (coalesced, 16 B per lane) and transposed through LDS so each
 // lane then walks its own channel.  The next chunk's global loads are in flight while the current
@@ -2482,7 +2620,17 @@ template <int M, typename InT>
 static hipError_t launch_predecim(const LaunchCtx& ctx, SlotRef r, const InT* d_iq, hipStream_t s) {
     const Dims& d = ctx.d;
     using G = PredecimGeom<M>;
-    if (ctx.fast)
+    static const bool valu_form = std::getenv("FMD_PREDECIM_VALU") != nullptr;      // (A/B hook: the tolerance mode's first decimator on the VALU)
+    // tile: 2048 input samples of cf32 (16 KB; the kernel then sits on its HBM floor whatever the tile), 8192 of u8 (16 KB as well:
+    // with 4 KB per workgroup too few bytes are in flight per CU); blocks that are no multiple of it: 256 outputs per workgroup
+    constexpr int TPM = (sizeof(InT) == 2 ? 8192 : 2048) / M;
+    if (ctx.fast && !valu_form && d.n_fm_in % TPM != 0 && d.n_fm_in % 256 == 0) {
+        FMD_LAUNCH(r, true, true, (k_predecim_mfma<M, InT, 256>), dim3((unsigned)(d.n_fm_in / 256 * d.C)), dim3(256), 0, s, d, d_iq, ctx.b.pre_tail[r.par], ctx.b.pre_tail[r.par ^ 1],
+                   reinterpret_cast<float*>(ctx.b.fm_in[r.buf]), ctx.b.front_mfma + kFrontImgU4);
+    } else if (ctx.fast && !valu_form && d.n_fm_in % TPM == 0) {
+        FMD_LAUNCH(r, true, true, (k_predecim_mfma<M, InT, TPM>), dim3((unsigned)(d.n_fm_in / TPM * d.C)), dim3(256), 0, s, d, d_iq, ctx.b.pre_tail[r.par], ctx.b.pre_tail[r.par ^ 1],
+                   reinterpret_cast<float*>(ctx.b.fm_in[r.buf]), ctx.b.front_mfma + kFrontImgU4);
+    } else if (ctx.fast)
         FMD_LAUNCH(r, true, true, (k_predecim<M, InT, true>), dim3((unsigned)(d.n_fm_in / G::TP * d.C)), dim3(256), 0, s, d, d_iq, ctx.b.pre_tail[r.par], ctx.b.pre_tail[r.par ^ 1],
                    ctx.b.fm_in[r.buf], ctx.front);
     else

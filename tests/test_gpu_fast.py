@@ -147,7 +147,7 @@ def _compare(pkg, caps, bs, fs, from_block=0, sym_skip_s=0.4, **kw):
     return worst, counts_equal, bytes_equal, bits_equal
 
 
-@pytest.mark.parametrize("fs,u8", [(256_000, False), (256_000, True), (1_024_000, False), (2_048_000, False)])
+@pytest.mark.parametrize("fs,u8", [(256_000, False), (256_000, True), (1_024_000, False), (1_024_000, True), (2_048_000, False), (2_048_000, True)])
 def test_fast_mode_is_within_the_north_star_tolerance_of_the_oracle(pkg, fs, u8):
     """Every block from the very first (acquisition included): audio, L+R, L-R and the discriminator output within 1e-4 RMS,
     RDS bits identical once the synchroniser is in lock (same_bits_once_in_lock), and for most stations from the first
@@ -167,6 +167,35 @@ def test_fast_mode_is_within_the_north_star_tolerance_of_the_oracle(pkg, fs, u8)
     assert worst["lmr_audio_excess"] <= 1.0, worst     # L-R and audio: every block within 1e-4 (lmr_audio_excess: the one allowance and why)
     assert worst["rds_sym"] <= 2e-3 * 0.7   # 99 % of the symbols within 2e-3 of their RMS (~0.7)
     assert worst["pll_dt"] <= 5e-5          # turns
+
+
+def test_fast_mode_first_decimator_small_tile_and_format_switch(pkg):
+    """k_predecim_mfma's 256-output tiles (u8 blocks that are no multiple of its 2048-output tile: 12288 samples at 1.024 MSa/s), and a
+    handle fed u8 blocks and cf32 blocks in turn (the first decimator's history is kept as cf32 whatever the capture's format):
+    discriminator output and L+R within 1e-4 RMS of the oracle."""
+    fs, bs, nb = 1_024_000, 12288, 48
+    caps = _caps(3, nb * bs, float(fs), seed=9300, u8=True)
+    worst, _, _, _ = _compare(pkg, caps, bs, fs)
+    print("small tiles:", {k: f"{v:.2e}" for k, v in worst.items()})
+    for k in ("lpr", "fm_out_iq"):
+        assert worst[k] <= TOL_RMS, (k, worst[k])
+    # u8 and cf32 blocks in turn: the cf32 blocks carry the same integers, so the oracle's u8 run is the reference for both
+    bs = 65536
+    caps = _caps(2, 6 * bs, float(fs), seed=9301, u8=True)
+    dm = pkg.BatchDemod(2, bs, fs, keep_taps=True, fast_math=True)
+    coeffs = [dm.get_coeffs(c) for c in range(2)]
+    lpr = []
+    for b in range(6):
+        blk = np.ascontiguousarray(caps[:, b * bs:(b + 1) * bs])
+        if b % 2:
+            blk = blk.astype(np.float32) - 127.0                      # (reference src/app.cpp:56-62)
+        assert dm.process(blk) == 0
+        lpr.append(dm.stream("lpr").copy())
+    dm.close()
+    lpr = np.concatenate(lpr, axis=1)
+    for c in range(2):
+        o = O.run_chain(caps[c], bs, fs, u8=True, coeffs=lib_coeffs_to_oracle(coeffs[c]), streams=["lpr"])
+        assert rms(lpr[c].astype(np.float64) - o["lpr"].reshape(-1)) <= TOL_RMS
 
 
 def test_fast_mode_blocks_longer_than_the_inline_lmr_phase_limit(pkg):
