@@ -614,6 +614,16 @@ __global__ __launch_bounds__(256) void k_predecim_mfma(Dims d, const InT* __rest
     const InT* in_c = in + (size_t)c * d.N;
     const float2* tail_c = tail_in + (size_t)c * G::HIST;
     auto word_of = [](int pair) { return pair + 4 * (pair / (SEG / 2)); };      // pair p = elements 2 p, 2 p + 1 -> word of the padded array
+    // the Toeplitz operands (cf32: not before the staging, whose load buffers are the register peak; u8: first, the staging is short)
+    bf16x8 adh[KS], adl[KS];
+    auto load_operands = [&]() {
+#pragma unroll
+        for (int sK = 0; sK < KS; sK++) {
+            adh[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 0) * kWave + lane]);
+            adl[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 1) * kWave + lane]);
+        }
+    };
+    if constexpr (U8) load_operands();
     if constexpr (!U8) {
         constexpr int ITEMS = NB / 2, PER = (ITEMS + 255) / 256;      // two samples (16 bytes) per lane and round; all loads first
         float4 buf[PER];
@@ -669,15 +679,7 @@ __global__ __launch_bounds__(256) void k_predecim_mfma(Dims d, const InT* __rest
             }
         }
     }
-    // the Toeplitz operands (not before the staging: its load buffers are the register peak)
-    bf16x8 adh[KS], adl[KS];
-    if (wv < G::NT) {
-#pragma unroll
-        for (int sK = 0; sK < KS; sK++) {
-            adh[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 0) * kWave + lane]);
-            adl[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 1) * kWave + lane]);
-        }
-    }
+    if constexpr (!U8) { if (wv < G::NT) load_operands(); }
     __syncthreads();
     float* out_c = fm_in + (size_t)c * d.n_fm_in + n0;
     for (int ct = wv; ct < G::NT; ct += 4) {
@@ -2593,6 +2595,10 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
         if (ctx.fast) return launch_front<InT, TT, true>(ctx, r, d_iq, s);
     }
     if constexpr (TT == 512) {
+        if constexpr (FAST && sizeof(InT) == 2) {   // u8 captures: 2048-output tiles (4 KB of input per 1024-output workgroup leaves too few bytes in flight per CU)
+            static const bool t1024 = std::getenv("FMD_FRONT_U8_T1024") != nullptr;      // (A/B hook)
+            if (d.n_fm_out % 2048 == 0 && !ctx.deemph_in_tile && !t1024) return launch_front<InT, 2048, FAST>(ctx, r, d_iq, s);
+        }
         if (d.n_fm_out % 1024 == 0) return launch_front<InT, 1024, FAST>(ctx, r, d_iq, s);
     }
     const int tiles = d.n_fm_out / G::T;
