@@ -146,6 +146,8 @@ int fmd_get_coeffs(fmd_handle h, int channel, fmd_coeffs* k);
  * the block run on the library's own streams and overlap with the neighbouring blocks' stages (up to six blocks in
  * flight); outputs become readable after fmd_synchronize / fmd_wait_outputs and stay valid as the lifetime rule at the
  * top of this header says.  *_host: `iq` is a host pointer; copies, runs, synchronises.
+ * `d_iq` may start at any sample (8 / 2 bytes) of an allocation, as the reference's span may; blocks that start on a 16-byte
+ * boundary are read fastest (16 bytes per lane).
  * A call that fails with FMD_ERR_DEVICE after some of its kernels were queued leaves the handle in FMD_ERR_STATE. */
 int fmd_process_cf32_dev(fmd_handle h, const float* d_iq, int n_channels, int n_samples, void* stream);
 int fmd_process_u8_dev(fmd_handle h, const uint8_t* d_iq, int n_channels, int n_samples, void* stream);

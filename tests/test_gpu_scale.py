@@ -135,6 +135,34 @@ def test_low_work_pll_kernel_pipelined_without_host_sync(pkg):
             assert np.array_equal(got[nb - 1][k], want[nb - 1][k]), k
 
 
+@pytest.mark.parametrize("fs,u8,fast", [(256_000, False, True), (256_000, True, True), (1_024_000, False, True), (1_024_000, True, True),
+                                        (256_000, False, False), (1_024_000, True, False)])
+def test_device_input_at_any_sample_alignment(pkg, fs, u8, fast):
+    """The reference takes a span of samples at whatever address (broadcast_fm_demod.h:231); the kernels read 16 bytes per lane where the
+    capture allows.  A device block that starts one sample (8 / 2 bytes) into an allocation gives the same bits as an aligned one."""
+    import torch
+    bs, n_ch, nb = fs * 64 // 1000, 3, 3
+    caps = _caps(n_ch, nb * bs, float(fs), seed=7700, u8=u8)
+    outs = []
+    for shift in (0, 1):
+        dm = pkg.BatchDemod(n_ch, bs, fs, fast_math=fast)
+        audio = []
+        for b in range(nb):
+            blk = torch.from_numpy(np.ascontiguousarray(caps[:, b * bs:(b + 1) * bs])).cuda()
+            if shift:
+                flat = torch.empty(blk.numel() + 2 * shift, dtype=blk.dtype, device="cuda")
+                view = flat[2 * shift:].view(n_ch, bs, 2)
+                view.copy_(blk)
+                blk = view
+                assert blk.data_ptr() % 16 != 0 and blk.is_contiguous()
+            assert dm.process(blk) == 0
+            audio.append(dm.audio().copy())
+        by, bc = dm.rds_bytes()
+        outs.append((np.concatenate(audio, axis=1), by.copy(), bc.copy()))
+        dm.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+
+
 def test_outputs_stay_valid_for_the_stated_number_of_blocks(pkg):
     """include/fmdemod.h: a block's output views stay valid while at most FMD_OUTPUT_LIFETIME_BLOCKS further blocks have been
     submitted.  Read block 3's device views after exactly that many more submissions (no host sync in between)."""
