@@ -60,6 +60,16 @@ def algorithmic_bytes_per_sample(fs: int, u8: bool) -> float:
 SIDE_QUEUE_KERNELS = ("k_rds_sync", "k_pll_span", "k_lmr_phase")
 
 
+def lookup_traffic(kernel: str, C: int, fs: int, block: int, u8: bool, fast: bool):
+    """HBM bytes per launch of `kernel` in this configuration from the committed PMC table (profiles/hbm_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes, tools/r3_collect.sh + tools/r3_digest.py), or None if the configuration was not profiled."""
+    tf = ROOT / "profiles" / "hbm_traffic.json"
+    try:
+        return json.loads(tf.read_text()).get(f"{kernel}|C={C}|fs={fs}|block={block}|{'u8' if u8 else 'cf32'}|{'fast' if fast else 'exact'}")
+    except Exception:
+        return None
+
+
 def dominant_kernel(avg_ms: dict, ms_per_step: float, fast: bool):
     """The kernel `roofline` is quoted on: the longest average launch.  Tolerance mode: its two throughput kernels (k_front_mfma,
     k_extract_mfma) take turns on one queue while the serial stages (k_pll_span: one wavefront per SIMD; k_rds_sync: 64 wavefronts) run
@@ -320,7 +330,8 @@ def measure_config(torch, pkg, device, label: str, C: int, fs: int, u8: bool, fa
             "mode": MODE_TEXT[fast], "steps": steps, "ms_per_step": el / steps * 1e3, "value": value, "unit": "MSa/s",
             "channels_at_realtime": value * 1e6 / fs, "algorithmic_bytes_per_sample": bps,
             "roofline": {"kernel": dom[0], "avg_launch_ms": dom[1], "frac": (bps * C * block / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom[1] else None,
-                         "whole_step_frac": bps * value * 1e6 / 1e9 / HBM_PEAK_GBS, "kernels_ms_per_step": kt}}
+                         "whole_step_frac": bps * value * 1e6 / 1e9 / HBM_PEAK_GBS, "traffic": lookup_traffic(dom[0], C, fs, block, u8, fast) if dom[0] else None,
+                         "kernels_ms_per_step": kt}}
 
 
 # what the two arithmetic modes promise and what tests/ assert (tests/test_gpu_fast.py, tests/test_gpu_long.py)
@@ -554,15 +565,7 @@ def main() -> None:
         avg_ms = dom[1]
         algo_bytes = bps * C * block  # per launch: every kernel launch covers one block of all local channels
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tf = ROOT / "profiles" / "hbm_traffic.json"
-        if tf.exists():
-            try:
-                tj = json.loads(tf.read_text())
-                key = f"{dom[0]}|C={C}|fs={fs}|block={block}|{'u8' if args.u8 else 'cf32'}|{'fast' if args.fast_math else 'exact'}"
-                traffic = tj.get(key)
-            except Exception:
-                traffic = None
+        traffic = lookup_traffic(dom[0], C, fs, block, args.u8, args.fast_math)
         # second roof: the chain is fp32-VALU work; profiles/valu_instructions.json holds the PMC count of VALU
         # wave-instructions one block costs (tools/collect_profiles.sh), the chip issues 1024 SIMDs x clock / 4 of them per second
         valu = None
@@ -608,7 +611,8 @@ def main() -> None:
         "vs_baseline": None,
         "dtype": DTYPE_TEXT[args.fast_math],
         "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[2]: {C} synthetic FM channels/GPU @ {fs} Sa/s, {block}-sample blocks, "
+        "config": {"workload": ("BASELINE configs[2]: " if (C, fs, args.u8) == (4096, 256000, False) else "variant of BASELINE configs[2]: ") +
+                               f"{C} synthetic FM channels/GPU @ {fs} Sa/s, {block}-sample blocks, "
                                f"{'u8' if args.u8 else 'cf32'} IQ resident in HBM, full stereo + pilot PLL + RDS",
                    "channels_per_gpu": C, "fs_baseband": fs, "block_size": block, "ingest": "u8" if args.u8 else "cf32",
                    "preroll_blocks": P, "resident_signal": f"{n_blocks_resident} consecutive blocks cycled (phase-continuous for the 19 kHz pilot)",

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Round-3 evidence (run on the GPU box through gpurun, from the repo root): the default bench line, kernel-trace statistics and a
 # pipelined trace digest of the same command, and PMC passes of the un-pipelined run — counters only, one rocprofv3 run per
-# counter set, no tracing domains combined with --pmc.  BENCH_ARGS=--exact for the exact mode.  Outputs: gpurun_out/r3prof<sfx>/.
+# counter set, no tracing domains combined with --pmc.  BENCH_ARGS=--exact for the exact mode (SFX names another configuration's output).  Outputs: gpurun_out/r3prof<sfx>/.
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 X="${BENCH_ARGS:-}"
-SFX=""; [ -n "$X" ] && SFX="_exact"
+if [ -z "${SFX+x}" ]; then SFX=""; [ -n "$X" ] && SFX="_exact"; fi      # SFX=_1024k BENCH_ARGS="--fs 1024000": another configuration
 O=$R/gpurun_out/r3prof$SFX
 rm -rf $O && mkdir -p $O
 cd $R
