@@ -181,10 +181,24 @@ def bench_wideband(args, torch, pkg, device) -> dict:
     ch = pkg.Channelizer(fs_in, centers, float(fs), max_input_samples=n_in)
     dm = pkg.BatchDemod(C, block, fs, device=device.index, fast_math=args.fast_math)
     outs = [torch.empty((C, block, 2), dtype=torch.float32, device=device) for _ in range(4)]
+    # fmd_process_* would order this stream — and with it the NEXT block's channeliser launch — behind the demodulator's read of the
+    # block (two queue hops of ~50 us each around a 165 us kernel).  fmd_submit_* + fmd_wait_input on a side stream instead: the
+    # channeliser runs back to back, and a station buffer is rewritten only once the front end has read it (four buffers rotate).
+    main, side = torch.cuda.current_stream(device), torch.cuda.Stream(device=device)
+    consumed = [None] * len(outs)
 
     def step(k):
-        y = ch.process(wide[k % n_res], out=outs[k % 4])
-        dm.process(y)
+        j = k % len(outs)
+        if not args.fast_math:       # (exact mode: its pilot loops hand over from block to block and gain nothing from more blocks in flight)
+            dm.process(ch.process(wide[k % n_res], out=outs[j]))
+            return
+        if consumed[j] is not None:
+            main.wait_event(consumed[j])
+        y = ch.process(wide[k % n_res], out=outs[j])
+        dm.submit(y, ready_stream=main)
+        dm.wait_input(side)
+        consumed[j] = torch.cuda.Event()
+        consumed[j].record(side)
 
     for k in range(P + W):
         step(k)
