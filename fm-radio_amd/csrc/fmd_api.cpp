@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <complex>
 #include <cstring>
 #include <map>
 #include <new>
@@ -60,9 +61,20 @@ struct fmd_handle_s {
     // Tolerance mode, fmd_submit_*: k_extract_mfma shares k_front_mfma's stream and a block's extract + RDS stages are queued when the
     // NEXT block is submitted (behind that block's front end) or when somebody asks for the outputs — see process_dev
     bool lazy_extract = false, lazy_capable = false;
-    struct Deferred { bool active = false; SlotRef ref{}; hipEvent_t pll_dep = nullptr; int slot = 0; long block = 0; ProfiledBlock* pm = nullptr; bool prof_x = false, prof_r = false; } deferred;
+    bool no_fused_pll = false;               // development A/B: the deferred pilot stage as a launch of its own
+    bool pll_eager = false;                  // development A/B: the pilot stage queued at submission on its own queue (round 3's arrangement)
+    // pll_pending: the block's pilot stage has not been queued either — it rides in the next block's front-end launch (k_front_mfma<FUSED>) or,
+    // where that is not possible (a start-up block, the getters' per-sample streams, a flush), goes in front of the extract stage on its own;
+    // front_dep: the event behind the stage that made the block's fm_out; pll_dep / pll_stream: where the pilot stage was queued (NULL event: same
+    // queue as the front end, nothing to wait for)
+    struct Deferred { bool active = false, pll_pending = false, front_cross = false; SlotRef ref{}; hipEvent_t pll_dep = nullptr, front_dep = nullptr; hipStream_t pll_stream = nullptr;
+                      int slot = 0; long block = 0; ProfiledBlock* pm = nullptr; bool prof_p = false, prof_x = false, prof_r = false; } deferred;
     hipStream_t last_x_stream = nullptr;     // where the newest extract stage was queued, and the event behind it: consecutive blocks'
     hipEvent_t last_x_event = nullptr;       // extract stages are ordered (L-R phase estimate), whichever of the two streams they take
+    hipStream_t last_p_stream = nullptr;     // where the newest pilot stage was queued and the event behind it: consecutive blocks' pilot stages run in
+    hipEvent_t last_p_event = nullptr;       // order (loop state), whichever queue each takes (its own, or the front end's); NULL: drained
+    hipEvent_t x_done[kSlots] = {};          // fires when the extract stage of the block in that slot has run (its timing event while it is being timed); NULL: drained
+    int warm_left = 0;                       // tolerance mode: blocks still inside some station's start-up transient (k_pll_span runs beside k_pll_sparse)
     long n_blocks = 0;                       // blocks submitted since create/reset; slot = n_blocks % kSlots
     int out_slot = 0;                        // slot holding the newest outputs (the newest block's; under fmd_set_output_lag: the newest QUEUED outputs)
     int sub_slot = 0;                        // slot of the newest submitted block
@@ -267,7 +279,8 @@ void design_pilot_fast(const fmd_coeffs& k, PilotFastTab* t) {
 // at sample n it uses the previous sample's error, lpf[n] = b0 e[n-2] + b1 e[n-1] + a0 lpf[n-1], I[n] = I[n-1] + 0.1 Ts e[n-1],
 // f[n] = -19000 - 100 (0.01 lpf[n] + I[n]), t[n] = t[n-1] + Ts f[n]; with the hold at F0 = f[0] + r0 the error is
 // e[n] = 2 pi (eh[n] + dev[n]), dev[n] = Ts sum_{j <= n} (f[j] - F0): substituting sample by sample is the triangular solve.
-void design_pll_span(const fmd_coeffs& k, PllSpanTab* t) {
+// rows[r][i]: coefficient of unknown i = (lpf, I, e1, e2, r0, eh[0..L-1]) in row r, in double
+void span_rows(const fmd_coeffs& k, std::vector<double> (&rows)[kSpanRows]) {
     constexpr int L = kSpan, NV = 5 + L;
     const double b0 = k.pll_lpf_b[0], b1 = k.pll_lpf_b[1], a0 = k.pll_lpf_a[0];
     const float Ts32 = 1.0f / 128000.0f;                       // the reference's PLL_Mixer KTs (broadcast_fm_demod.cpp:226-235), a float
@@ -275,7 +288,6 @@ void design_pll_span(const fmd_coeffs& k, PllSpanTab* t) {
     using Vec = std::vector<double>;
     auto unit = [&](int i) { Vec v(NV, 0.0); v[(size_t)i] = 1.0; return v; };
     Vec lpf = unit(0), I = unit(1), e1 = unit(2), e2 = unit(3), dev(NV, 0.0), g0;
-    Vec rows[kSpanRows];
     for (int n = 0; n < L; n++) {
         Vec g(NV), e(NV);
         for (int i = 0; i < NV; i++) {
@@ -293,12 +305,11 @@ void design_pll_span(const fmd_coeffs& k, PllSpanTab* t) {
         if (n == L - 1) { rows[0] = lpf; rows[1] = I; rows[4] = dev; }
         e2 = e1; e1 = e;
     }
-    std::memset(t, 0, sizeof(*t));
-    for (int r = 0; r < kSpanRows; r++) {
-        for (int n = 0; n < L; n++) t->w[r][n] = (float)rows[r][(size_t)(5 + n)];
-        for (int i = 0; i < 5; i++) t->s[r][i] = (float)rows[r][(size_t)i];
-    }
-    // dev(n) ~ alpha n + beta n^2 + gamma n^3 through the three deviation rows
+}
+
+// (alpha, beta, gamma) of dev(n) ~ alpha n + beta n^2 + gamma n^3 through the three deviation rows
+void span_cubic_inverse(float (&minv)[3][4]) {
+    constexpr int L = kSpan;
     const double x[3] = {(double)kSpanN1, (double)kSpanN2, (double)(L - 1)};
     double A[3][3], inv[3][3];
     for (int i = 0; i < 3; i++) { A[i][0] = x[i]; A[i][1] = x[i] * x[i]; A[i][2] = x[i] * x[i] * x[i]; }
@@ -308,7 +319,21 @@ void design_pll_span(const fmd_coeffs& k, PllSpanTab* t) {
             const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
             inv[j][i] = (A[i1][j1] * A[i2][j2] - A[i1][j2] * A[i2][j1]) / det;     // cofactor (cyclic indices carry the sign), transposed
         }
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) t->minv[i][j] = (float)inv[i][j];
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) minv[i][j] = (float)inv[i][j]; minv[i][3] = 0.0f; }
+}
+
+void design_pll_span(const fmd_coeffs& k, PllSpanTab* t) {
+    constexpr int L = kSpan;
+    const float Ts32 = 1.0f / 128000.0f;
+    const double Ts = (double)Ts32, two_pi = 6.283185307179586476925;
+    std::vector<double> rows[kSpanRows];
+    span_rows(k, rows);
+    std::memset(t, 0, sizeof(*t));
+    for (int r = 0; r < kSpanRows; r++) {
+        for (int n = 0; n < L; n++) t->w[r][n] = (float)rows[r][(size_t)(5 + n)];
+        for (int i = 0; i < 5; i++) t->s[r][i] = (float)rows[r][(size_t)i];
+    }
+    span_cubic_inverse(t->minv);
     // quadrature of the filtered pilot's real rail.  The reference's Hilbert rail is im[n] = sum_k b[k] s[n - 64 + k] beside
     // re[n] = s[n - 32] (hilbert_fir_filter.h:26-46); for s = cos(w0 n) that is |H(w0)| sin(w0 (n - 32)), and
     // re[n-1] - re[n+1] = 2 sin(w0) sin(w0 (n - 32)): im[n] = quad (re[n-1] - re[n+1]), quad = |H(w0)| / (2 sin w0)
@@ -318,6 +343,73 @@ void design_pll_span(const fmd_coeffs& k, PllSpanTab* t) {
     t->quad = (float)(std::sqrt(hr * hr + hi * hi) / (2.0 * std::sin(w0)));
     t->kappa = (float)(-19000.0 * Ts + 19.0 / 128.0);
     for (int i = 0; i < 32; i++) t->hil[i] = k.b_hilbert[2 * i + 1];
+}
+
+// Tables of k_pll_sparse (fmd_kernels.h PllSparseTab; float64 model: tools/proto/sparse_pll.py design_sparse)
+void design_pll_sparse(const fmd_coeffs& k, PllSparseTab* t) {
+    using cd = std::complex<double>;
+    constexpr int L = kSpan, D = kSparseDec, KP = kSparsePts;
+    const double two_pi = 6.283185307179586476925, w0 = two_pi * 19.0 / 128.0;
+    const float Ts32 = 1.0f / 128000.0f;
+    std::memset(t, 0, sizeof(*t));
+    // the poles of the peak filter as its float coefficients have them: y[n] = K x[n-2] + a1 y[n-1] + a0 y[n-2], a0 = -r^2, a1 = 2 r cos wp
+    const double r = std::sqrt(-(double)k.pilot_a[0]), wp = std::acos((double)k.pilot_a[1] / (2.0 * r));
+    const cd rho = std::polar(r, wp - w0);
+    // W[q], q = -8 .. 23: the 17-tap boxcar (centred) in front of the exact decimation by 16, sum_i rho^i over the i it covers
+    cd W[2 * D];
+    for (int q = -8; q < 24; q++) {
+        cd acc = 0.0;
+        for (int i = 0; i < D; i++) if (std::abs(q - i) <= 8) acc += std::pow(rho, i);
+        W[q + 8] = acc / 17.0;
+    }
+    for (int tt = 0; tt < 2 * D; tt++) {                        // tap tt multiplies x[m' - 25 + tt], q = 23 - tt; the mixer relative to the point
+        const cd wc = W[(23 - tt) + 8] * std::polar(1.0, -w0 * (double)(tt - 40));
+        t->wre[tt] = (float)wc.real(); t->wim[tt] = (float)wc.imag();
+    }
+    const cd rho16 = std::pow(rho, D);
+    for (int kk = 0; kk < KP; kk++) {
+        const cd ro = std::polar(1.0, -w0 * (double)(D * kk)), ca = std::pow(rho16, kk + 1);
+        t->rot[kk][0] = (float)ro.real(); t->rot[kk][1] = (float)ro.imag();
+        t->carry[kk][0] = (float)ca.real(); t->carry[kk][1] = (float)ca.imag();
+        t->nk1[kk] = (float)(D * kk + D);
+    }
+    double nbar = 0.0, s2 = 0.0;
+    for (int kk = 0; kk < KP; kk++) nbar += (double)(D * kk + D - 1) / KP;
+    for (int kk = 0; kk < KP; kk++) { const double c = (double)(D * kk + D - 1) - nbar; t->ck[kk] = (float)c; s2 += c * c; }
+    for (int s_ = 0; s_ < 3; s_++) { const cd p = std::pow(rho16, 1 << s_); t->scan[s_][0] = (float)p.real(); t->scan[s_][1] = (float)p.imag(); }
+    const cd cA = cd(0.0, -1.0) * ((double)k.pilot_b[0] / std::sin(wp)) * std::polar(1.0, wp);
+    double phi0 = std::arg(cA) / two_pi - 19.0 * 33.0 / 128.0;
+    phi0 -= std::nearbyint(phi0);
+    t->phi0 = (float)phi0; t->inv_s2 = (float)(1.0 / s2); t->nbar = (float)nbar;
+    t->kappa = (float)(-19000.0 * (double)Ts32 + 19.0 / 128.0);
+    double hr = 0.0, hi = 0.0;
+    for (int i = 0; i < 65; i++) { hr += k.b_hilbert[i] * std::cos(w0 * i); hi += k.b_hilbert[i] * std::sin(w0 * i); }
+    const double g2 = hr * hr + hi * hi;                        // |H_hilbert(w0)|^2: the reference's imaginary rail carries it
+    t->pw_scale = (float)(std::norm(cA) * (1.0 + g2) * 0.5 * (double)D);
+    // the non-resonant branch: Z_eff = Z - e^{-2 j wp} u_slow / (1 - rho2), rho2 = r e^{-j (wp + w0)}, u_slow = V / (DC gain of a point's 32 weights)
+    cd wdc = 0.0;
+    for (int q = 0; q < 2 * D; q++) wdc += W[q];
+    const cd kap2 = -std::polar(1.0, -2.0 * wp) / (wdc * (1.0 - std::polar(r, -(wp + w0))));
+    t->kap2[0] = (float)kap2.real(); t->kap2[1] = (float)kap2.imag();
+    std::vector<double> rows[kSpanRows];
+    span_rows(k, rows);
+    {   // rows 2..4 -> (alpha, beta, gamma) of the deviation's cubic
+        float mi[3][4];
+        span_cubic_inverse(mi);
+        const std::vector<double> d1 = rows[2], d2 = rows[3], d3 = rows[4];
+        for (int i = 0; i < 3; i++)
+            for (size_t j = 0; j < d1.size(); j++) rows[2 + i][j] = (double)mi[i][0] * d1[j] + (double)mi[i][1] * d2[j] + (double)mi[i][2] * d3[j];
+    }
+    for (int rr = 0; rr < kSpanRows; rr++) {
+        double ws = 0.0, wm = 0.0, suf = 0.0;
+        for (int n = L - 1; n >= 0; n--) {
+            const double w = rows[rr][(size_t)(5 + n)];
+            ws += w; wm += w * ((double)n - nbar); suf += w;
+            t->sw[rr][n] = (float)suf;
+        }
+        t->wsum[rr] = (float)ws; t->wmom[rr] = (float)wm;
+        for (int i = 0; i < 5; i++) t->s[rr][i] = (float)rows[rr][(size_t)i];
+    }
 }
 
 void design_front_mfma(const fmd_coeffs& k, int m, std::vector<uint16_t>& img) {
@@ -366,7 +458,10 @@ int zero_history(fmd_handle h, hipStream_t s) {
     if (b.pll_chain) HIP_TRY(h, hipMemsetAsync(b.pll_chain, 0, sizeof(unsigned) * ((size_t)h->pll_waves + 1), s));
     h->pll_seq = 0;
     h->n_blocks = 0;
-    h->deferred.active = false; h->last_x_event = nullptr;
+    h->warm_left = h->ctx.fast ? (int)((8192 + d.n_fm_out - 1) / d.n_fm_out) : 0;     // kPllWarmSamples of every station's life
+    if (h->ctx.fast && std::getenv("FMD_DEBUG_PLL_DENSE")) h->warm_left = 1 << 30;   // development knob: k_pll_span for every block (A/B against round 3's pilot stage)
+    h->deferred.active = false; h->last_x_event = nullptr; h->last_p_event = nullptr;
+    for (hipEvent_t& e : h->x_done) e = nullptr;
     h->ev_consumed = nullptr;
     h->out_slot = 0; h->sub_slot = 0; h->have_out = false; h->out_block = -1;
     for (bool& u : h->slot_used) u = false;
@@ -382,6 +477,29 @@ int zero_history(fmd_handle h, hipStream_t s) {
 // turns on one queue, in the order front(k + 1), extract(k), front(k + 2), ...; by the time extract(k) is reached, the pilot loop of
 // block k has run on its own queue, as the RDS stages do.  Otherwise (somebody asks for the block's outputs before the next block is
 // there: fmd_wait_outputs, a getter, fmd_synchronize) it goes on the extract stream as in the exact mode, beside the next front end.
+// The pilot stage of the put-off block as a launch of its own on `sP`: the front end's queue, or the pilot queue as in the undeferred
+// arrangement (consecutive blocks' pilot stages must run in order: a block whose stage is queued at submission sends the put-off one ahead).
+int launch_deferred_pll(fmd_handle h, hipStream_t sP) {
+    auto& q = h->deferred;
+    if (!q.active || !q.pll_pending) return FMD_OK;
+    q.pll_pending = false;
+    if (h->last_p_event && h->last_p_stream != sP) HIP_TRY(h, hipStreamWaitEvent(sP, h->last_p_event, 0));
+    if (sP != h->sF || q.front_cross) HIP_TRY(h, hipStreamWaitEvent(sP, q.front_dep, 0));
+    if (sP != h->sF) {          // (see process_dev: the stage also writes the history in front of the next slot's rows)
+        const int nx = (q.slot + 1) % kSlots;
+        if (h->slot_used[nx] && h->x_done[nx]) HIP_TRY(h, hipStreamWaitEvent(sP, h->x_done[nx], 0));
+    }
+    SlotRef r = q.ref;
+    if (q.pm && q.prof_p) { r.t0 = q.pm->t0[ST_PLL]; r.t1 = q.pm->t1[ST_PLL]; q.pm->used[ST_PLL] = true; }
+    if (!r.t1) r.done = h->ev_B[q.slot];
+    q.pll_dep = r.t1 ? r.t1 : h->ev_B[q.slot];
+    q.pll_stream = sP;
+    hipError_t e = (h->debug_skip & (1u << ST_PLL)) ? hipEventRecord(q.pll_dep, sP) : launch_stage_pll(h->ctx, r, sP);
+    if (e != hipSuccess) { h->poisoned = true; return fail(h, FMD_ERR_DEVICE, "k_pll_sparse launch: %s", hipGetErrorString(e)); }
+    h->last_p_stream = sP; h->last_p_event = q.pll_dep;
+    return FMD_OK;
+}
+
 int launch_deferred(fmd_handle h, bool behind_front) {
     auto& q = h->deferred;
     if (!q.active) return FMD_OK;
@@ -393,7 +511,8 @@ int launch_deferred(fmd_handle h, bool behind_front) {
         h->consumer_pending[q.slot] = false;
     }
     if (h->last_x_event && h->last_x_stream != sXq) HIP_TRY(h, hipStreamWaitEvent(sXq, h->last_x_event, 0));
-    HIP_TRY(h, hipStreamWaitEvent(sXq, q.pll_dep, 0));
+    { int rc = launch_deferred_pll(h, behind_front ? h->sF : h->sB); if (rc) return rc; }
+    if (q.pll_dep && q.pll_stream != sXq) HIP_TRY(h, hipStreamWaitEvent(sXq, q.pll_dep, 0));
     hipEvent_t dep;
     {
         SlotRef r = q.ref;
@@ -402,7 +521,7 @@ int launch_deferred(fmd_handle h, bool behind_front) {
         dep = r.t1 ? r.t1 : h->ev_E[q.slot];
         hipError_t e = (h->debug_skip & (1u << ST_EXTRACT)) ? hipEventRecord(dep, sXq) : launch_stage_extract(h->ctx, r, sXq);
         if (e != hipSuccess) { h->poisoned = true; return fail(h, FMD_ERR_DEVICE, "k_extract launch: %s", hipGetErrorString(e)); }
-        h->last_x_stream = sXq; h->last_x_event = dep;
+        h->last_x_stream = sXq; h->last_x_event = dep; h->x_done[q.slot] = dep;
     }
     HIP_TRY(h, hipStreamWaitEvent(sR, dep, 0));
     {
@@ -433,6 +552,8 @@ int sync_all(fmd_handle h) {
     { int rc = launch_deferred(h, true); if (rc) return rc; }    // (everything drains: the front end's queue is as good as any)
     for (hipStream_t st : {h->sF, h->sD, h->sA, h->sB, h->sB2, h->sX, h->sR, h->own_stream}) if (st) HIP_TRY(h, hipStreamSynchronize(st));
     h->last_x_event = nullptr;        // (everything has run: no order left to keep; a timed block's events are about to be freed)
+    h->last_p_event = nullptr;
+    for (hipEvent_t& e : h->x_done) e = nullptr;
     if (!h->pipelined && h->n_blocks > 0) HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     if (h->pll_chained && h->pll_seq) {   // the hand-over watchdog of k_pilot_pll
         unsigned timed_out = 0;
@@ -464,7 +585,8 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         if (rc) return rc;
     }
     const int slot = (int)(h->n_blocks % kSlots);
-    const SlotRef ref{slot, (int)(h->n_blocks & 1), nullptr, nullptr};
+    SlotRef ref{slot, (int)(h->n_blocks & 1), nullptr, nullptr};
+    ref.warm = (h->ctx.fast && h->warm_left > 0) ? (h->warm_left >= (1 << 29) ? 2 : 1) : 0;
     const bool u8 = sizeof(InT) == 2;
     const bool pipe = h->pipelined;
     if (!pipe) ordered = true;                     // every stage runs on `s` itself
@@ -543,8 +665,18 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         hipEvent_t front_done = h->ctx.any_deemph ? h->ev_D[slot] : h->ev_F[slot];
         if (pipe && !r.t1) r.done = front_done;
         dep = r.t1 ? r.t1 : front_done;
+        // the previous block's pilot stage, put off with its extract stage: as the first workgroups of this launch
+        const SlotRef* ride = nullptr;
+        auto& q = h->deferred;
+        if (lazy && q.active && q.pll_pending && !q.ref.warm && !q.front_cross && !h->ctx.any_deemph && !h->ctx.b.fm_out_iq[q.slot] &&
+            !(h->debug_skip & ((1u << ST_PLL) | (1u << ST_FRONT))) && !h->no_fused_pll) {
+            ride = &q.ref;
+            q.pll_pending = false; q.pll_dep = nullptr; q.pll_stream = sF;
+            if (h->last_p_event && h->last_p_stream != sF) HIP_TRY(h, hipStreamWaitEvent(sF, h->last_p_event, 0));
+            h->last_p_stream = sF; h->last_p_event = dep;          // (the launch's own event)
+        }
         if (h->debug_skip & (1u << ST_FRONT)) e = pipe ? hipEventRecord(dep, sF) : hipSuccess;
-        else e = launch_stage_front(h->ctx, r, d_iq, u8, sF);
+        else e = launch_stage_front(h->ctx, r, d_iq, u8, sF, ride);
     }
     if (e != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_front launch: %s", hipGetErrorString(e));
     hipEvent_t front_dep = dep;                    // k_front itself: the caller's buffer (256 kSa/s captures) has been consumed
@@ -567,19 +699,36 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         if (pipe) HIP_TRY(h, hipStreamWaitEvent(sA, dep, 0));
         if ((e = run(ST_POWER, sA, launch_stage_power, h->ev_A[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_pilot_power launch: %s", hipGetErrorString(e));
     }
+    const hipEvent_t fm_out_dep = dep;              // behind this event the block's fm_out is complete
+    const bool fm_out_cross = h->ctx.any_deemph != 0;
+    const bool pll_now = !lazy || h->pll_eager;
+    if (pll_now) {
+    { int rc = launch_deferred_pll(h, sB); if (rc) return rc; }        // (the put-off block's pilot stage first)
     if (pipe) HIP_TRY(h, hipStreamWaitEvent(sB, dep, 0));
+    // Tolerance mode: the pilot stage of block k also writes the history in front of the NEXT slot's rows (fm_out tail, last span's cubic),
+    // which the extract stage of the block that last used that slot (k - 5) reads.  On the deferred schedule that stage sits ahead on
+    // the front end's queue; otherwise (fmd_process_*, small batches, a consumer holding outputs back) nothing else orders the two.
+    if (pipe && h->ctx.fast) {
+        const int nx = (slot + 1) % kSlots;
+        if (h->slot_used[nx] && h->x_done[nx]) HIP_TRY(h, hipStreamWaitEvent(sB, h->x_done[nx], 0));
+    }
+    if (pipe && h->ctx.fast && h->last_p_event && h->last_p_stream != sB) HIP_TRY(h, hipStreamWaitEvent(sB, h->last_p_event, 0));
     if ((e = run(ST_PLL, sB, launch_stage_pll, h->ev_B[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_pilot_pll launch: %s", hipGetErrorString(e));
+    if (pipe && h->ctx.fast) { h->last_p_stream = sB; h->last_p_event = dep; }
+    }
     // the previous block's extract + RDS stages, if fmd_submit_* put them off: behind this block's front end (launch_deferred)
     { int rc = launch_deferred(h, true); if (rc) return rc; }
     if (lazy) {
-        h->deferred.active = true; h->deferred.ref = ref; h->deferred.pll_dep = dep; h->deferred.slot = slot; h->deferred.block = h->n_blocks; h->deferred.pm = pm;
-        h->deferred.prof_x = pm && prof_stage(ST_EXTRACT); h->deferred.prof_r = pm && prof_stage(ST_RDS);
+        auto& q = h->deferred;
+        q.active = true; q.pll_pending = !pll_now; q.front_cross = fm_out_cross; q.ref = ref; q.pll_dep = pll_now ? dep : nullptr; q.pll_stream = pll_now ? sB : nullptr; q.front_dep = fm_out_dep;
+        q.slot = slot; q.block = h->n_blocks; q.pm = pm;
+        q.prof_p = pm && prof_stage(ST_PLL); q.prof_x = pm && prof_stage(ST_EXTRACT); q.prof_r = pm && prof_stage(ST_RDS);
     } else {
         if (pipe) HIP_TRY(h, hipStreamWaitEvent(sX, dep, 0));
         if (pipe && h->last_x_event && h->last_x_stream != sX) HIP_TRY(h, hipStreamWaitEvent(sX, h->last_x_event, 0));
         // the extract stage's event fires behind k_extract itself: k_rds_sync does not need k_lmr_phase (same stream, behind it)
         if ((e = run(ST_EXTRACT, sX, launch_stage_extract, h->ev_E[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_extract launch: %s", hipGetErrorString(e));
-        if (pipe) { h->last_x_stream = sX; h->last_x_event = dep; }
+        if (pipe) { h->last_x_stream = sX; h->last_x_event = dep; h->x_done[slot] = dep; }
         if (pipe) HIP_TRY(h, hipStreamWaitEvent(sR, dep, 0));
         if ((e = run(ST_RDS, sR, launch_stage_rds, h->ev_X[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_rds_sync launch: %s", hipGetErrorString(e));
         // ev_X outlives this call (slot reuse, fmd_wait_outputs): when the dispatch carried a timing event instead, record it
@@ -590,6 +739,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     h->sub_slot = slot;
     if (!lazy) { h->out_slot = slot; h->have_out = true; h->out_block = h->n_blocks; }
     h->n_blocks++;
+    if (h->warm_left > 0) h->warm_left--;
     if (h->deemph_linger) { h->deemph_linger = false; h->ctx.any_deemph = 0; }
     h->last_stream = s;
     poison.armed = false;
@@ -744,6 +894,8 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     // +10 % at 2560, +6-7 % from 3072 on; smaller batches are pure stage latency and keep every stage on a queue of its own)
     h->lazy_capable = h->pipelined && h->ctx.fast && (size_t)d.C * d.n_fm_out >= (size_t)1024 * 8192 && !std::getenv("FMD_NO_LAZY_EXTRACT");
     h->lazy_extract = h->lazy_capable;
+    h->no_fused_pll = std::getenv("FMD_NO_FUSED_PLL") != nullptr;
+    h->pll_eager = std::getenv("FMD_PLL_EAGER") != nullptr;
 
     fmd_controls def;
     fmd_default_controls(&def);
@@ -814,6 +966,13 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
                 design_pll_span(h->base, &st_);
                 if (hipMemcpyAsync(b.span_tab, &st_, sizeof(st_), hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
                     hipStreamSynchronize(h->own_stream) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "span table upload failed");
+            }
+            if (!rc) rc = dev_alloc(h, &b.sparse_tab, 1);
+            if (!rc) {
+                PllSparseTab sp_;
+                design_pll_sparse(h->base, &sp_);
+                if (hipMemcpyAsync(b.sparse_tab, &sp_, sizeof(sp_), hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
+                    hipStreamSynchronize(h->own_stream) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "sparse table upload failed");
             }
             PilotFastTab tab;
             design_pilot_fast(h->base, &tab);
@@ -1174,6 +1333,9 @@ int fmd_set_state(fmd_handle h, int channel, const void* blob, size_t n_bytes) {
     std::vector<float> fields(in, in + S_NUM_FIELDS);
     if (par == 1) std::swap(fields[S_LMR_PHASE_CUR], fields[S_LMR_PHASE_PREV]);   // see fmd_get_state
     HIP_TRY(h, hipMemcpy2D(h->ctx.b.state + channel, sizeof(float) * (size_t)d.C, fields.data(), sizeof(float), sizeof(float), S_NUM_FIELDS, hipMemcpyHostToDevice));
+    // a station restored inside its start-up transient (tolerance mode: SA_X1I counts its samples since the reset) keeps k_pll_span for the rest of it
+    if (h->ctx.fast && fields[SA_X1I] < kPllWarmSamples)
+        h->warm_left = std::max(h->warm_left, (int)((kPllWarmSamples - fields[SA_X1I] + (float)d.n_fm_out - 1.0f) / (float)d.n_fm_out));
     in += S_NUM_FIELDS;
     for (const StatePart& p : state_parts(h)) {
         HIP_TRY(h, hipMemcpy(p.base + (size_t)channel * p.stride, in, sizeof(float) * p.floats, hipMemcpyHostToDevice));
@@ -1228,6 +1390,24 @@ int fmd_design_pll_span(int fs_baseband, float* w, float* s, float* minv, float*
     design_pll_span(k, &t);
     std::memcpy(w, t.w, sizeof(t.w)); std::memcpy(s, t.s, sizeof(t.s)); std::memcpy(minv, t.minv, sizeof(t.minv));
     misc2[0] = t.quad; misc2[1] = t.kappa;
+    return FMD_OK;
+}
+
+int fmd_design_pll_sparse(int fs_baseband, float* taps, float* cplx, float* rows, float* sw, float* misc8) {
+    if (!taps || !cplx || !rows || !sw || !misc8) return FMD_ERR_ARG;
+    if (fs_baseband != 256000 && fs_baseband != 1024000 && fs_baseband != 2048000) return FMD_ERR_ARG;
+    fmd_controls def;
+    fmd_default_controls(&def);
+    fmd_coeffs k{};
+    design_all(&k, fs_baseband, &def);
+    PllSparseTab t;
+    design_pll_sparse(k, &t);
+    std::memcpy(taps, t.wre, sizeof(t.wre)); std::memcpy(taps + 2 * kSparseDec, t.wim, sizeof(t.wim));
+    std::memcpy(cplx, t.rot, sizeof(t.rot)); std::memcpy(cplx + 16, t.scan, sizeof(t.scan)); std::memcpy(cplx + 22, t.carry, sizeof(t.carry));
+    std::memcpy(rows, t.wsum, sizeof(t.wsum)); std::memcpy(rows + 8, t.wmom, sizeof(t.wmom));
+    std::memcpy(sw, t.sw, sizeof(t.sw));
+    const float m[8] = {t.phi0, t.inv_s2, t.nbar, t.kappa, t.pw_scale, t.kap2[0], t.kap2[1], 0.f};
+    std::memcpy(misc8, m, sizeof(m));
     return FMD_OK;
 }
 

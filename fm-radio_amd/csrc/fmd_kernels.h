@@ -80,6 +80,38 @@ struct PllSpanTab {
     float pad[2];
     float hil[32];                   // the Hilbert FIR's non-zero taps b[1], b[3], ... (a station's warm-up makes that rail for itself)
 };
+// Round 4: k_pll_sparse.  Behind the peak filter the pilot is a line a few Hz wide, and the filter itself is a complex one-pole low-pass
+// of the down-mixed input:  P[m] = K x[m-2] + a1 P[m-1] + a0 P[m-2] = (K / sin wp) Im{ e^{j wp} e^{j w0 m} Z[m] },
+// Z[m] = rho Z[m-1] + e^{-j w0 m} x[m-2],  rho = r e^{j (wp - w0)}  (r e^{+-j wp}: the poles the float coefficients really have;
+// w0 = 2 pi 19 / 128: the mixer is periodic in the span).  Z decimates exactly (Z[m] = rho^16 Z[m-16] + 16 weighted inputs), so the
+// loop's phase detector is evaluated at kSparsePts points per span instead of at every sample: one arctangent of Z per point, and
+// the span's five weight rows applied to the straight line through the eight errors (the held-frequency error of a narrow line is
+// a straight line in the span; what the reference's per-sample detector adds — the ellipse of its Hilbert rail, programme content
+// >= 4 kHz away — its rows average out).  A 17-tap boxcar in front of the decimation (zeros every 8 kHz from the pilot: exactly what
+// would alias onto it) is folded into the 32 input weights of a point.  tools/proto/sparse_pll.py is the float64 model of this
+// against the oracle; tests/test_span_design.py checks the tables.  The filter has TWO poles: by partial fractions its output's analytic
+// signal is e^{j wp} (x filtered by 1 / (1 - p z^-1)) - e^{-j wp} (x filtered by 1 / (1 - p* z^-1)); the second branch is not resonant at
+// +19 kHz (gain 1 / (1 - r e^{-j (wp + w0)}) ~ 0.6 against 1 / (1 - r) = 10^4) and answers within a sample, so at a point it is the
+// point's own input sum times a constant (kap2): 6e-5 rad of pilot phase in lock, 1e-3 rad for a pilot 35 Hz off.  A station's first 8192 samples after a reset stay with
+// k_pll_span (the reference's start-up transient, see its warm-up rail).
+static constexpr int kSparsePts = 8, kSparseDec = kSpan / kSparsePts;      // points per span, samples between them
+static constexpr float kPllWarmSamples = 8192.0f;
+struct PllSparseTab {
+    float wre[2 * kSparseDec], wim[2 * kSparseDec];   // tap t of a point multiplies fm_out[span + 16 k - 42 + t]; taps 16.. are the lane's own chunk ("new"), 0..15 the previous lane's ("old")
+    float rot[kSparsePts][2];        // e^{-j w0 16 k}
+    float scan[3][2];                // rho^16, rho^32, rho^64
+    float carry[kSparsePts][2];      // rho^(16 (k + 1))
+    float ck[kSparsePts];            // n_k - nbar, n_k = 16 k + 15
+    float nk1[kSparsePts];           // n_k + 1
+    float phi0;                      // arg(-j (K / sin wp) e^{j wp}) / 2 pi - 19 * 33 / 128: arg Z -> the phase the reference's detector sees, minus frac(19 (n + 1) / 128)
+    float inv_s2, nbar, kappa, pw_scale;
+    float kap2[2], pad_;             // the filter's second, non-resonant pole branch (see below): Z_eff = Z + kap2 V, V = the point's own 32-sample sum
+    // rows: 0 loop filter output after the span, 1 integrator after the span (as PllSpanTab), 2..4 the coefficients alpha, beta, gamma of the
+    // phase deviation's cubic directly (PllSpanTab's three deviation rows times its minv)
+    float wsum[8], wmom[8];          // sum_n w[r][n], sum_n w[r][n] (n - nbar): the rows applied to a + b (n - nbar)
+    float s[kSpanRows][8];           // weights of (lpf, I, e1, e2, r0)
+    float sw[kSpanRows][kSpan + 4];  // sw[r][n] = sum_{n' >= n} w[r][n'] (the rare span in which the error crosses half a turn)
+};
 // rows of the fast-mode planes carry the previous block's last samples in front (written by k_pll_span of that block), so the
 // consumers address history and block uniformly
 static constexpr int kFrontImgU4 = 2 * 3 * 2 * 64;   // uint4s of k_front_mfma's two operand images in Buffers::front_mfma; k_predecim_mfma's image follows them
@@ -106,7 +138,9 @@ static_assert(kSlots <= 8, "one S_PILOT_POWER state field per slot");
 // packet (a separate hipEventRecord is one more queue packet between two dependent kernels, ~25 us on the PLL stream)
 // seq: 1-based number of the block when consecutive blocks' k_pilot_pll launches hand over per wavefront (Buffers::pll_chain),
 // 0: plain stream order
-struct SlotRef { int buf; int par; hipEvent_t t0 = nullptr; hipEvent_t t1 = nullptr; hipEvent_t done = nullptr; unsigned seq = 0; };
+// warm: tolerance mode, a block inside some station's first kPllWarmSamples after a reset / a restored start-up state: k_pll_span runs
+// beside k_pll_sparse and each station takes the result of the one in charge of it
+struct SlotRef { int buf; int par; hipEvent_t t0 = nullptr; hipEvent_t t1 = nullptr; hipEvent_t done = nullptr; unsigned seq = 0; int warm = 0; };
 struct Buffers {
     // history tails: stage of block b reads [par], writes [par^1] (producer and consumer are the same stage, same stream)
     float2* base_tail[2];   // [C][tail_base]  fm_in history of k_front
@@ -143,6 +177,7 @@ struct Buffers {
     float4* pll_poly[kSlots];        // [C][1 + n_fm_out / kSpan]  NCO phase of a span: c0 + c1 u + c2 u^2 + c3 u^3 - frac(19 (u + 1) / 128), u = sample in span
     float*  rds_pow[kSlots];         // [C][2 n_audio / 256]  partial sums of |rds|^2 (k_extract_mfma -> k_rds_sync's AGC)
     PllSpanTab* span_tab;
+    PllSparseTab* sparse_tab;
     PilotFastTab* pilot_tab;         // FMD_FLAG_FAST_MATH only
     uint4*  aud_img;                 // ... of k_extract_mfma's audio FIRs, one per distinct cut-off: [slot][k-step][hi/lo][lane]
     int2*   aud_idx;                 // [C] slots of a station's L+R and L-R images
@@ -174,7 +209,8 @@ struct LaunchCtx {
 // One launcher per pipeline stage of one block.  The host (fmd_api.cpp) places the stages on
 // streams and orders them with events.
 hipError_t launch_stage_predecim(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s);   // k_predecim (m > 1)
-hipError_t launch_stage_front(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s);   // k_front
+// pll != NULL (tolerance mode only): the pilot stage of the block in slot pll->buf rides in the same launch (k_front_mfma<..., FUSED>)
+hipError_t launch_stage_front(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s, const SlotRef* pll = nullptr);   // k_front
 hipError_t launch_stage_deemph(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                            // k_deemphasis + k_hilbert
 hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                             // k_pilot_power
 hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                               // k_pilot_pll

@@ -47,6 +47,8 @@ static constexpr int kWave = 64;
 
 __device__ __forceinline__ float& st(float* state, int field, int C, int c) { return state[(size_t)field * C + c]; }
 
+#include "fmd_kernels_sparse.inc"
+
 // =============================================================================================
 // k_front — reference Run_FM_Demodulate (broadcast_fm_demod.cpp:391-416) without the optional IIR, from the 256 kSa/s stream
 // fm_in on (the capture itself at 256 kSa/s, k_predecim's output at 1.024 / 2.048 MSa/s):
@@ -265,20 +267,34 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
 // bf16 x 3 matrix product (FrontGeomM above); WU > 0: with the de-emphasis IIR inside the tile (see k_front).  The Hilbert FIR is
 // k_extract_mfma's: the analytic signal never goes through HBM, only fm_out does (4 bytes per sample instead of 8).
 // =============================================================================================
-template <typename InT, int TT, int WU>
-__global__ __launch_bounds__(256) void k_front_mfma(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
+// FUSED: the launch's first pf.n_wg workgroups run the pilot stage (k_pll_sparse's body) of the block BEFORE this one — on the deferred
+// schedule (fmd_api.cpp) the front end's queue then carries front(k + 1) + pilot(k), extract(k), front(k + 2) + pilot(k + 1), ... and no
+// kernel on it waits for another queue; the pilot stage's half-thousand wavefronts start first and finish inside the front end's HBM-bound time.
+template <typename InT, int TT, int WU, bool FUSED = false>
+__global__ __launch_bounds__(256, FUSED ? 4 : 1) void k_front_mfma(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
                                                     float2* __restrict__ tail_out, float* __restrict__ fo_pl, float fm_gain,
-                                                    const float* __restrict__ deemph, const uint4* __restrict__ tab) {
+                                                    const float* __restrict__ deemph, const uint4* __restrict__ tab, PllFusedArgs pf) {
     using G = FrontGeomM<TT, WU>;
     constexpr int T = G::T, NW = G::NW, NF = G::NF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    int bid = (int)blockIdx.x;
+    if constexpr (FUSED) {
+        if (bid < pf.n_wg) {
+            float4* wl = reinterpret_cast<float4*>(smem);
+            if (threadIdx.x < 16) wl[threadIdx.x] = threadIdx.x < 8 ? *reinterpret_cast<const float4*>(&pf.tab->wre[4 * threadIdx.x]) : *reinterpret_cast<const float4*>(&pf.tab->wim[4 * (threadIdx.x - 8)]);
+            __syncthreads();
+            pll_sparse_body(d, bid * 4 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & (kWave - 1)), pf.fo, pf.fo_next, pf.poly, pf.poly_next, pf.state, pf.k, pf.tab, wl, 0, pf.spec_stats);
+            return;
+        }
+        bid -= pf.n_wg;
+    }
     float* theta = smem + G::OFF_THETA;
     uint32_t* dem_hi32 = reinterpret_cast<uint32_t*>(smem);                        // two bf16 per word
     uint32_t* dem_lo32 = dem_hi32 + G::NWB / 2;
     float* fo = smem + G::OFF_FO;
 
     const int tiles = d.n_fm_out / T;
-    const int c = blockIdx.x / tiles, tile = blockIdx.x % tiles, o0 = tile * T, tid = threadIdx.x;
+    const int c = bid / tiles, tile = bid % tiles, o0 = tile * T, tid = threadIdx.x;
     __builtin_assume(tid >= 0 && tid < 256);     // (the bounds of the unrolled staging loops are tested against it)
     const int lane = tid & (kWave - 1), wv = tid >> 6, lrow = lane & 15, lq = lane >> 4;
     const int g_lo = 2 * o0 - G::TAIL;                            // first input index of the tile (block relative)
@@ -2588,31 +2604,39 @@ __global__ void k_reset(Dims d, float* __restrict__ state) {
 // host-side stage launchers
 // ---------------------------------------------------------------------------------------------
 template <typename InT, int TT = 512, bool FAST = false>
-static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq, hipStream_t s) {
+static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq, hipStream_t s, const SlotRef* pll = nullptr) {
     using G = FrontGeom<TT>;
     const Dims& d = ctx.d;
     if constexpr (!FAST) {
-        if (ctx.fast) return launch_front<InT, TT, true>(ctx, r, d_iq, s);
+        if (ctx.fast) return launch_front<InT, TT, true>(ctx, r, d_iq, s, pll);
     }
     if constexpr (TT == 512) {
         if constexpr (FAST && sizeof(InT) == 2) {   // u8 captures: 2048-output tiles (4 KB of input per 1024-output workgroup leaves too few bytes in flight per CU)
             static const bool t1024 = std::getenv("FMD_FRONT_U8_T1024") != nullptr;      // (A/B hook)
-            if (d.n_fm_out % 2048 == 0 && !ctx.deemph_in_tile && !t1024) return launch_front<InT, 2048, FAST>(ctx, r, d_iq, s);
+            if (d.n_fm_out % 2048 == 0 && !ctx.deemph_in_tile && !t1024) return launch_front<InT, 2048, FAST>(ctx, r, d_iq, s, pll);
         }
-        if (d.n_fm_out % 1024 == 0) return launch_front<InT, 1024, FAST>(ctx, r, d_iq, s);
+        if (d.n_fm_out % 1024 == 0) return launch_front<InT, 1024, FAST>(ctx, r, d_iq, s, pll);
     }
     const int tiles = d.n_fm_out / G::T;
     if constexpr (FAST) {   // tolerance mode: k_front_mfma; with the de-emphasis IIR inside the tile when a channel asks for it
+        PllFusedArgs pf{};
+        if (pll) {          // the pilot stage of the block in slot pll->buf as this launch's first workgroups
+            const int nxt = (pll->buf + 1) % kSlots;
+            pf = PllFusedArgs{(d.C + 31) / 32, ctx.b.fo_pl[pll->buf], ctx.b.fo_pl[nxt], ctx.b.pll_poly[pll->buf], ctx.b.pll_poly[nxt], ctx.b.state, ctx.loops, ctx.b.sparse_tab, ctx.b.spec_stats};
+        }
+        const unsigned grid = (unsigned)(tiles * d.C + pf.n_wg);
         if (ctx.deemph_in_tile) {
-            auto kern = k_front_mfma<InT, TT, kDeemphWarmup>;
             using GM = FrontGeomM<TT, kDeemphWarmup>;
-            FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
-                       ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma);
+            if (pll) FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, kDeemphWarmup, true>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
+                                ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, pf);
+            else FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, kDeemphWarmup, false>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
+                            ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, pf);
         } else {
-            auto kern = k_front_mfma<InT, TT, 0>;
             using GM = FrontGeomM<TT, 0>;
-            FMD_LAUNCH(r, true, true, kern, dim3((unsigned)(tiles * d.C)), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
-                       ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma);
+            if (pll) FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, 0, true>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
+                                ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, pf);
+            else FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, 0, false>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
+                            ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, pf);
         }
         return hipGetLastError();
     }
@@ -2658,15 +2682,15 @@ hipError_t launch_stage_predecim(const LaunchCtx& ctx, SlotRef r, const void* d_
 }
 
 // k_front on the 256 kSa/s stream: the capture itself (m == 1) or fm_in[slot]
-hipError_t launch_stage_front(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s) {
+hipError_t launch_stage_front(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s, const SlotRef* pll) {
     if (ctx.d.m > 1) {
         LaunchCtx c1 = ctx;
         c1.d.N = ctx.d.n_fm_in; c1.d.m = 1;
-        if (ctx.fast) return launch_front<float>(c1, r, reinterpret_cast<const float*>(ctx.b.fm_in[r.buf]), s);   // (phases: k_predecim<.., true>)
+        if (ctx.fast) return launch_front<float>(c1, r, reinterpret_cast<const float*>(ctx.b.fm_in[r.buf]), s, pll);   // (phases: k_predecim<.., true>)
         return launch_front<float2>(c1, r, ctx.b.fm_in[r.buf], s);
     }
-    if (u8) return launch_front<uchar2>(ctx, r, static_cast<const uchar2*>(d_iq), s);
-    return launch_front<float2>(ctx, r, static_cast<const float2*>(d_iq), s);
+    if (u8) return launch_front<uchar2>(ctx, r, static_cast<const uchar2*>(d_iq), s, pll);
+    return launch_front<float2>(ctx, r, static_cast<const float2*>(d_iq), s, pll);
 }
 
 static unsigned serial_waves(const Dims& d) { return (unsigned)((d.C + kWave - 1) / kWave); }
@@ -2701,8 +2725,14 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     if (ctx.fast) {
         const int nxt = (r.buf + 1) % kSlots;
         const bool iq = ctx.b.fm_out_iq[r.buf] != nullptr;    // FMD_FLAG_KEEP_TAPS, or audio blocks that are not multiples of 256: the interleaved streams too
-        FMD_LAUNCH(r, true, !iq, k_pll_span, dim3((unsigned)((d.C + 3) / 4)), dim3(kWave), 0, s, d, ctx.b.fo_pl[r.buf], ctx.b.fo_pl[nxt],
-                   ctx.b.pll_poly[r.buf], ctx.b.pll_poly[nxt], iq ? ctx.b.pll_dt[r.buf] : (float*)nullptr, ctx.b.state, ctx.loops, ctx.b.pilot_tab, ctx.b.span_tab, ctx.b.spec_stats);
+        // k_pll_sparse: 8 stations per wavefront, 4 wavefronts per workgroup.  In a block inside some station's start-up transient (r.warm)
+        // k_pll_span runs behind it and takes those stations (fmd_kernels_fast.inc)
+        FMD_LAUNCH(r, true, !iq && !r.warm, k_pll_sparse, dim3((unsigned)((d.C + 31) / 32)), dim3(4 * kWave), 0, s, d, ctx.b.fo_pl[r.buf], ctx.b.fo_pl[nxt],
+                   ctx.b.pll_poly[r.buf], ctx.b.pll_poly[nxt], ctx.b.state, ctx.loops, ctx.b.sparse_tab, r.warm, ctx.b.spec_stats);
+        if (r.warm)
+            FMD_LAUNCH(r, false, !iq, k_pll_span, dim3((unsigned)((d.C + 3) / 4)), dim3(kWave), 0, s, d, ctx.b.fo_pl[r.buf], ctx.b.fo_pl[nxt],
+                       ctx.b.pll_poly[r.buf], ctx.b.pll_poly[nxt], (float*)nullptr, ctx.b.state, ctx.loops, ctx.b.pilot_tab, ctx.b.span_tab, ctx.b.spec_stats, r.warm == 2 ? 1 : 0);
+        if (iq) FMD_LAUNCH(r, false, false, k_poly_to_dt, dim3((unsigned)((size_t)d.n_fm_out * d.C / 256)), dim3(256), 0, s, d, ctx.b.pll_poly[r.buf], ctx.b.pll_dt[r.buf]);
         if (iq) FMD_LAUNCH(r, false, true, k_planes_to_iq, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, ctx.b.fo_pl[r.buf], ctx.b.fm_out_iq[r.buf], ctx.front);
         return hipGetLastError();
     }
@@ -2798,10 +2828,16 @@ static hipError_t prepare_front() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front<InT, TT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(sizeof(float) * FrontGeom<TT>::LDS_FLOATS));
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(float) * FrontGeomM<TT, 0>::LDS_FLOATS));
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, kDeemphWarmup>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, kDeemphWarmup, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(float) * FrontGeomM<TT, kDeemphWarmup>::LDS_FLOATS));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(float) * FrontGeomM<TT, 0>::LDS_FLOATS));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, kDeemphWarmup, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(float) * FrontGeomM<TT, kDeemphWarmup>::LDS_FLOATS));
     if (e != hipSuccess) return e;
     return e;

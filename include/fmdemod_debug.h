@@ -43,6 +43,11 @@ int fmd_selftest_fast_math(int kind, const float* a, const float* b, float* out,
  * phase deviation at samples 41, 84, 127), s [5][8] weights of the state (lpf, I, e1, e2, r0), minv [3][4] cubic fit, misc[0] = the
  * quadrature factor, misc[1] = kappa.  tests/test_span_design.py checks them against an independent float64 restatement. */
 int fmd_design_pll_span(int fs_baseband, float* w, float* s, float* minv, float* misc2);
+/* ... and of the round-4 form that evaluates the loop's phase detector at 8 points of a span (PllSparseTab, k_pll_sparse): taps [2][32]
+ * (real, imaginary weight of a point's 32 input samples), cplx [19][2] = rot[8], scan[3], carry[8] as (re, im), rows [2][8] = wsum, wmom
+ * (5 used each), sw [5][132] suffix sums of the weight rows, misc8 = phi0, inv_s2, nbar, kappa, pw_scale, kap2 (re, im), 0.
+ * tests/test_span_design.py checks them against a float64 model of the reference's peak filter and loop. */
+int fmd_design_pll_sparse(int fs_baseband, float* taps, float* cplx, float* rows, float* sw, float* misc8);
 
 /* Counters of k_pilot_pll's frequency speculation since creation / the last reset (DESIGN.md "Pilot PLL"):
  * out8[0] = 128-sample chunks, summed over wavefronts (4 channels each); out8[1] = of those, chunks run with the plain serial

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round-4 GPU run: tolerance-mode tests with the pilot stage riding in the front end's launch, then A/B of the bench line
+O=gpurun_out/r4_3; mkdir -p $O
+python -m pytest tests/test_gpu_fast.py tests/test_gpu_long.py tests/test_gpu_scale.py -m gpu -q -x 2>&1 | tail -30 > $O/tests_fast.log
+Q="--no-cpu-baseline --no-other-mode --no-configs --no-host-fed"
+for rep in 1 2; do
+python bench.py $Q > $O/bench_fused_$rep.json 2> $O/bench.err
+FMD_NO_FUSED_PLL=1 python bench.py $Q > $O/bench_unfused_$rep.json 2>> $O/bench.err
+done
+python bench.py $Q --steps 20 --warmup 5 > $O/bench_driver.json 2>> $O/bench.err
+python bench.py $Q --fs 1024000 > $O/bench_1024k.json 2>> $O/bench.err
+python bench.py $Q --u8 > $O/bench_u8.json 2>> $O/bench.err
+python bench.py $Q --channels 1024 > $O/bench_1024ch.json 2>> $O/bench.err
+python bench.py $Q --channels 8192 > $O/bench_8192ch.json 2>> $O/bench.err
+bash tools/r3_alone_trace.sh > $O/alone.log 2>&1
