@@ -346,7 +346,7 @@ void design_pll_span(const fmd_coeffs& k, PllSpanTab* t) {
 }
 
 // Tables of k_pll_sparse (fmd_kernels.h PllSparseTab; float64 model: tools/proto/sparse_pll.py design_sparse)
-void design_pll_sparse(const fmd_coeffs& k, PllSparseTab* t) {
+void design_pll_sparse(const fmd_coeffs& k, PllSparseTab* t, std::vector<uint16_t>* pv_img = nullptr) {
     using cd = std::complex<double>;
     constexpr int L = kSpan, D = kSparseDec, KP = kSparsePts;
     const double two_pi = 6.283185307179586476925, w0 = two_pi * 19.0 / 128.0;
@@ -362,20 +362,44 @@ void design_pll_sparse(const fmd_coeffs& k, PllSparseTab* t) {
         for (int i = 0; i < D; i++) if (std::abs(q - i) <= 8) acc += std::pow(rho, i);
         W[q + 8] = acc / 17.0;
     }
-    for (int tt = 0; tt < 2 * D; tt++) {                        // tap tt multiplies x[m' - 25 + tt], q = 23 - tt; the mixer relative to the point
-        const cd wc = W[(23 - tt) + 8] * std::polar(1.0, -w0 * (double)(tt - 40));
-        t->wre[tt] = (float)wc.real(); t->wim[tt] = (float)wc.imag();
+    cd wcd[2 * D];
+    for (int tt = 0; tt < 2 * D; tt++) {                        // tap tt multiplies x[m' - 25 + tt], q = 23 - tt; the mixer relative to the point (m' = span + 16 k - 23)
+        wcd[tt] = W[(23 - tt) + 8] * std::polar(1.0, -w0 * (double)(tt - 46));
+        t->wre[tt] = (float)wcd[tt].real(); t->wim[tt] = (float)wcd[tt].imag();
+    }
+    if (pv_img) {
+        // k_front_mfma's extra operand rows: row r of the 16 x 16 x 32 tile sums v_r over a column's 16 outputs, v_0 / v_1 the new half's
+        // real / imaginary weights, v_2 / v_3 the old half's; an output is y[m] = sum_t h[t - 2 m] dem[t] (design_front_mfma), so
+        // A2[r][t] = sum_m v_r[m] h[t - 2 m], t < 96.  Rows 4-15 are zero.  Layout as toeplitz_image.
+        pv_img->assign((size_t)3 * 2 * 64 * 8, 0);
+        for (int sK = 0; sK < 3; sK++)
+            for (int l = 0; l < 64; l++)
+                for (int i = 0; i < 8; i++) {
+                    const int tt = 32 * sK + 8 * (l / 16) + i, row = l % 16;
+                    double v = 0.0;
+                    if (row < 4)
+                        for (int m = 0; m < D; m++) {
+                            const int idx = tt - 2 * m;
+                            if (idx < 0 || idx >= 64) continue;
+                            const cd w = wcd[(row < 2 ? D : 0) + m];
+                            v += ((row & 1) ? w.imag() : w.real()) * (double)k.b_fm_out[idx];
+                        }
+                    const float vf = (float)v;
+                    const uint16_t hi = bf16_rne(vf), lo = bf16_rne(vf - bf16_to_f32(hi));
+                    (*pv_img)[(((size_t)sK * 2 + 0) * 64 + l) * 8 + i] = hi;
+                    (*pv_img)[(((size_t)sK * 2 + 1) * 64 + l) * 8 + i] = lo;
+                }
     }
     const cd rho16 = std::pow(rho, D);
     for (int kk = 0; kk < KP; kk++) {
         const cd ro = std::polar(1.0, -w0 * (double)(D * kk)), ca = std::pow(rho16, kk + 1);
         t->rot[kk][0] = (float)ro.real(); t->rot[kk][1] = (float)ro.imag();
         t->carry[kk][0] = (float)ca.real(); t->carry[kk][1] = (float)ca.imag();
-        t->nk1[kk] = (float)(D * kk + D);
+        t->nk1[kk] = (float)(D * kk + 10);
     }
     double nbar = 0.0, s2 = 0.0;
-    for (int kk = 0; kk < KP; kk++) nbar += (double)(D * kk + D - 1) / KP;
-    for (int kk = 0; kk < KP; kk++) { const double c = (double)(D * kk + D - 1) - nbar; t->ck[kk] = (float)c; s2 += c * c; }
+    for (int kk = 0; kk < KP; kk++) nbar += (double)(D * kk + 9) / KP;
+    for (int kk = 0; kk < KP; kk++) { const double c = (double)(D * kk + 9) - nbar; t->ck[kk] = (float)c; s2 += c * c; }
     for (int s_ = 0; s_ < 3; s_++) { const cd p = std::pow(rho16, 1 << s_); t->scan[s_][0] = (float)p.real(); t->scan[s_][1] = (float)p.imag(); }
     const cd cA = cd(0.0, -1.0) * ((double)k.pilot_b[0] / std::sin(wp)) * std::polar(1.0, wp);
     double phi0 = std::arg(cA) / two_pi - 19.0 * 33.0 / 128.0;
@@ -444,6 +468,7 @@ int zero_history(fmd_handle h, hipStream_t s) {
         HIP_TRY(h, hipMemsetAsync(b.dt_tail[p], 0, sizeof(float) * (size_t)d.C * 128, s));
         HIP_TRY(h, hipMemsetAsync(b.fo_tail[p], 0, sizeof(float) * (size_t)d.C * 64, s));
         HIP_TRY(h, hipMemsetAsync(b.lmr_est[p], 0, sizeof(float) * (size_t)d.C * d.n_est, s));
+        if (b.pv_hist[p]) HIP_TRY(h, hipMemsetAsync(b.pv_hist[p], 0, sizeof(float4) * (size_t)d.C * 4, s));
     }
     for (int p = 0; p < kSlots; p++) {
         if (b.fo_pl[p]) {   // the history in front of the planes' rows (and the rows themselves)
@@ -503,7 +528,6 @@ int launch_deferred_pll(fmd_handle h, hipStream_t sP) {
 int launch_deferred(fmd_handle h, bool behind_front) {
     auto& q = h->deferred;
     if (!q.active) return FMD_OK;
-    q.active = false;
     hipStream_t sXq = behind_front ? h->sF : h->sX, sR = h->sR;
     if (h->consumer_pending[q.slot]) {       // fmd_release_outputs: a consumer still reads this slot's old outputs
         HIP_TRY(h, hipStreamWaitEvent(sXq, h->ev_C[q.slot], 0));
@@ -512,6 +536,7 @@ int launch_deferred(fmd_handle h, bool behind_front) {
     }
     if (h->last_x_event && h->last_x_stream != sXq) HIP_TRY(h, hipStreamWaitEvent(sXq, h->last_x_event, 0));
     { int rc = launch_deferred_pll(h, behind_front ? h->sF : h->sB); if (rc) return rc; }
+    q.active = false;
     if (q.pll_dep && q.pll_stream != sXq) HIP_TRY(h, hipStreamWaitEvent(sXq, q.pll_dep, 0));
     hipEvent_t dep;
     {
@@ -925,6 +950,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
         if (!rc && streams) rc = dev_alloc(h, &b.pll_dt[p], C * d.n_fm_out);
         if (!rc && fast) rc = dev_alloc(h, &b.fo_pl[p], C * ((size_t)kFoPad + d.n_fm_out));
         if (!rc && fast) rc = dev_alloc(h, &b.pll_poly[p], C * ((size_t)1 + d.n_fm_out / kSpan));
+        if (!rc && fast) rc = dev_alloc(h, &b.pv_pl[p], C * (size_t)(d.n_fm_out / 16));
         if (!rc && fast) rc = dev_alloc(h, &b.rds_pow[p], C * (size_t)(2 * (d.n_audio / 256) + 2));
         if (!rc) rc = dev_alloc(h, &b.audio[p], C * d.n_audio * 2);
         if (!rc) rc = dev_alloc(h, &b.rds_sym[p], C * d.n_rds);
@@ -937,6 +963,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
         if (!rc) rc = dev_alloc(h, &b.rds[p], C * d.n_rds);
     }
     for (int p = 0; p < 2 && !rc; p++) rc = dev_alloc(h, &b.lmr_est[p], C * d.n_est);
+    for (int p = 0; p < 2 && !rc && fast; p++) rc = dev_alloc(h, &b.pv_hist[p], C * 4);
     if (!rc) rc = dev_alloc(h, &b.lmr_peek, C);
     if (!rc) rc = dev_alloc(h, &b.b_lpr, C * 128);
     if (!rc) rc = dev_alloc(h, &b.b_lmr, C * 128);
@@ -970,9 +997,12 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
             if (!rc) rc = dev_alloc(h, &b.sparse_tab, 1);
             if (!rc) {
                 PllSparseTab sp_;
-                design_pll_sparse(h->base, &sp_);
-                if (hipMemcpyAsync(b.sparse_tab, &sp_, sizeof(sp_), hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
-                    hipStreamSynchronize(h->own_stream) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "sparse table upload failed");
+                std::vector<uint16_t> pimg;
+                design_pll_sparse(h->base, &sp_, &pimg);
+                rc = dev_alloc(h, &b.pv_img, pimg.size() * 2 / sizeof(uint4));
+                if (!rc && (hipMemcpyAsync(b.sparse_tab, &sp_, sizeof(sp_), hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
+                            hipMemcpyAsync(b.pv_img, pimg.data(), pimg.size() * 2, hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
+                            hipStreamSynchronize(h->own_stream) != hipSuccess)) rc = fail(h, FMD_ERR_DEVICE, "sparse table upload failed");
             }
             PilotFastTab tab;
             design_pilot_fast(h->base, &tab);
@@ -1267,6 +1297,7 @@ std::vector<StatePart> state_parts(fmd_handle h) {
     }
     { void* p[2] = {b.fo_tail[0], b.fo_tail[1]}; by_par(p, 64, 0); }
     { void* p[2] = {b.lmr_est[0], b.lmr_est[1]}; by_par(p, (size_t)d.n_est, 1); }   // the newest block's L-R phase estimates (the next k_extract integrates them)
+    if (b.pv_hist[0]) { void* p[2] = {b.pv_hist[0], b.pv_hist[1]}; by_par(p, 16, 0); }   // tolerance mode: the last four columns' pilot sums (k_pll_sparse)
     if (b.fo_pl[0]) {       // tolerance mode: the previous block's tails in front of the next slot's rows (k_pll_span)
         v.push_back({b.fo_pl[slot], (size_t)kFoPad, (size_t)kFoPad + d.n_fm_out});
         v.push_back({reinterpret_cast<float*>(b.pll_poly[slot]), 4, 4 * ((size_t)1 + d.n_fm_out / kSpan)});

@@ -97,11 +97,15 @@ struct PllSpanTab {
 static constexpr int kSparsePts = 8, kSparseDec = kSpan / kSparsePts;      // points per span, samples between them
 static constexpr float kPllWarmSamples = 8192.0f;
 struct PllSparseTab {
-    float wre[2 * kSparseDec], wim[2 * kSparseDec];   // tap t of a point multiplies fm_out[span + 16 k - 42 + t]; taps 16.. are the lane's own chunk ("new"), 0..15 the previous lane's ("old")
+    // points sit at n_k = 16 k + 9 of a span: a point's 32 inputs fm_out[span + 16 k - 48 + t] are then two whole 16-sample columns of the
+    // front end's tiles, (k - 3) its "old" half (taps 0..15) and (k - 2) its "new" half (taps 16..31): k_front_mfma sums both halves of every
+    // column on the matrix cores (four more rows of a Toeplitz operand, Buffers::pv_img) and k_pll_sparse reads 16 bytes per column
+    // instead of the 64 bytes of fm_out
+    float wre[2 * kSparseDec], wim[2 * kSparseDec];
     float rot[kSparsePts][2];        // e^{-j w0 16 k}
     float scan[3][2];                // rho^16, rho^32, rho^64
     float carry[kSparsePts][2];      // rho^(16 (k + 1))
-    float ck[kSparsePts];            // n_k - nbar, n_k = 16 k + 15
+    float ck[kSparsePts];            // n_k - nbar, n_k = 16 k + 9
     float nk1[kSparsePts];           // n_k + 1
     float phi0;                      // arg(-j (K / sin wp) e^{j wp}) / 2 pi - 19 * 33 / 128: arg Z -> the phase the reference's detector sees, minus frac(19 (n + 1) / 128)
     float inv_s2, nbar, kappa, pw_scale;
@@ -178,6 +182,9 @@ struct Buffers {
     float*  rds_pow[kSlots];         // [C][2 n_audio / 256]  partial sums of |rds|^2 (k_extract_mfma -> k_rds_sync's AGC)
     PllSpanTab* span_tab;
     PllSparseTab* sparse_tab;
+    float4* pv_pl[kSlots];           // [C][n_fm_out / 16] per 16-sample column of fm_out: (new.re, new.im, old.re, old.im), the two half sums of the pilot points' inputs
+    float4* pv_hist[2];              // [C][4] the previous block's last four columns, by block parity (k_pll_sparse reads [par], writes [par ^ 1])
+    uint4*  pv_img;                  // operand image of those sums for k_front_mfma: rows 0-3 = (sum_m v_r[m] h[t - 2 m]), [k-step][hi/lo][lane]
     PilotFastTab* pilot_tab;         // FMD_FLAG_FAST_MATH only
     uint4*  aud_img;                 // ... of k_extract_mfma's audio FIRs, one per distinct cut-off: [slot][k-step][hi/lo][lane]
     int2*   aud_idx;                 // [C] slots of a station's L+R and L-R images

@@ -41,6 +41,10 @@
     } while (0)
 
 
+#ifndef FMD_PV_VARIANT
+#define FMD_PV_VARIANT 4
+#endif
+
 namespace fmd {
 
 static constexpr int kWave = 64;
@@ -271,19 +275,18 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
 // schedule (fmd_api.cpp) the front end's queue then carries front(k + 1) + pilot(k), extract(k), front(k + 2) + pilot(k + 1), ... and no
 // kernel on it waits for another queue; the pilot stage's half-thousand wavefronts start first and finish inside the front end's HBM-bound time.
 template <typename InT, int TT, int WU, bool FUSED = false>
-__global__ __launch_bounds__(256, FUSED ? 4 : 1) void k_front_mfma(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
+__global__ __launch_bounds__(256, 5) void k_front_mfma(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
                                                     float2* __restrict__ tail_out, float* __restrict__ fo_pl, float fm_gain,
-                                                    const float* __restrict__ deemph, const uint4* __restrict__ tab, PllFusedArgs pf) {
+                                                    const float* __restrict__ deemph, const uint4* __restrict__ tab, float4* __restrict__ pv_pl,
+                                                    const uint4* __restrict__ pv_img, const PllSparseTab* __restrict__ sp, PllFusedArgs pf) {
     using G = FrontGeomM<TT, WU>;
     constexpr int T = G::T, NW = G::NW, NF = G::NF;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bid = (int)blockIdx.x;
     if constexpr (FUSED) {
         if (bid < pf.n_wg) {
-            float4* wl = reinterpret_cast<float4*>(smem);
-            if (threadIdx.x < 16) wl[threadIdx.x] = threadIdx.x < 8 ? *reinterpret_cast<const float4*>(&pf.tab->wre[4 * threadIdx.x]) : *reinterpret_cast<const float4*>(&pf.tab->wim[4 * (threadIdx.x - 8)]);
-            __syncthreads();
-            pll_sparse_body(d, bid * 4 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & (kWave - 1)), pf.fo, pf.fo_next, pf.poly, pf.poly_next, pf.state, pf.k, pf.tab, wl, 0, pf.spec_stats);
+            pll_sparse_body(d, bid * 4 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & (kWave - 1)), pf.pv, pf.hist_in, pf.hist_out, pf.fo, pf.fo_next, pf.poly, pf.poly_next,
+                            pf.state, pf.k, pf.tab, 0, pf.spec_stats);
             return;
         }
         bid -= pf.n_wg;
@@ -307,6 +310,22 @@ __global__ __launch_bounds__(256, FUSED ? 4 : 1) void k_front_mfma(Dims d, const
     for (int sK = 0; sK < 3; sK++) {
         adh[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 0) * kWave + lane]);
         adl[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 1) * kWave + lane]);
+    }
+    // ... and of the pilot stage's column sums (PllSparseTab): rows 0-3 of a second tile on the same windows = the four half sums of the
+    // column's 16 outputs (k_pll_sparse then reads 16 bytes per column instead of fm_out's 64)
+    float4* pv_row = pv_pl + (size_t)c * (d.n_fm_out / 16) + o0 / 16;
+    float4 wNr, wNi, wOr, wOi;           // FMD_PV_VARIANT 4: the weights of this lane's four outputs in the four sums (with the other early loads)
+    if constexpr (WU == 0 && FMD_PV_VARIANT == 4) {
+        wNr = *reinterpret_cast<const float4*>(&sp->wre[16 + 4 * lq]); wNi = *reinterpret_cast<const float4*>(&sp->wim[16 + 4 * lq]);
+        wOr = *reinterpret_cast<const float4*>(&sp->wre[4 * lq]); wOi = *reinterpret_cast<const float4*>(&sp->wim[4 * lq]);
+    }
+    bf16x8 aph[3], apl[3];
+    if constexpr (WU == 0 && FMD_PV_VARIANT < 3) {
+#pragma unroll
+        for (int sK = 0; sK < 3; sK++) {
+            aph[sK] = __builtin_bit_cast(bf16x8, pv_img[(sK * 2 + 0) * kWave + lane]);
+            apl[sK] = __builtin_bit_cast(bf16x8, pv_img[(sK * 2 + 1) * kWave + lane]);
+        }
     }
     // a0-a2: staging, arctangent (all loads first)
     bool staged = false;
@@ -428,6 +447,7 @@ __global__ __launch_bounds__(256, FUSED ? 4 : 1) void k_front_mfma(Dims d, const
         const int col = ct * 16 + lrow, colr = col < G::NCOL ? col : G::NCOL - 1;
         // (round 3, PMC: a wavefront of this kernel spent 37 % of its cycles waiting for the previous MFMA of one nine-long chain)
         f32x4 acc, acc1, acc2;   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
+        f32x4 pc, pc1, pc2;
 #pragma unroll
         for (int sK = 0; sK < 3; sK++) {
             const int e = 32 * colr + 32 * sK + 8 * lq;              // bf16 element index, a multiple of 8
@@ -436,8 +456,42 @@ __global__ __launch_bounds__(256, FUSED ? 4 : 1) void k_front_mfma(Dims d, const
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bh, sK ? acc : kZero4, 0, 0, 0);      // (the first step starts from the constant 0: no registers to clear)
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adl[sK], bh, sK ? acc1 : kZero4, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bl, sK ? acc2 : kZero4, 0, 0, 0);
+            if constexpr (WU == 0 && FMD_PV_VARIANT == 0) {
+                pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aph[sK], bh, sK ? pc : kZero4, 0, 0, 0);
+                pc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(apl[sK], bh, sK ? pc1 : kZero4, 0, 0, 0);
+                pc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aph[sK], bl, sK ? pc2 : kZero4, 0, 0, 0);
+            }
+            if constexpr (WU == 0 && FMD_PV_VARIANT == 1) {
+                pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aph[sK], bh, sK ? pc : kZero4, 0, 0, 0);
+                pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(apl[sK], bh, pc, 0, 0, 0);
+            }
+            if constexpr (WU == 0 && FMD_PV_VARIANT == 2) {
+                pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aph[sK], bh, sK ? pc : kZero4, 0, 0, 0);
+            }
         }
         acc = acc + (acc1 + acc2);
+        if constexpr (WU == 0 && FMD_PV_VARIANT == 4) {
+            // the pilot stage's column sums from the fp32 outputs in the accumulators: a lane holds outputs 4 lq .. 4 lq + 3 of its column; its four
+            // partial sums meet their column's other three lanes (16, 32, 48 lanes on) in two swap steps that leave ONE total in each lane
+            const float p0 = fmaf(wNr.x, acc[0], fmaf(wNr.y, acc[1], fmaf(wNr.z, acc[2], wNr.w * acc[3])));
+            const float p1 = fmaf(wNi.x, acc[0], fmaf(wNi.y, acc[1], fmaf(wNi.z, acc[2], wNi.w * acc[3])));
+            const float p2 = fmaf(wOr.x, acc[0], fmaf(wOr.y, acc[1], fmaf(wOr.z, acc[2], wOr.w * acc[3])));
+            const float p3 = fmaf(wOi.x, acc[0], fmaf(wOi.y, acc[1], fmaf(wOi.z, acc[2], wOi.w * acc[3])));
+            // v_permlane16_swap: the odd rows (of 16 lanes) of the first operand change places with the even rows of the second
+            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p0), __float_as_uint(p2), false, false);
+            const float s02 = __uint_as_float(r[0]) + __uint_as_float(r[1]);       // even rows: p0 over the row pair; odd rows: p2
+            r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p1), __float_as_uint(p3), false, false);
+            const float s13 = __uint_as_float(r[0]) + __uint_as_float(r[1]);       // even rows: p1; odd rows: p3
+            // v_permlane32_swap: the upper half of the first operand changes places with the lower half of the second
+            r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s02), __float_as_uint(s13), false, false);
+            const float tot = __uint_as_float(r[0]) + __uint_as_float(r[1]);        // rows 0-3: new.re, old.re, new.im, old.im
+            const int idx = ((lq & 1) << 1) | (lq >> 1);
+            if (col < G::NCOL) reinterpret_cast<float*>(pv_row + col)[idx] = tot;
+        }
+        if constexpr (WU == 0 && FMD_PV_VARIANT < 3) {
+            if constexpr (FMD_PV_VARIANT == 0) pc = pc + (pc1 + pc2);
+            if (col < G::NCOL && lq == 0) pv_row[col] = make_float4(pc[0], pc[1], pc[2], pc[3]);       // rows 0-3: 16 lanes, 256 bytes in a row
+        }
         if (col < G::NCOL) {
             if constexpr (WU == 0) *reinterpret_cast<float4*>(fo_row + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);   // a wavefront: 4 KB in a row
             else *reinterpret_cast<float4*>(fo + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -475,6 +529,16 @@ __global__ __launch_bounds__(256, FUSED ? 4 : 1) void k_front_mfma(Dims d, const
             __syncthreads();
         }
         for (int q4 = tid; q4 < T / 4; q4 += 256) *reinterpret_cast<float4*>(fo_row + 4 * q4) = *reinterpret_cast<const float4*>(fo + WU + 4 * q4);
+        // the pilot stage's column sums from the de-emphasised outputs (the reference filters fm_out in place ahead of every consumer,
+        // broadcast_fm_demod.cpp:403-406): thread = (column, one of its four sums), fp32
+        for (int cc = tid >> 2; cc < T / 16; cc += 64) {
+            const int part = tid & 3;
+            const float* w = ((part & 1) ? sp->wim : sp->wre) + ((part < 2) ? 16 : 0);
+            float a0_ = 0.0f, a1_ = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) { a0_ = fmaf(w[i], fo[WU + 16 * cc + i], a0_); a1_ = fmaf(w[i + 1], fo[WU + 16 * cc + i + 1], a1_); }
+            reinterpret_cast<float*>(pv_row + cc)[part] = a0_ + a1_;
+        }
     }
     if (tile == tiles - 1) {
         float2* tout = tail_out + (size_t)c * d.tail_base;
@@ -2622,21 +2686,22 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
         PllFusedArgs pf{};
         if (pll) {          // the pilot stage of the block in slot pll->buf as this launch's first workgroups
             const int nxt = (pll->buf + 1) % kSlots;
-            pf = PllFusedArgs{(d.C + 31) / 32, ctx.b.fo_pl[pll->buf], ctx.b.fo_pl[nxt], ctx.b.pll_poly[pll->buf], ctx.b.pll_poly[nxt], ctx.b.state, ctx.loops, ctx.b.sparse_tab, ctx.b.spec_stats};
+            pf = PllFusedArgs{(d.C + 31) / 32, ctx.b.pv_pl[pll->buf], ctx.b.pv_hist[pll->par], ctx.b.pv_hist[pll->par ^ 1], ctx.b.fo_pl[pll->buf], ctx.b.fo_pl[nxt],
+                              ctx.b.pll_poly[pll->buf], ctx.b.pll_poly[nxt], ctx.b.state, ctx.loops, ctx.b.sparse_tab, ctx.b.spec_stats};
         }
         const unsigned grid = (unsigned)(tiles * d.C + pf.n_wg);
         if (ctx.deemph_in_tile) {
             using GM = FrontGeomM<TT, kDeemphWarmup>;
             if (pll) FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, kDeemphWarmup, true>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
-                                ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, pf);
+                                ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, ctx.b.pv_pl[r.buf], ctx.b.pv_img, ctx.b.sparse_tab, pf);
             else FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, kDeemphWarmup, false>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
-                            ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, pf);
+                            ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, ctx.b.pv_pl[r.buf], ctx.b.pv_img, ctx.b.sparse_tab, pf);
         } else {
             using GM = FrontGeomM<TT, 0>;
             if (pll) FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, 0, true>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
-                                ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, pf);
+                                ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, ctx.b.pv_pl[r.buf], ctx.b.pv_img, ctx.b.sparse_tab, pf);
             else FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, 0, false>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
-                            ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, pf);
+                            ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, ctx.b.pv_pl[r.buf], ctx.b.pv_img, ctx.b.sparse_tab, pf);
         }
         return hipGetLastError();
     }
@@ -2699,7 +2764,9 @@ hipError_t launch_stage_deemph(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
     if (ctx.fast) {   // a time constant beyond the in-tile form: in place on the plane (rows: kFoPad samples of history in front of the block)
-        FMD_LAUNCH(r, true, true, k_deemphasis, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.fo_pl[r.buf] + kFoPad, b.deemph, b.state, kFoPad + d.n_fm_out);
+        FMD_LAUNCH(r, true, false, k_deemphasis, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.fo_pl[r.buf] + kFoPad, b.deemph, b.state, kFoPad + d.n_fm_out);
+        const int ncol = d.n_fm_out / kSparseDec;
+        FMD_LAUNCH(r, false, true, k_pilot_sums, dim3((unsigned)(d.C * ((ncol + 63) / 64))), dim3(256), 0, s, d, b.fo_pl[r.buf], b.pv_pl[r.buf], b.sparse_tab);
         return hipGetLastError();
     }
     FMD_LAUNCH(r, true, false, k_deemphasis, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.fm_out[r.buf], b.deemph, b.state, d.n_fm_out);
@@ -2727,8 +2794,8 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
         const bool iq = ctx.b.fm_out_iq[r.buf] != nullptr;    // FMD_FLAG_KEEP_TAPS, or audio blocks that are not multiples of 256: the interleaved streams too
         // k_pll_sparse: 8 stations per wavefront, 4 wavefronts per workgroup.  In a block inside some station's start-up transient (r.warm)
         // k_pll_span runs behind it and takes those stations (fmd_kernels_fast.inc)
-        FMD_LAUNCH(r, true, !iq && !r.warm, k_pll_sparse, dim3((unsigned)((d.C + 31) / 32)), dim3(4 * kWave), 0, s, d, ctx.b.fo_pl[r.buf], ctx.b.fo_pl[nxt],
-                   ctx.b.pll_poly[r.buf], ctx.b.pll_poly[nxt], ctx.b.state, ctx.loops, ctx.b.sparse_tab, r.warm, ctx.b.spec_stats);
+        FMD_LAUNCH(r, true, !iq && !r.warm, k_pll_sparse, dim3((unsigned)((d.C + 31) / 32)), dim3(4 * kWave), 0, s, d, ctx.b.pv_pl[r.buf], ctx.b.pv_hist[r.par], ctx.b.pv_hist[r.par ^ 1],
+                   ctx.b.fo_pl[r.buf], ctx.b.fo_pl[nxt], ctx.b.pll_poly[r.buf], ctx.b.pll_poly[nxt], ctx.b.state, ctx.loops, ctx.b.sparse_tab, r.warm, ctx.b.spec_stats);
         if (r.warm)
             FMD_LAUNCH(r, false, !iq, k_pll_span, dim3((unsigned)((d.C + 3) / 4)), dim3(kWave), 0, s, d, ctx.b.fo_pl[r.buf], ctx.b.fo_pl[nxt],
                        ctx.b.pll_poly[r.buf], ctx.b.pll_poly[nxt], (float*)nullptr, ctx.b.state, ctx.loops, ctx.b.pilot_tab, ctx.b.span_tab, ctx.b.spec_stats, r.warm == 2 ? 1 : 0);

@@ -98,7 +98,7 @@ def test_sparse_rows_are_the_span_rows_applied_to_a_line():
     w, s, minv, _ = _tables()
     taps, cplx, rows, sw, misc = _sparse_tables()
     nbar = float(misc[2])
-    assert abs(nbar - np.mean(16 * np.arange(8) + 15)) < 1e-6
+    assert abs(nbar - np.mean(16 * np.arange(8) + 9)) < 1e-6
     n = np.arange(L, dtype=np.float64)
     w64 = w.astype(np.float64)
     w64[2:5] = minv[:, :3].astype(np.float64) @ w64[2:5]              # the sparse form's rows 2..4 are the cubic's coefficients themselves
@@ -107,7 +107,7 @@ def test_sparse_rows_are_the_span_rows_applied_to_a_line():
     suf = np.cumsum(w64[:, ::-1], axis=1)[:, ::-1]
     assert np.allclose(sw[:, :L], suf, rtol=2e-5, atol=1e-9) and np.all(sw[:, L] == 0.0)
     # a line through the 8 points: mean and slope as the kernel takes them reproduce sum_n w[r][n] (a + b (n - nbar))
-    nk = 16 * np.arange(8) + 15
+    nk = 16 * np.arange(8) + 9
     a, b = 0.0123, -3.1e-4
     ek = a + b * (nk - nbar)
     am, bs = ek.mean(), np.sum((nk - nbar) * ek) * float(misc[1])
@@ -143,14 +143,14 @@ def test_sparse_points_see_the_phase_the_reference_filter_has(offset_hz):
     worst = 0.0
     for q in range(n // L):
         for kk in range(8):
-            base = 192 + L * q + 16 * kk - 42
+            base = 192 + L * q + 16 * kk - 48                        # the point's 32 inputs: columns k - 3 and k - 2 of the front end's tiles
             V = rot[kk] * np.sum(Wc * xp[base:base + 32])
             Z = rho16 * Z + V
             if q >= 400:                                             # settled
-                nn = L * q + 16 * kk + 15                            # sample index of the point
+                nn = L * q + 16 * kk + 9                             # sample index of the point
                 phi = np.angle(Z + kap2 * V) / TWO_PI + float(misc[0])          # + phi0
                 re, im = P[nn + 1], (P[nn] - P[nn + 2]) / (2.0 * np.sin(wt))      # P'[nn - 1], (P'[nn - 2] - P'[nn]) / (2 sin w)
-                psi = np.arctan2(im, re) / TWO_PI - 19.0 * ((16 * kk + 15) + 1) / 128.0
+                psi = np.arctan2(im, re) / TWO_PI - 19.0 * ((16 * kk + 9) + 1) / 128.0
                 dlt = phi - psi
                 worst = max(worst, abs(dlt - np.round(dlt)))
     assert worst < (2e-6 if abs(offset_hz) < 5 else 6e-6), worst
