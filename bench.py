@@ -401,7 +401,9 @@ def main() -> None:
     ap.add_argument("--block", type=int, default=0, help="baseband samples per channel per step (default: 64 ms)")
     ap.add_argument("--u8", action="store_true", help="u8 IQ ingest (2 B/sample) instead of cf32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", default="root", choices=["root", "all", "none"],
+    ap.add_argument("--config3", action="store_true", help="BASELINE configs[3] literally: 8192 stations per GPU (65 536 on 8 GPUs); the default for "
+                    "every N is configs[2]'s 4096 per GPU, so that the per-N values the driver compares are one workload (weak scaling)")
+    ap.add_argument("--gather", default="rotate", choices=["rotate", "root", "all", "none"],
                     help="N>1: per-step audio collective — 'root': every rank sends its block to rank 0 (point-to-point over the "
                          "direct xGMI links; default), 'all': all-gather to every rank, 'none': no collective")
     ap.add_argument("--gather-format", default="pcm16", choices=["pcm16", "f32"],
@@ -475,6 +477,8 @@ def main() -> None:
 
     fs = args.fs
     block = args.block or (fs * 64 // 1000)
+    if args.config3:
+        args.channels = 8192
     C = args.channels
     K, W, P = args.steps, args.warmup, max(args.preroll, 0)
     n_blocks_resident = min(K + W + P, 8)  # distinct consecutive blocks kept in HBM, cycled
@@ -494,8 +498,9 @@ def main() -> None:
     dm_n_audio = dm.rates.n_audio
     pcm16 = args.gather_format == "pcm16"
     if do_gather:
+        rds_cap = int(dm.rds_bytes_tensors()[0].shape[1])
         gather = pkg.AudioGather(dist, torch, C, dm.rates.n_audio, world, device, mode=args.gather,
-                                 dtype=torch.int16 if pcm16 else torch.float32)
+                                 dtype=torch.int16 if pcm16 else torch.float32, rds_cap=rds_cap)
         gstream = torch.cuda.Stream(device)   # consumes outputs; the submitting stream never waits on them
         dm.set_output_lag(True)
 
@@ -513,10 +518,14 @@ def main() -> None:
                 else:
                     dm.wait_outputs(gstream)
                     gather.stage[s].copy_(dm.audio_tensor(), non_blocking=True)
+                # ... and the block's RDS bytes and their counts: the reference's second observer per station (src/app.cpp:27-34)
+                rb, rc_ = dm.rds_bytes_tensors()
+                sb, sc = gather.stage_rds_views(s)
+                sb.copy_(rb, non_blocking=True); sc.copy_(rc_, non_blocking=True)
                 # the output views of this block have been read into the staging buffer once gstream gets here: the library
                 # must not reuse them earlier, however far the submitting side runs ahead of the collective
                 dm.release_outputs(gstream)
-                gather.launch(s)
+                gather.launch(s, k)
 
     def drain():
         if do_gather:
@@ -553,20 +562,28 @@ def main() -> None:
     gather_verified = None
     if do_gather:
         s_last = (P + W + K - 1) % gather.depth
-        mine = gather.stage[s_last].to(torch.float64).sum().item(), int(gather.stage[s_last].ne(0).sum().item())
+        mine = (gather.stage[s_last].to(torch.float64).sum().item(), int(gather.stage[s_last].ne(0).sum().item()),
+                gather.stage_rds[s_last].to(torch.float64).sum().item())
         sums = [None] * world
         dist.all_gather_object(sums, mine)
-        if gather.out[s_last] is not None:
+        ok = None
+        if gather.holds(s_last):       # the rank that collected the last block (mode "rotate": whichever it fell to) checks it
             parts = gather.out[s_last].chunk(world, dim=0)
-            gather_verified = all((pt.to(torch.float64).sum().item(), int(pt.ne(0).sum().item())) == tuple(sm) for pt, sm in zip(parts, sums))
-            gather_verified = gather_verified and torch.equal(parts[rank], gather.stage[s_last]) and sums[0][1] > 0
+            ok = all((pt.to(torch.float64).sum().item(), int(pt.ne(0).sum().item())) == tuple(sm[:2]) for pt, sm in zip(parts, sums))
+            ok = ok and torch.equal(parts[rank], gather.stage[s_last]) and sums[0][1] > 0
+            ok = ok and all(gather.out_rds[s_last][q].to(torch.float64).sum().item() == sums[q][2] for q in range(world))
+            ok = bool(ok and torch.equal(gather.out_rds[s_last][rank], gather.stage_rds[s_last]))
+        oks = [None] * world
+        dist.all_gather_object(oks, ok)
+        gather_verified = next((o for o in oks if o is not None), None)
     ktimes = dm.profile_read()
     gaps = {k[4:]: v[0] / max(v[1], 1) for k, v in ktimes.items() if k.startswith("gap:")}   # stream hand-over between launches
     ktimes = {k: v for k, v in ktimes.items() if not k.startswith("gap:")}
     spec = dm.spec_stats()
 
-    gather_note = "" if not do_gather else (f", per-step audio gather to rank 0 ({args.gather_format}, RCCL)" if args.gather == "root"
-                                            else f", per-step audio all-gather ({args.gather_format}, RCCL)")
+    gather_note = "" if not do_gather else ({"root": f", per-step gather of audio ({args.gather_format}) + RDS bytes to rank 0 (RCCL)",
+                                             "rotate": f", per-step gather of audio ({args.gather_format}) + RDS bytes to rank k mod {world} (RCCL)",
+                                             "all": f", per-step all-gather of audio ({args.gather_format}) + RDS bytes (RCCL)"}[args.gather])
     samples_per_step = C * block * world
     value = samples_per_step * K / el / 1e6
     bps = algorithmic_bytes_per_sample(fs, args.u8)
@@ -627,7 +644,9 @@ def main() -> None:
         "data": "synthetic",
         "config": {"workload": ("BASELINE configs[2]: " if (C, fs, args.u8) == (4096, 256000, False) else "variant of BASELINE configs[2]: ") +
                                f"{C} synthetic FM channels/GPU @ {fs} Sa/s, {block}-sample blocks, "
-                               f"{'u8' if args.u8 else 'cf32'} IQ resident in HBM, full stereo + pilot PLL + RDS",
+                               f"{'u8' if args.u8 else 'cf32'} IQ resident in HBM, full stereo + pilot PLL + RDS" +
+                               ("" if world == 1 else f"; {C * world} stations over {world} GPUs" +
+                                (" = BASELINE configs[3]" if (C, world) == (8192, 8) else " (BASELINE configs[3] literally, 65536 stations over 8 GPUs, is --config3: 8192 per GPU)")),
                    "channels_per_gpu": C, "fs_baseband": fs, "block_size": block, "ingest": "u8" if args.u8 else "cf32",
                    "preroll_blocks": P, "resident_signal": f"{n_blocks_resident} consecutive blocks cycled (phase-continuous for the 19 kHz pilot)",
                    "mode": MODE_TEXT[args.fast_math],
@@ -637,10 +656,14 @@ def main() -> None:
         "gather_verified": gather_verified,
         # what the per-step gather asks of the collector's xGMI links (one direct link per peer): at throughput-mode rates this, not the
         # demodulation, can bound the multi-GPU step
-        "gather": None if not do_gather else {
-            "format": args.gather_format, "bytes_per_rank_per_step": C * dm_n_audio * 2 * (2 if pcm16 else 4),
-            "gb_per_s_per_link_at_this_rate": C * dm_n_audio * 2 * (2 if pcm16 else 4) * K / el / 1e9,
-            "collector_ingress_gb_per_s": (world - 1) * C * dm_n_audio * 2 * (2 if pcm16 else 4) * K / el / 1e9 if args.gather == "root" else None},
+        "gather": None if not do_gather else (lambda per_rank: {
+            "mode": args.gather, "format": args.gather_format, "payload": "audio + RDS byte buffers + counts",
+            "bytes_per_rank_per_step": per_rank,
+            # root: every block of a rank crosses its link to the one collector; rotate: 1 / world of them cross each of its links
+            "gb_per_s_per_link_at_this_rate": per_rank * K / el / 1e9 / (world if args.gather == "rotate" else 1),
+            "xgmi_link_gb_per_s_per_direction": 77,
+            "collector_ingress_gb_per_s": (world - 1) * per_rank * K / el / 1e9 / (world if args.gather == "rotate" else 1) if args.gather != "all" else None,
+        })(C * dm_n_audio * 2 * (2 if pcm16 else 4) + gather.rds_bytes),
         "channels_at_realtime": value * 1e6 / fs,
         "msa_per_gpu": value / world,
         "roofline": roofline,

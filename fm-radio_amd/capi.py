@@ -435,6 +435,21 @@ class BatchDemod:
             __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (p.value, False), "version": 2}
         return torch.as_tensor(_Arr(), device="cuda").view(self.n_channels, self.rates.n_audio, 2)
 
+    def rds_bytes_tensors(self):
+        """Zero-copy torch views of the newest block's RDS byte buffers: (bytes [C, cap] uint8, counts [C] int32) — fmd_rds_bytes_dev; same
+        lifetime rule as audio_tensor()."""
+        import torch
+        pb, pc, cap = C.c_void_p(), C.c_void_p(), C.c_int(0)
+        self._check(self.L.fmd_rds_bytes_dev(self.h, C.byref(pb), C.byref(pc), C.byref(cap)))
+        nC = self.n_channels
+
+        class _B:
+            __cuda_array_interface__ = {"shape": (nC * cap.value,), "typestr": "|u1", "data": (pb.value, False), "version": 2}
+
+        class _C:
+            __cuda_array_interface__ = {"shape": (nC,), "typestr": "<i4", "data": (pc.value, False), "version": 2}
+        return torch.as_tensor(_B(), device="cuda").view(nC, cap.value), torch.as_tensor(_C(), device="cuda")
+
 
 def chan_design(fs_in: float, fs_out: float, taps_per_phase: int = 640):
     """Host-only prototype design of the wideband channeliser: (taps [T, L] float32, L, M).  Needs no GPU."""

@@ -568,6 +568,7 @@ int launch_deferred(fmd_handle h, bool behind_front) {
 // stall that queue for the length of the pilot loop each time).  fmd_set_output_lag: nothing is forced, the views are the newest queued ones.
 int outputs_wanted(fmd_handle h) {
     if (h->lag_outputs || !h->deferred.active) return FMD_OK;
+    HIP_TRY(h, hipSetDevice(h->device));        // (the *_dev getters reach this without one: launches follow)
     h->lazy_extract = false;
     return launch_deferred(h, false);
 }
@@ -1304,6 +1305,7 @@ std::vector<StatePart> state_parts(fmd_handle h) {
     }
     return v;
 }
+uint32_t state_version(fmd_handle h) { return h->ctx.fast ? 4u : 3u; }
 size_t state_floats(fmd_handle h) {
     size_t n = S_NUM_FIELDS;
     for (const StatePart& p : state_parts(h)) n += p.floats;
@@ -1322,7 +1324,7 @@ int fmd_get_state(fmd_handle h, int channel, void* blob, size_t cap_bytes) {
     int rc = sync_all(h);
     if (rc) return rc;
     const Dims& d = h->ctx.d;
-    StateHeader hd{kStateMagic, 3u, h->cfg.fs_baseband, d.m, (int32_t)S_NUM_FIELDS, d.tail_base, {0u, 0u}};
+    StateHeader hd{kStateMagic, state_version(h), h->cfg.fs_baseband, d.m, (int32_t)S_NUM_FIELDS, d.tail_base, {0u, 0u}};
     std::memcpy(blob, &hd, sizeof(hd));
     float* out = reinterpret_cast<float*>(static_cast<char*>(blob) + sizeof(hd));
     // SoA fields [field][C] -> one float per field
@@ -1354,9 +1356,14 @@ int fmd_set_state(fmd_handle h, int channel, const void* blob, size_t n_bytes) {
     StateHeader hd;
     if (n_bytes < sizeof(hd)) return fail(h, FMD_ERR_ARG, "state blob too short");
     std::memcpy(&hd, blob, sizeof(hd));
-    if (hd.magic != kStateMagic || hd.version != 3u || hd.fs_baseband != h->cfg.fs_baseband || hd.m != d.m || hd.n_fields != (int32_t)S_NUM_FIELDS ||
-        hd.tail_base != d.tail_base || n_bytes != fmd_state_size(h))
-        return fail(h, FMD_ERR_ARG, "state blob does not match this handle (rate %d vs %d, %zu vs %zu bytes)", hd.fs_baseband, h->cfg.fs_baseband, n_bytes, fmd_state_size(h));
+    if (hd.magic != kStateMagic) return fail(h, FMD_ERR_ARG, "not a state blob");
+    // exact mode: the layout has not changed since version 2; tolerance mode: version 4 (round 4: the pilot stage's decimated filter state and
+    // its last four column sums) — older tolerance-mode blobs lack what k_pll_sparse continues from
+    if (h->ctx.fast ? hd.version != 4u : (hd.version < 2u || hd.version > 4u))
+        return fail(h, FMD_ERR_ARG, "state blob version %u, this handle takes %s", hd.version, h->ctx.fast ? "4" : "2-4");
+    if (hd.fs_baseband != h->cfg.fs_baseband || hd.m != d.m || hd.n_fields != (int32_t)S_NUM_FIELDS || hd.tail_base != d.tail_base || n_bytes != fmd_state_size(h))
+        return fail(h, FMD_ERR_ARG, "state blob does not match this handle (rate %d vs %d, %d vs %d fields, %zu vs %zu bytes: the mode or the flags differ)", hd.fs_baseband,
+                    h->cfg.fs_baseband, hd.n_fields, (int)S_NUM_FIELDS, n_bytes, fmd_state_size(h));
     int rc = sync_all(h);
     if (rc) return rc;
     const float* in = reinterpret_cast<const float*>(static_cast<const char*>(blob) + sizeof(hd));

@@ -34,7 +34,8 @@ namespace fmd_host {
 
 class MultiGpuHost {
 public:
-    struct Views {                       // device views on the collector's GPU, valid until the next Collect()
+    struct Views {                       // device views on the block's collector GPU (`device`), valid until the next Collect()
+        int device = 0;                  // HIP ordinal the views live on: the root's, or with FMD_GATHER_ROTATE the device of rank (root + block) % n_ranks
         const void* audio = nullptr;     // [n_ranks * C_local][n_audio][2] float or int16
         const uint8_t* rds_bytes = nullptr;   // [n_ranks * C_local][rds_cap]
         const int* rds_counts = nullptr;      // [n_ranks * C_local]
@@ -57,7 +58,11 @@ public:
         for (size_t r = 0; r < devices.size(); r++) ranks[r].th = std::thread([this, r] { run((int)r); });
     }
     ~MultiGpuHost() {
-        for (Rank& k : ranks) { { std::lock_guard<std::mutex> lk(k.mu); k.stop = true; } k.cv.notify_all(); }
+        // blocks that were submitted and never collected are dropped: a rank thread waiting for the collector's buffers must not keep join() waiting
+        bool pending = false;
+        for (Rank& k : ranks) { std::lock_guard<std::mutex> lk(k.mu); k.stop = true; pending = pending || !k.q.empty() || !k.error.empty(); }
+        if (gather && (pending || collected < submitted)) fmd_gather_abort(gather);
+        for (Rank& k : ranks) k.cv.notify_all();
         for (Rank& k : ranks) if (k.th.joinable()) k.th.join();
         cleanup();
     }
@@ -70,10 +75,15 @@ public:
     void SubmitCF32(const std::vector<const float*>& d_iq) { push(reinterpret_cast<const uint8_t* const*>(d_iq.data()), false); }
 
     // The oldest block not yet collected, from every rank: blocks until it has arrived on the collector's GPU.
+    // A rank that failed (its error is what this throws) aborts the gather, so that this call does not wait for a block that never comes.
     Views Collect() {
         Views v;
-        if (fmd_gather_wait(gather, &v.audio, &v.rds_bytes, &v.rds_counts, &v.rds_cap) != FMD_OK) throw std::runtime_error(std::string("fmd_gather_wait: ") + fmd_gather_last_error(gather));
         rethrow();
+        const int rc = fmd_gather_wait(gather, &v.audio, &v.rds_bytes, &v.rds_counts, &v.rds_cap);
+        rethrow();
+        if (rc != FMD_OK) throw std::runtime_error(std::string("fmd_gather_wait: ") + fmd_gather_last_error(gather));
+        fmd_gather_collector(gather, collected, nullptr, &v.device);
+        collected++;
         return v;
     }
 
@@ -96,6 +106,7 @@ private:
 
     void push(const uint8_t* const* d_iq, bool u8) {
         rethrow();
+        submitted++;
         for (size_t r = 0; r < ranks.size(); r++) {
             { std::lock_guard<std::mutex> lk(ranks[r].mu); ranks[r].q.push_back(Task{d_iq[r], u8}); }
             ranks[r].cv.notify_one();
@@ -112,11 +123,15 @@ private:
                 if (k.q.empty()) return;
                 t = k.q.front(); k.q.pop_front();
             }
-            if (!k.error.empty()) continue;           // (keep draining: the caller sees the error at its next call)
+            { std::lock_guard<std::mutex> lk(k.mu); if (!k.error.empty() || k.stop) continue; }   // (keep draining: the caller sees the error at its next call)
             const int rc = t.u8 ? fmd_submit_u8_dev(handles[(size_t)r], t.iq, C, N, nullptr)
                                 : fmd_submit_cf32_dev(handles[(size_t)r], reinterpret_cast<const float*>(t.iq), C, N, nullptr);
-            if (rc != FMD_OK) { std::lock_guard<std::mutex> lk(k.mu); k.error = std::string("fmd_submit: ") + fmd_last_error(handles[(size_t)r]); continue; }
-            if (fmd_gather_submit(gather, r) != FMD_OK) { std::lock_guard<std::mutex> lk(k.mu); k.error = std::string("fmd_gather_submit: ") + fmd_gather_last_error(gather); }
+            // (a failed rank aborts the gather: the collector and the other ranks must not wait for its block)
+            if (rc != FMD_OK) { { std::lock_guard<std::mutex> lk(k.mu); k.error = std::string("fmd_submit: ") + fmd_last_error(handles[(size_t)r]); } fmd_gather_abort(gather); continue; }
+            if (fmd_gather_submit(gather, r) != FMD_OK) {
+                { std::lock_guard<std::mutex> lk(k.mu); if (!k.stop) k.error = std::string("fmd_gather_submit: ") + fmd_gather_last_error(gather); }
+                fmd_gather_abort(gather);
+            }
         }
     }
     void rethrow() {
@@ -131,6 +146,7 @@ private:
     int C, N;
     std::vector<fmd_handle> handles;
     fmd_gather gather = nullptr;
+    long submitted = 0, collected = 0;   // blocks (caller thread only)
     fmd_rates rates{};
     std::vector<Rank> ranks;
 };

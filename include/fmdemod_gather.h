@@ -30,6 +30,11 @@ enum { FMD_GATHER_F32 = 0, FMD_GATHER_PCM16 = 1 };
 /* shards on the collector's own device (its own included) also travel through ncclSend / ncclRecv to the self peer instead of a
  * device-to-device copy: exercises the RCCL path where only one GPU is present */
 #define FMD_GATHER_LOOPBACK_RCCL 1u
+/* The collector ROTATES: block k is gathered on rank (root + k) mod n_ranks.  At throughput-mode rates a single collector would need
+ * more than its seven xGMI links carry (83 GB/s asked of each ~77 GB/s link at N = 8) and has ONE PCIe link to hand
+ * the result to the host; rotating puts 1 / n_ranks of every rank's output on each link and spreads the hand-over over every GPU's PCIe
+ * link.  fmd_gather_wait then returns views on the device of that block's collector (fmd_gather_collector).  Needs one rank per device. */
+#define FMD_GATHER_ROTATE 2u
 
 typedef struct {
     int        n_ranks;
@@ -56,6 +61,13 @@ int fmd_gather_submit(fmd_gather g, int rank);
  *   audio  [n_ranks * C_local][n_audio][2]  float or int16 (cfg.format)
  *   bytes  [n_ranks * C_local][*cap]        counts [n_ranks * C_local]   (as fmd_rds_bytes_dev) */
 int fmd_gather_wait(fmd_gather g, const void** d_audio, const uint8_t** d_rds_bytes, const int** d_rds_counts, int* rds_cap);
+
+/* which rank collects block `block` (0 = the first since fmd_gather_create) and on which device fmd_gather_wait's views of it live */
+int fmd_gather_collector(fmd_gather g, long block, int* rank, int* device);
+/* Give up: every fmd_gather_submit / fmd_gather_wait that is waiting on the host (for a rank that will never submit, for views that will
+ * never be given back) returns FMD_ERR_STATE, now and from here on, and the communicators are aborted so that a receive whose sender is
+ * gone completes.  For a host whose rank thread failed (fm-radio_amd/host/multi_gpu_host.hpp).  Any thread. */
+int fmd_gather_abort(fmd_gather g);
 
 /* bytes one block moves into the collector from the other GPUs (for sizing against the 7 x ~153 GB/s of xGMI ingress) */
 size_t fmd_gather_remote_bytes_per_block(fmd_gather g);

@@ -1,6 +1,7 @@
 // Test driver of fm-radio_amd/host/multi_gpu_host.hpp + libfmdgather.so (include/fmdemod_gather.h).
 //
-//   multi_gpu_main <captures.u8> <n_ranks> <stations_per_rank> <block_size> <fs> <n_blocks> <f32|pcm16> <loopback 0|1> [fast]
+//   multi_gpu_main <captures.u8> <n_ranks> <stations_per_rank> <block_size> <fs> <n_blocks> <f32|pcm16> <loopback 0|1> [fast] [rotate]
+//       rotate: FMD_GATHER_ROTATE, block k is collected on rank k mod n_ranks (needs one GPU per rank)
 //       captures.u8 holds [n_ranks * stations_per_rank][n_blocks * block_size][2] u8; rank r gets device r when the box has that
 //       many GPUs, otherwise every rank shares device 0 (copy hand-over; with loopback = 1 and one rank the shard travels through
 //       ncclSend / ncclRecv to the self peer).
@@ -26,7 +27,9 @@ int main(int argc, char** argv) {
     if (argc < 9) { fprintf(stderr, "usage: multi_gpu_main <captures.u8> <n_ranks> <stations_per_rank> <block> <fs> <n_blocks> <f32|pcm16> <loopback> [fast]\n"); return 1; }
     const std::string path = argv[1];
     const int R = atoi(argv[2]), C = atoi(argv[3]), N = atoi(argv[4]), fs = atoi(argv[5]), nb = atoi(argv[6]);
-    const bool pcm = std::string(argv[7]) == "pcm16", loopback = atoi(argv[8]) != 0, fast = argc > 9 && std::string(argv[9]) == "fast";
+    const bool pcm = std::string(argv[7]) == "pcm16", loopback = atoi(argv[8]) != 0;
+    bool fast = false, rotate = false;
+    for (int i = 9; i < argc; i++) { fast = fast || std::string(argv[i]) == "fast"; rotate = rotate || std::string(argv[i]) == "rotate"; }
     FILE* fp = fopen(path.c_str(), "rb");
     if (!fp) return 2;
     std::vector<uint8_t> data((size_t)R * C * nb * N * 2);
@@ -50,13 +53,14 @@ int main(int argc, char** argv) {
                 HIPC(hipMemcpy(d_in[(size_t)r][(size_t)b], tmp.data(), blk, hipMemcpyHostToDevice));
             }
         }
-        const unsigned dflags = fast ? FMD_FLAG_FAST_MATH : 0u, gflags = loopback ? FMD_GATHER_LOOPBACK_RCCL : 0u;
+        const unsigned dflags = fast ? FMD_FLAG_FAST_MATH : 0u, gflags = (loopback ? FMD_GATHER_LOOPBACK_RCCL : 0u) | (rotate ? FMD_GATHER_ROTATE : 0u);
         const int fmt = pcm ? FMD_GATHER_PCM16 : FMD_GATHER_F32;
         long mismatches = 0;
         std::vector<Block> pass1((size_t)nb);
         size_t remote = 0;
         int n_audio = 0, cap = 0;
-        auto fetch = [&](const MultiGpuHost::Views& v, Block& out, int n_audio_, int root_dev) -> int {
+        auto fetch = [&](const MultiGpuHost::Views& v, Block& out, int n_audio_) -> int {
+            const int root_dev = v.device;
             const size_t ab = (size_t)R * C * n_audio_ * 2 * (pcm ? 2 : 4);
             out.audio.resize(ab); out.bytes.resize((size_t)R * C * v.rds_cap); out.counts.resize((size_t)R * C);
             HIPC(hipSetDevice(root_dev));
@@ -76,7 +80,7 @@ int main(int argc, char** argv) {
                 host.SubmitU8(ptrs);
                 const MultiGpuHost::Views v = host.Collect();
                 cap = v.rds_cap;
-                if (int rc = fetch(v, pass1[(size_t)b], n_audio, devs[0])) return rc;
+                if (int rc = fetch(v, pass1[(size_t)b], n_audio)) return rc;
                 for (int r = 0; r < R; r++) {      // what the rank's own handle holds for this block
                     if (fmd_get_audio(host.Handle(r), a.data()) != FMD_OK) return 6;
                     std::vector<uint8_t> by((size_t)C * cap); std::vector<int> cn((size_t)C);
@@ -109,7 +113,7 @@ int main(int argc, char** argv) {
                     submitted++;
                 }
                 const MultiGpuHost::Views v = host.Collect();
-                if (int rc = fetch(v, got, n_audio, devs[0])) return rc;
+                if (int rc = fetch(v, got, n_audio)) return rc;
                 const Block& w = pass1[(size_t)collected];
                 mismatches2 += got.audio != w.audio;
                 mismatches2 += got.counts != w.counts;
@@ -117,9 +121,9 @@ int main(int argc, char** argv) {
                 collected++;
             }
         }
-        printf("{\"ranks\": %d, \"devices\": %d, \"stations_per_rank\": %d, \"blocks\": %d, \"format\": \"%s\", \"loopback_rccl\": %s, \"lockstep_mismatches\": %ld, "
+        printf("{\"ranks\": %d, \"devices\": %d, \"stations_per_rank\": %d, \"blocks\": %d, \"format\": \"%s\", \"loopback_rccl\": %s, \"rotate\": %s, \"lockstep_mismatches\": %ld, "
                "\"pipelined_mismatches\": %ld, \"rds_bytes_gathered\": %ld, \"remote_bytes_per_block\": %zu}\n",
-               R, ndev, C, nb, pcm ? "pcm16" : "f32", loopback ? "true" : "false", mismatches, mismatches2, bytes_total, remote);
+               R, ndev, C, nb, pcm ? "pcm16" : "f32", loopback ? "true" : "false", rotate ? "true" : "false", mismatches, mismatches2, bytes_total, remote);
         return (mismatches == 0 && mismatches2 == 0 && bytes_total > 0) ? 0 : 3;
     } catch (const std::exception& e) {
         fprintf(stderr, "multi_gpu_main: %s\n", e.what());

@@ -83,6 +83,49 @@ def same_bits_once_in_lock(a: np.ndarray, b: np.ndarray, skip_bits: int, max_shi
     return False
 
 
+def soft_symbol_stats(sym_g, cnt_g, sym_o, cnt_o, lock_blocks):
+    """The tolerance mode's soft RDS symbols (OnRDSOut's payload, reference broadcast_fm_demod.cpp:327) against the oracle's, for one station.
+    The two symbol streams are aligned from the first block behind which both runs emit the same number of symbols in EVERY block
+    (at least `lock_blocks` in): before that a zero-crossing / clock-wrap decision of the synchroniser (bpsk_synchroniser.cpp:159-183) that
+    fell on the other side has the two clocks a sample apart.  Such decisions also tip in lock now and then — two builds of the REFERENCE
+    differ the same way, far more often (profiles/round4/reference_flip_evidence.json: 1.4 % of its symbols move by ~0.1-0.3 between its own
+    gcc preset and a scalar build; every bit stays) — so the statistics separate the symbols that moved by more than 1e-2 from the rest.
+    Returns None when fewer than 200 symbols can be compared."""
+    cnt_g = np.asarray(cnt_g).reshape(-1); cnt_o = np.asarray(cnt_o).reshape(-1)[:cnt_g.size]
+    agree_from = 0
+    for b in range(cnt_g.size - 1, -1, -1):
+        if cnt_g[b] != cnt_o[b]:
+            agree_from = b + 1
+            break
+    first = max(agree_from, lock_blocks)
+    if first >= cnt_g.size:
+        return None
+    lg, lo = int(cnt_g[:first].sum()), int(cnt_o[:first].sum())
+    m = int(cnt_g[first:].sum())
+    if m < 200:
+        return None
+    d = np.abs(np.asarray(sym_g, np.float64).reshape(-1)[lg:lg + m] - np.asarray(sym_o, np.float64).reshape(-1)[lo:lo + m])
+    big = d > 1e-2
+    return {"compared_from_block": int(first), "symbols": m, "median": float(np.median(d)), "p99": float(np.percentile(d, 99)),
+            "rms": float(np.sqrt(np.mean(d ** 2))), "moved_over_1e-2": int(big.sum()),
+            "rms_of_the_rest": float(np.sqrt(np.mean(d[~big] ** 2))) if (~big).any() else 0.0}
+
+
+def record_parity_metrics(name, metrics):
+    """Merge one test's measured parity figures into gpurun_out/parity_metrics.json (FMD_PARITY_METRICS overrides the path); the builder
+    copies it to profiles/roundN/parity_metrics.json.  Never fails a test."""
+    import json, os, pathlib
+    try:
+        root = pathlib.Path(__file__).resolve().parent.parent
+        path = pathlib.Path(os.environ.get("FMD_PARITY_METRICS", root / "gpurun_out" / "parity_metrics.json"))
+        path.parent.mkdir(parents=True, exist_ok=True)
+        doc = json.loads(path.read_text()) if path.exists() else {}
+        doc[name] = metrics
+        path.write_text(json.dumps(doc, indent=1, sort_keys=True))
+    except Exception as e:      # noqa: BLE001
+        print("parity metrics not recorded:", e)
+
+
 def lmr_audio_excess(g, o, c, nb):
     """The L-R and audio bar of the tolerance mode, block by block.  Every block must be within TOL_RMS (audio: 2 x, it carries
     2 (L+R +- L-R)) of the oracle — except for what ONE documented discontinuity of the reference explains: each of a block's
@@ -114,7 +157,7 @@ def _compare(pkg, caps, bs, fs, from_block=0, sym_skip_s=0.4, **kw):
     u8 = caps.dtype == np.uint8
     m = fs // 256_000
     n_fm_out = bs // m // 2
-    worst = {k: 0.0 for k in ("audio", "lpr", "lmr", "fm_out_iq", "pll_dt", "rds_sym", "lmr_audio_excess", "flips")}
+    worst = {k: 0.0 for k in ("audio", "lpr", "lmr", "fm_out_iq", "pll_dt", "rds_sym", "rds_sym_rest_rms", "lmr_audio_excess", "flips", "sym_stations", "sym_moved", "sym_total")}
     counts_equal = bytes_equal = 0
     bits_equal = True
     for c in range(caps.shape[0]):
@@ -134,14 +177,13 @@ def _compare(pkg, caps, bs, fs, from_block=0, sym_skip_s=0.4, **kw):
                 worst[k] = max(worst[k], rms(a - b))
         if np.array_equal(g["rds_count"][c], o["rds_count"]):
             counts_equal += 1
-            # symbol VALUES from lock on: while the synchroniser acquires, a last-bits difference can tip a clock-wrap
-            # decision and the two runs integrate their symbols over windows one sample apart for a few hundred symbols (same bits,
-            # values ~0.1 apart) before the loops have pulled them together again
-            first = max(from_block, int(np.ceil(sym_skip_s * fs / bs)))
-            lo = int(o["rds_count"][:first].sum())
-            # 99th percentile, not RMS: where a clock-wrap decision tips, one symbol integrates one sample more or fewer (its
-            # value moves by ~0.1, its sign — the bit — does not) and would dominate an RMS
-            worst["rds_sym"] = max(worst["rds_sym"], float(np.percentile(np.abs(g["rds_sym"][c][lo:].astype(np.float64) - o["rds_sym"][lo:]), 99)))
+        # symbol VALUES from lock on (soft_symbol_stats: aligned behind the last block in which the two symbol clocks disagreed)
+        st = soft_symbol_stats(g["rds_sym"][c], g["rds_count"][c], o["rds_sym"], o["rds_count"], max(from_block, int(np.ceil(sym_skip_s * fs / bs))))
+        if st is not None:
+            worst["sym_stations"] += 1
+            worst["rds_sym"] = max(worst["rds_sym"], st["median"])
+            worst["rds_sym_rest_rms"] = max(worst["rds_sym_rest_rms"], st["rms_of_the_rest"])
+            worst["sym_moved"] += st["moved_over_1e-2"]; worst["sym_total"] += st["symbols"]
         bytes_equal += int(np.array_equal(g["rds_bytes"][c], o["rds_bytes"]))
         bits_equal = bits_equal and same_bits_once_in_lock(g["rds_bytes"][c], o["rds_bytes"], skip_bits=5 * 76)
     return worst, counts_equal, bytes_equal, bits_equal
@@ -165,8 +207,13 @@ def test_fast_mode_is_within_the_north_star_tolerance_of_the_oracle(pkg, fs, u8)
     for k in ("lpr", "fm_out_iq"):
         assert worst[k] <= TOL_RMS, (k, worst[k])
     assert worst["lmr_audio_excess"] <= 1.0, worst     # L-R and audio: every block within 1e-4 (lmr_audio_excess: the one allowance and why)
-    assert worst["rds_sym"] <= 2e-3 * 0.7   # 99 % of the symbols within 2e-3 of their RMS (~0.7)
+    # soft symbols, in lock, on at least 4 of the 5 stations: every station's median difference within 1e-4, at most 2 % of the symbols moved by a
+    # tipped clock decision (the reference's own two builds: 1.4 %), the rest within 3e-4 RMS
+    assert worst["sym_stations"] >= 4, worst
+    assert worst["rds_sym"] <= 1e-4 and worst["rds_sym_rest_rms"] <= 3e-4, worst
+    assert worst["sym_moved"] <= 0.02 * worst["sym_total"], worst
     assert worst["pll_dt"] <= 5e-5          # turns
+    record_parity_metrics(f"fast_vs_oracle_12_blocks_fs{fs}_{'u8' if u8 else 'cf32'}", {k: float(v) for k, v in worst.items()})
 
 
 def test_fast_mode_first_decimator_small_tile_and_format_switch(pkg):

@@ -87,9 +87,17 @@ def test_tolerance_mode_whole_run_rms_64_stations_30_s(pkg):
           f"L-R worst {whole_lmr.max():.2e} median {np.median(whole_lmr):.2e}; flipped L-R phase estimates {flips} "
           f"({100.0 * flips / (n_st * n_blocks):.3f} % of station-blocks, {flips / (n_st * 30.0):.3f} per station-second); "
           f"station-blocks with audio error > 2e-4: {over} of {n_st * n_blocks}; worst block / allowance {excess:.2f}")
+    lmr_over = int(np.sum(np.sqrt(sq["lmr"]) > F.TOL_RMS))
+    F.record_parity_metrics("whole_run_64_stations_30_s", {
+        "audio_rms_worst": float(whole_audio.max()), "audio_rms_median": float(np.median(whole_audio)), "lmr_rms_worst": float(whole_lmr.max()),
+        "lmr_rms_median": float(np.median(whole_lmr)), "flipped_lmr_phase_estimates": flips, "flips_per_station_second": flips / (n_st * 30.0),
+        "station_blocks": n_st * n_blocks, "station_blocks_lmr_over_1e-4": lmr_over, "station_blocks_audio_over_2e-4": over,
+        "worst_block_lmr_rms": float(np.sqrt(sq["lmr"]).max()), "worst_block_over_allowance": excess})
     assert whole_audio.max() <= F.TOL_RMS, whole_audio.max()         # the north star's bar, every station, the whole run
     assert whole_lmr.max() <= F.TOL_RMS, whole_lmr.max()
     assert excess <= 1.0, excess                                       # and block by block (test_gpu_fast.lmr_audio_excess)
+    # blocks behind a flipped sign decision of the reference's L-R phase tracker (lmr_audio_excess): no more of them above 1e-4 than there are flips
+    assert lmr_over <= flips, (lmr_over, flips)
     for c in range(n_st):
         assert F.same_bits_once_in_lock(rds_g[c], rds_o[c], skip_bits=5 * 76), c
 
@@ -106,6 +114,8 @@ def test_tolerance_mode_whole_run_rms_at_the_reference_rate_16_stations_10_s(pkg
                  float(np.max(np.sqrt(sq["audio"]) / (2.0 * np.maximum(F.TOL_RMS, 0.7 * prev)))))
     print(f"16 stations x 10 s @1.024 MSa/s u8: whole-run RMS audio worst {whole_audio.max():.2e} median {np.median(whole_audio):.2e}, "
           f"L-R worst {whole_lmr.max():.2e}; worst block / allowance {excess:.2f}")
+    F.record_parity_metrics("whole_run_16_stations_10_s_1024k_u8", {"audio_rms_worst": float(whole_audio.max()), "audio_rms_median": float(np.median(whole_audio)),
+                                                                    "lmr_rms_worst": float(whole_lmr.max()), "worst_block_over_allowance": excess})
     assert whole_audio.max() <= F.TOL_RMS, whole_audio.max()
     assert whole_lmr.max() <= F.TOL_RMS, whole_lmr.max()
     assert excess <= 1.0, excess
@@ -161,20 +171,31 @@ def test_tolerance_mode_rds_stage_on_pipelined_wavefronts(pkg):
                 counts[c, b] = sc[c]
         dm.close()
         out[keep] = ([np.frombuffer(x, np.uint8) for x in rds], [np.concatenate(x) for x in syms], counts)
-    worst = 0.0
+    summary = {}
     for keep in (False, True):
         rds_g, sym_g, cnt_g = out[keep]
+        stats = []
         for c in range(n_st):
             assert F.same_bits_once_in_lock(rds_g[c], res[c][2], skip_bits=5 * 76), (keep, c)
             groups = decode_groups(rds_g[c])
             pi = (0x1234 + c) & 0xFFFF
             assert len(groups) >= 12 and sum(1 for w in groups if w[0] == pi) >= len(groups) - 1, (keep, c, len(groups))
-            o_cnt = np.asarray(res[c][4]).reshape(-1)[:n_blocks]
-            if np.array_equal(cnt_g[c], o_cnt):            # same symbol clock from the first block on: compare the soft symbols in lock
-                lo = int(o_cnt[:8].sum())
-                e = float(np.percentile(np.abs(sym_g[c][lo:].astype(np.float64) - np.asarray(res[c][3], np.float64).reshape(-1)[lo:lo + len(sym_g[c]) - lo]), 99))
-                worst = max(worst, e)
-    print(f"RDS soft symbols, 99th percentile of |difference| to the oracle in lock: {worst:.2e}")
-    assert worst <= 2e-3 * 0.7
+            st = F.soft_symbol_stats(sym_g[c], cnt_g[c], res[c][3], res[c][4], lock_blocks=8)
+            if st is not None:
+                stats.append(st)
+        # the soft symbols (OnRDSOut's payload) in lock: see soft_symbol_stats for what is compared and why a few symbols move
+        moved = sum(s["moved_over_1e-2"] for s in stats); total = sum(s["symbols"] for s in stats)
+        summary[f"keep_taps_{int(keep)}"] = {
+            "stations": n_st, "stations_compared": len(stats), "symbols_compared": total, "symbols_moved_over_1e-2": moved,
+            "median_of_station_medians": float(np.median([s["median"] for s in stats])), "worst_station_median": max(s["median"] for s in stats),
+            "worst_station_p99": max(s["p99"] for s in stats), "worst_station_rms": max(s["rms"] for s in stats),
+            "median_station_rms": float(np.median([s["rms"] for s in stats])), "worst_station_rms_of_the_rest": max(s["rms_of_the_rest"] for s in stats)}
+        print("RDS soft symbols against the oracle, in lock:", summary[f"keep_taps_{int(keep)}"])
+        assert len(stats) >= int(np.ceil(0.9 * n_st)), (keep, len(stats))                 # at least 90 % of the stations are compared
+        assert max(s["median"] for s in stats) <= 1e-4, keep                                 # every station: the typical symbol within 1e-4
+        assert float(np.median([s["rms"] for s in stats])) <= 2e-4, keep                     # the typical station: RMS within 2e-4 (moved symbols included)
+        assert moved <= 0.02 * total, (keep, moved, total)                                   # tipped clock decisions: the reference's own builds move 1.4 % of theirs
+        assert max(s["rms_of_the_rest"] for s in stats) <= 3e-4, keep                        # ... and the symbols that did not move, on every station
+    F.record_parity_metrics("rds_soft_symbols_24_stations_2_s", summary)
     same = sum(int(np.array_equal(out[False][0][c], out[True][0][c])) for c in range(n_st))
     assert same == n_st                                     # (the flag changes nothing the demodulator computes)

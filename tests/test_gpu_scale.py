@@ -191,26 +191,29 @@ def test_outputs_stay_valid_for_the_stated_number_of_blocks(pkg):
     dm.close()
 
 
-def test_release_outputs_holds_a_slot_for_a_slow_consumer(pkg):
+@pytest.mark.parametrize("fast,n_ch,submit", [(False, 512, False), (True, 512, False), (True, 2048, False), (True, 2048, True)])
+def test_release_outputs_holds_a_slot_for_a_slow_consumer(pkg, fast, n_ch, submit):
     """fmd_release_outputs: a consumer that is still reading block b's audio view when b + 6 is submitted (the call that
-    reuses the slot) is waited for on the device.  The consumer stream is stalled with a long spin kernel before its copy."""
+    reuses the slot) is waited for on the device.  The consumer stream is stalled with a long spin kernel before its copy.
+    Both modes; in the tolerance mode below and above the batch size of the deferred schedule, through fmd_process_* and fmd_submit_*:
+    a stalled extract stage must also hold back the pilot stage that writes the history in front of its slot's rows."""
     import torch
-    n_ch, bs, nb = 512, 16384, 16
+    bs, nb = 16384, 16
     base = _caps(4, nb * bs, 256_000.0, seed=6200)
     idx = torch.from_numpy(np.arange(n_ch) % 4).cuda()
     dbase = torch.from_numpy(base).cuda()
     blocks = [dbase[:, b * bs:(b + 1) * bs][idx].contiguous() for b in range(nb)]
-    ref = pkg.BatchDemod(n_ch, bs, 256_000, pipelined=False)
+    ref = pkg.BatchDemod(n_ch, bs, 256_000, pipelined=False, fast_math=fast)
     want = []
     for b in range(nb):
         ref.process(blocks[b])
         want.append(ref.audio().copy())
     ref.close()
-    dm = pkg.BatchDemod(n_ch, bs, 256_000)
+    dm = pkg.BatchDemod(n_ch, bs, 256_000, fast_math=fast)
     side = torch.cuda.Stream()
     kept = {}
     for b in range(nb):
-        dm.process(blocks[b])
+        (dm.submit if submit else dm.process)(blocks[b])
         if b in (2, 5):
             view = dm.audio_tensor()
             with torch.cuda.stream(side):

@@ -34,7 +34,8 @@ def test_gather_library_builds_and_exports_its_header(tmp_path):
     lib = C.CDLL(str(CSRC / "libfmdgather.so"))
     text = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "fmdemod_gather.h").read_text(), flags=re.S)
     names = sorted(set(re.findall(r"\b(fmd_gather_[a-z0-9_]+)\s*\(", text)))
-    assert names == ["fmd_gather_create", "fmd_gather_destroy", "fmd_gather_last_error", "fmd_gather_remote_bytes_per_block", "fmd_gather_submit", "fmd_gather_wait"]
+    assert names == ["fmd_gather_abort", "fmd_gather_collector", "fmd_gather_create", "fmd_gather_destroy", "fmd_gather_last_error", "fmd_gather_remote_bytes_per_block",
+                     "fmd_gather_submit", "fmd_gather_wait"]
     for n in names:
         assert hasattr(lib, n), n
     assert build_driver(tmp_path).exists()          # the host header and its driver: plain C++ against the two C ABIs
@@ -45,17 +46,23 @@ def test_gather_library_builds_and_exports_its_header(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks,fmt,loopback,fast", [(2, "pcm16", 0, True), (2, "f32", 0, False), (1, "pcm16", 1, True), (1, "f32", 1, False)])
-def test_multi_gpu_host_gathers_audio_and_rds_bytes(tmp_path, ranks, fmt, loopback, fast):
+@pytest.mark.parametrize("ranks,fmt,loopback,fast,rotate", [(2, "pcm16", 0, True, False), (2, "f32", 0, False, False), (1, "pcm16", 1, True, False), (1, "f32", 1, False, False),
+                                                             (2, "pcm16", 0, True, True)])
+def test_multi_gpu_host_gathers_audio_and_rds_bytes(tmp_path, ranks, fmt, loopback, fast, rotate):
+    """With as many GPUs as ranks the driver puts every rank on its own device (everything crosses RCCL); `rotate`: the collector moves
+    from GPU to GPU block by block (FMD_GATHER_ROTATE) — needs >= 2 devices, skipped on a one-GPU box."""
     import fmradio_loader
+    import torch
     fmradio_loader.load().load_library()
+    if rotate and torch.cuda.device_count() < ranks:
+        pytest.skip("FMD_GATHER_ROTATE needs one GPU per rank")
     exe = build_driver(tmp_path)
     c_local, bs, fs, nb = 6, 16384, 256_000, 10                   # 0.64 s: the Manchester decoder has handed on bytes by then
     base = np.stack([synth.to_u8(synth.fm_capture(nb * bs, fs=float(fs), seed=5600, channel=c)["iq"]) for c in range(4)])
     caps = base[np.arange(ranks * c_local) % 4]
     f = tmp_path / "caps.u8"
     np.ascontiguousarray(caps).tofile(f)
-    r = subprocess.run([str(exe), str(f), str(ranks), str(c_local), str(bs), str(fs), str(nb), fmt, str(loopback)] + (["fast"] if fast else []),
+    r = subprocess.run([str(exe), str(f), str(ranks), str(c_local), str(bs), str(fs), str(nb), fmt, str(loopback)] + (["fast"] if fast else []) + (["rotate"] if rotate else []),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
     info = json.loads(r.stdout.strip().splitlines()[-1])

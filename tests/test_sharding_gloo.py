@@ -86,33 +86,43 @@ def _worker(rank: int, world: int, port: int, tmp: str, mode: str, pcm16: bool):
     lo, hi = pkg.channel_range(total, world, rank)
     c_local = hi - lo
     n_audio = bs // 32
+    rds_cap = 16 if mode == "rotate" else 0          # (rotate: with the RDS byte buffers and counts, as bench.py gathers them)
     gather = pkg.AudioGather(dist, torch, c_local, n_audio, world, torch.device("cpu"), mode=mode,
-                             dtype=torch.int16 if pcm16 else torch.float32)
+                             dtype=torch.int16 if pcm16 else torch.float32, rds_cap=rds_cap)
     demods = [O.Demod(bs, 1_024_000) for _ in range(c_local)]
     caps = [synth.to_cf32(synth.fm_capture(bs * nb, seed=50, channel=lo + i)["iq"]) for i in range(c_local)]
     results = []
     for k in range(nb):
         local = np.stack([(d.process_cf32(c[k * bs:(k + 1) * bs]), d.get("audio"))[1].reshape(n_audio, 2) for d, c in zip(demods, caps)])
-        slot = gather.issue(k, torch.from_numpy(local))
+        # stand-in RDS payload: station (lo + i) of block k carries bytes k + 16 (lo + i) + j and the count 16
+        rb = torch.tensor([[(k + 16 * (lo + i) + j) & 255 for j in range(16)] for i in range(c_local)], dtype=torch.uint8) if rds_cap else None
+        rc = torch.full((c_local,), 16, dtype=torch.int32) if rds_cap else None
+        slot = gather.issue(k, torch.from_numpy(local), rb, rc)
         got = gather.result(slot)
-        assert (got is None) == (mode == "root" and rank != 0)     # only the collector holds the gathered block in root mode
+        collects = mode == "all" or rank == (k % world if mode == "rotate" else 0)
+        assert (got is None) == (not collects)     # only the block's collector holds it (root: rank 0; rotate: rank k mod world)
         if got is not None:
-            results.append(got.clone())
+            results.append((k, got.clone()))
+            if rds_cap:
+                gb, gc = gather.result_rds(slot)
+                assert gb.shape == (total, 16) and torch.equal(gc, torch.full((total,), 16, dtype=torch.int32))
+                assert all(int(gb[c, j]) == ((k + 16 * c + j) & 255) for c in range(total) for j in (0, 7, 15))
     gather.drain()
     if results:
-        np.save(os.path.join(tmp, f"gathered{rank}.npy"), torch.stack(results).numpy())
+        np.save(os.path.join(tmp, f"gathered{rank}.npy"), torch.stack([t for _, t in results]).numpy())
+        np.save(os.path.join(tmp, f"blocks{rank}.npy"), np.array([k for k, _ in results]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,pcm16", [("root", True), ("root", False), ("all", False)])
+@pytest.mark.parametrize("mode,pcm16", [("root", True), ("root", False), ("all", False), ("rotate", True)])
 def test_two_rank_gather_equals_single_process(tmp_path, mode, pcm16):
     import oraclelib as O
     import synth
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_worker, args=(2, port, str(tmp_path), mode, pcm16), nprocs=2, join=True)
     collectors = [0] if mode == "root" else [0, 1]
-    assert (tmp_path / "gathered1.npy").exists() == (mode == "all")
+    assert (tmp_path / "gathered1.npy").exists() == (mode != "root")
     total, bs, nb = 6, 4096, 3
     want = np.empty((nb, total, bs // 32, 2), np.float32)
     for c in range(total):
@@ -125,4 +135,6 @@ def test_two_rank_gather_equals_single_process(tmp_path, mode, pcm16):
         want = (want * (np.float32(32767.0) * np.float32(0.95))).astype(np.int32).astype(np.int16)
     for r in collectors:
         got = np.load(tmp_path / f"gathered{r}.npy")          # [blocks, channels, n_audio, 2]
-        assert got.dtype == want.dtype and np.array_equal(got.view(np.uint8), want.view(np.uint8)), (mode, pcm16, r)
+        blocks = np.load(tmp_path / f"blocks{r}.npy")         # which blocks this rank collected (rotate: k mod world == r)
+        assert list(blocks) == ([k for k in range(nb) if k % 2 == r] if mode == "rotate" else list(range(nb)))
+        assert got.dtype == want.dtype and np.array_equal(got.view(np.uint8), want[blocks].view(np.uint8)), (mode, pcm16, r)
