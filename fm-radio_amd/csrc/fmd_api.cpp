@@ -484,7 +484,7 @@ int zero_history(fmd_handle h, hipStream_t s) {
     h->pll_seq = 0;
     h->n_blocks = 0;
     h->warm_left = h->ctx.fast ? (int)((8192 + d.n_fm_out - 1) / d.n_fm_out) : 0;     // kPllWarmSamples of every station's life
-    if (h->ctx.fast && std::getenv("FMD_DEBUG_PLL_DENSE")) h->warm_left = 1 << 30;   // development knob: k_pll_span for every block (A/B against round 3's pilot stage)
+    if (h->ctx.fast && dev_env("FMD_DEBUG_PLL_DENSE")) h->warm_left = 1 << 30;   // development knob: k_pll_span for every block (A/B against round 3's pilot stage)
     h->deferred.active = false; h->last_x_event = nullptr; h->last_p_event = nullptr;
     for (hipEvent_t& e : h->x_done) e = nullptr;
     h->ev_consumed = nullptr;
@@ -878,7 +878,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     {
         // experiment hook: FMD_STREAM_PRIORITIES="f,b,x,r" — priorities of the front / PLL / extract / RDS streams (0 = default, negative = higher)
         int prio[6] = {0, 0, 0, 0, 0, 0};       // sF, sD, sA, sB, sX, sR
-        if (const char* e = std::getenv("FMD_STREAM_PRIORITIES")) { int f = 0, b = 0, x = 0, r = 0; if (std::sscanf(e, "%d,%d,%d,%d", &f, &b, &x, &r) == 4) { prio[0] = f; prio[1] = f; prio[3] = b; prio[4] = x; prio[5] = r; } }
+        if (const char* e = dev_env("FMD_STREAM_PRIORITIES")) { int f = 0, b = 0, x = 0, r = 0; if (std::sscanf(e, "%d,%d,%d,%d", &f, &b, &x, &r) == 4) { prio[0] = f; prio[1] = f; prio[3] = b; prio[4] = x; prio[5] = r; } }
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         int i = 0;
@@ -887,7 +887,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
             hipError_t e = p ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, p) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
             if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e)));
         }
-        if (std::getenv("FMD_STREAM_PRIORITIES")) std::fprintf(stderr, "fmdemod: stream priority range [%d (least) .. %d (greatest)]\n", least, greatest);
+        if (dev_env("FMD_STREAM_PRIORITIES")) std::fprintf(stderr, "fmdemod: stream priority range [%d (least) .. %d (greatest)]\n", least, greatest);
     }
     {
         std::vector<hipEvent_t*> evs = {&h->ev_in};
@@ -906,7 +906,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     // within the time-parallel kernel: 16 lanes per channel while a lone wavefront's latency is what matters (same-box A/B:
     // 8 % faster at 2560 channels, 6 % at 3072), 8 lanes per channel (30 % fewer VALU instructions) beyond (2 % faster at 4096)
     h->ctx.pll_k16_max_channels = (cfg->flags & FMD_FLAG_PLL_K8) ? 0 : 3584;
-    if (const char* e = getenv("FMD_DEBUG_PLL_K16_MAX")) h->ctx.pll_k16_max_channels = atoi(e);   // development knob
+    if (const char* e = dev_env("FMD_DEBUG_PLL_K16_MAX")) h->ctx.pll_k16_max_channels = atoi(e);   // development knob
     d.n_fm_in = d.N / m; d.n_fm_out = d.n_fm_in / 2; d.n_rds = d.n_fm_out / 8; d.n_audio = d.n_fm_out / 4;
     d.n_est = (d.n_audio + 9) / 10;
     d.tail_base = front_tail_len(m, (cfg->flags & FMD_FLAG_FAST_MATH) != 0);
@@ -914,14 +914,14 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     h->ctx.bytes_cap = h->bytes_cap;
     h->ctx.keep_taps = (cfg->flags & FMD_FLAG_KEEP_TAPS) ? 1 : 0;
     h->ctx.fast = (cfg->flags & FMD_FLAG_FAST_MATH) ? 1 : 0;
-    if (const char* e = getenv("FMD_DEBUG_SKIP_STAGES")) h->debug_skip = (unsigned)strtoul(e, nullptr, 0);   // development knob
+    if (const char* e = dev_env("FMD_DEBUG_SKIP_STAGES")) h->debug_skip = (unsigned)strtoul(e, nullptr, 0);   // development knob
     // fmd_submit_* puts a block's extract stage off until the next block's front end is queued (launch_deferred) from 1024 stations'
     // worth of 256 kSa/s blocks on (same-box A/B with the three-wavefront RDS stage: +-0 at 1024 stations, +1 % at 1536, +6 % at 2048,
     // +10 % at 2560, +6-7 % from 3072 on; smaller batches are pure stage latency and keep every stage on a queue of its own)
-    h->lazy_capable = h->pipelined && h->ctx.fast && (size_t)d.C * d.n_fm_out >= (size_t)1024 * 8192 && !std::getenv("FMD_NO_LAZY_EXTRACT");
+    h->lazy_capable = h->pipelined && h->ctx.fast && (size_t)d.C * d.n_fm_out >= (size_t)1024 * 8192 && !dev_env("FMD_NO_LAZY_EXTRACT");
     h->lazy_extract = h->lazy_capable;
-    h->no_fused_pll = std::getenv("FMD_NO_FUSED_PLL") != nullptr;
-    h->pll_eager = std::getenv("FMD_PLL_EAGER") != nullptr;
+    h->no_fused_pll = dev_env("FMD_NO_FUSED_PLL") != nullptr;
+    h->pll_eager = dev_env("FMD_PLL_EAGER") != nullptr;
 
     fmd_controls def;
     fmd_default_controls(&def);

@@ -4,10 +4,19 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "fmdemod.h"
 
 namespace fmd {
+
+// Development switches (A/B timing, bounding experiments: tools/) are read from the environment only in builds with -DFMD_DEV_HOOKS
+// (`make -C fm-radio_amd/csrc dev`); the shipping library reads GPU_MAX_HW_QUEUES and FMD_QUIET and nothing else.
+#ifdef FMD_DEV_HOOKS
+inline const char* dev_env(const char* name) { return std::getenv(name); }
+#else
+inline const char* dev_env(const char*) { return nullptr; }
+#endif
 
 // Coefficients shared by every channel, passed to kernels by value (kernarg -> scalar loads).
 struct FrontTaps {

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
 // schedule (fmd_api.cpp) the front end's queue then carries front(k + 1) + pilot(k), extract(k), front(k + 2) + pilot(k + 1), ... and no
 // kernel on it waits for another queue; the pilot stage's half-thousand wavefronts start first and finish inside the front end's HBM-bound time.
 template <typename InT, int TT, int WU, bool FUSED = false>
-__global__ __launch_bounds__(256, 5) void k_front_mfma(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
+__global__ __launch_bounds__(256, FUSED ? 6 : 5) void k_front_mfma(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
                                                     float2* __restrict__ tail_out, float* __restrict__ fo_pl, float fm_gain,
                                                     const float* __restrict__ deemph, const uint4* __restrict__ tab, float4* __restrict__ pv_pl,
                                                     const uint4* __restrict__ pv_img, const PllSparseTab* __restrict__ sp, PllFusedArgs pf) {
@@ -2676,7 +2676,7 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
     }
     if constexpr (TT == 512) {
         if constexpr (FAST && sizeof(InT) == 2) {   // u8 captures: 2048-output tiles (4 KB of input per 1024-output workgroup leaves too few bytes in flight per CU)
-            static const bool t1024 = std::getenv("FMD_FRONT_U8_T1024") != nullptr;      // (A/B hook)
+            static const bool t1024 = dev_env("FMD_FRONT_U8_T1024") != nullptr;      // (A/B hook)
             if (d.n_fm_out % 2048 == 0 && !ctx.deemph_in_tile && !t1024) return launch_front<InT, 2048, FAST>(ctx, r, d_iq, s, pll);
         }
         if (d.n_fm_out % 1024 == 0) return launch_front<InT, 1024, FAST>(ctx, r, d_iq, s, pll);
@@ -2716,7 +2716,7 @@ template <int M, typename InT>
 static hipError_t launch_predecim(const LaunchCtx& ctx, SlotRef r, const InT* d_iq, hipStream_t s) {
     const Dims& d = ctx.d;
     using G = PredecimGeom<M>;
-    static const bool valu_form = std::getenv("FMD_PREDECIM_VALU") != nullptr;      // (A/B hook: the tolerance mode's first decimator on the VALU)
+    static const bool valu_form = dev_env("FMD_PREDECIM_VALU") != nullptr;      // (A/B hook: the tolerance mode's first decimator on the VALU)
     // tile: 2048 input samples of cf32 (16 KB; the kernel then sits on its HBM floor whatever the tile), 8192 of u8 (16 KB as well:
     // with 4 KB per workgroup too few bytes are in flight per CU); blocks that are no multiple of it: 256 outputs per workgroup
     constexpr int TPM = (sizeof(InT) == 2 ? 8192 : 2048) / M;
@@ -2873,7 +2873,7 @@ hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Buffers& b = ctx.b;
     if (ctx.fast) {
         const bool partials = d.n_audio % 256 == 0;       // k_extract_mfma ran and left the block's power as 2 partial sums per tile
-        static const bool two_waves = std::getenv("FMD_RDS_TWO_WAVES") != nullptr;      // (A/B hook: the two-wavefront form)
+        static const bool two_waves = dev_env("FMD_RDS_TWO_WAVES") != nullptr;      // (A/B hook: the two-wavefront form)
         if (partials && !two_waves) {      // the loop split over mixer, clock and dump wavefronts (fmd_kernels_fast.inc)
             FMD_LAUNCH(r, true, true, k_rds_sync3, dim3(serial_waves(d)), dim3(4 * kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
                        b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps,
