@@ -57,12 +57,12 @@ def algorithmic_bytes_per_sample(fs: int, u8: bool) -> float:
     return in_b + audio + syms
 
 
-SIDE_QUEUE_KERNELS = ("k_rds_sync", "k_pll_span", "k_lmr_phase")
+SIDE_QUEUE_KERNELS = ("k_rds_sync", "k_pll_sparse", "k_pll_span", "k_lmr_phase")
 
 
 def lookup_traffic(kernel: str, C: int, fs: int, block: int, u8: bool, fast: bool):
     """HBM bytes per launch of `kernel` in this configuration from the committed PMC table (profiles/hbm_traffic.json: rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE passes, tools/r3_collect.sh + tools/r3_digest.py), or None if the configuration was not profiled."""
+    FETCH_SIZE / WRITE_SIZE passes, tools/collect_round.sh + tools/digest_round.py), or None if the configuration was not profiled."""
     tf = ROOT / "profiles" / "hbm_traffic.json"
     try:
         return json.loads(tf.read_text()).get(f"{kernel}|C={C}|fs={fs}|block={block}|{'u8' if u8 else 'cf32'}|{'fast' if fast else 'exact'}")
@@ -72,7 +72,7 @@ def lookup_traffic(kernel: str, C: int, fs: int, block: int, u8: bool, fast: boo
 
 def dominant_kernel(avg_ms: dict, ms_per_step: float, fast: bool):
     """The kernel `roofline` is quoted on: the longest average launch.  Tolerance mode: its two throughput kernels (k_front_mfma,
-    k_extract_mfma) take turns on one queue while the serial stages (k_pll_span: one wavefront per SIMD; k_rds_sync: 64 wavefronts) run
+    k_extract_mfma) take turns on one queue while the serial stages (k_rds_sync: 64 workgroups; the pilot stage rides in the front end's launch) run
     beside them on queues of their own with launches that overlap consecutive blocks'; such a side-queue kernel is the dominant one only
     when its launch is what the step waits for (>= 90 % of the step: small batches) — otherwise the longest throughput kernel is, and
     `whole_step_frac` (algorithmic bytes over the whole step) is the figure that says how far the step is from the HBM roof."""
@@ -618,7 +618,7 @@ def main() -> None:
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "traffic_source": None if traffic is None else "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                      "configuration (tools/collect_profiles.sh), committed; not re-measured by this run",
+                                      "configuration (tools/collect_round.sh), committed; not re-measured by this run",
                     "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_launch": algo_bytes,
                     "whole_step_frac": (bps * C * block * K / el / 1e9) / HBM_PEAK_GBS if world == 1 else None,

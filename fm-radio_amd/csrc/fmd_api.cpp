@@ -28,7 +28,7 @@ using namespace fmd;
 enum Stage { ST_FRONT = 0, ST_DEEMPH, ST_POWER, ST_PLL, ST_EXTRACT, ST_RDS, ST_PREDECIM, ST_COUNT };
 static const char* const kStageName[ST_COUNT] = {"k_front", "k_deemphasis+k_hilbert", "k_pilot_power", "k_pilot_pll", "k_extract", "k_rds_sync", "k_predecim"};
 // ... and of the tolerance mode's kernels, as they appear in rocprofv3 kernel traces
-static const char* const kStageNameFast[ST_COUNT] = {"k_front_mfma", "k_deemphasis", "k_pilot_power", "k_pll_span", "k_extract_mfma", "k_rds_sync", "k_predecim_mfma"};
+static const char* const kStageNameFast[ST_COUNT] = {"k_front_mfma", "k_deemphasis", "k_pilot_power", "k_pll_sparse", "k_extract_mfma", "k_rds_sync", "k_predecim_mfma"};
 
 struct ProfiledBlock { hipEvent_t t0[ST_COUNT], t1[ST_COUNT]; bool used[ST_COUNT]; };
 

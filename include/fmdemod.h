@@ -73,14 +73,21 @@ typedef struct {
  * block from 1 % unlocked stations on): a band scan, where most channels are empty, wants the tolerance mode.
  * With the flag the chain keeps the reference's signal flow and state variables but uses cheaper arithmetic: minimax arctangent,
  * hardware sine/cosine, the FIRs as bf16 x 3 products on the matrix cores (fp32 accumulation, ~1e-6 relative), the pilot peak filter
- * on the real rail as a parallel scan, the pilot PLL advanced 128 samples at a time by weight vectors (the NCO frequency held over
- * the span, the feedback inside it solved exactly on the host), the optional de-emphasis inside the front-end tile (time constants
- * up to ~79 us).  Parity, as tests/test_gpu_fast.py and tests/test_gpu_long.py assert it: every block of audio / L-R within 1e-4 RMS
- * of the oracle except where a sign decision of the reference's L-R phase tracker falls on the other side (one estimate in ~300
- * blocks; bounded by the measured offset difference; two builds of the reference differ the same way,
- * profiles/round3/reference_flip_evidence.json), whole-run RMS 1e-5 on 64 stations x 30 s, RDS bits identical once the synchroniser
- * is in lock.  The cost of a block does not depend on the signals: there is no data-dependent path (a station's first 64 ms
- * after a reset take the Hilbert rail through a second peak filter).  The FMD_FLAG_PLL_* selectors are ignored. */
+ * as the complex one-pole low-pass of the down-mixed signal that it is, decimated by 16, the pilot PLL advanced 128 samples at a time
+ * from the phase at 8 points of the span (the NCO frequency held over the span, the feedback inside it solved exactly on the host),
+ * the optional de-emphasis inside the front-end tile (time constants up to ~79 us).  Parity, as tests/test_gpu_fast.py and
+ * tests/test_gpu_long.py assert it and profiles/round4/parity_metrics.json records it:
+ *   audio, L-R   every block within 1e-4 RMS of the oracle except right behind a sign decision of the reference's L-R phase tracker that
+ *                falls on the other side (the allowance is the measured offset difference).  64 stations x 30 s: no block above 1e-4 at all
+ *                (worst 6.8e-5) with 90 such decisions; whole-run RMS 1.3e-5.  Two builds of the reference itself: 0.008-0.042 decisions per
+ *                station-second (here 0.047), worst block 5.8e-5 (profiles/round4/reference_flip_evidence.json).
+ *   RDS bits     identical once the synchroniser is in lock (fmd_get_rds_bytes), every station.
+ *   RDS symbols  (fmd_get_rds_symbols, the reference's OnRDSOut payload) the typical symbol within 1.2e-5 and the typical station within
+ *                2.6e-5 RMS of the oracle; 0.2 % of the symbols move by 0.1-0.3 where a zero-crossing / clock-wrap decision of the
+ *                synchroniser tips (the sign, i.e. the bit, stays) - the reference's own two builds move 1.4 % of theirs.  A consumer that
+ *                needs the soft values inside 1e-4 on EVERY symbol wants the exact mode.
+ * The cost of a block does not depend on the signals: there is no data-dependent path (a station's first 64 ms after a reset also run
+ * round 3's per-sample pilot kernel, for the reference's start-up transient).  The FMD_FLAG_PLL_* selectors are ignored. */
 #define FMD_FLAG_FAST_MATH        64u
 
 /* reference Broadcast_FM_Demod_Controls (broadcast_fm_demod.h:64-89); defaults in fmd_default_controls */

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Development tool (GPU box): rocprofv3 kernel durations of single stages of the tolerance mode run on their own (FMD_DEBUG_SKIP_STAGES).
+# Development tool (GPU box; needs the development build of the library: make -C fm-radio_amd/csrc dev): rocprofv3 kernel durations of single stages of the tolerance mode run on their own (FMD_DEBUG_SKIP_STAGES).
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 export GPU_MAX_HW_QUEUES=8

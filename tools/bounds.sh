@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-3 bounding experiment (GPU box): the tolerance-mode step with single stages not launched (FMD_DEBUG_SKIP_STAGES,
+# Bounding experiment (GPU box; needs the development build of the library: make -C fm-radio_amd/csrc dev): the tolerance-mode step with single stages not launched (FMD_DEBUG_SKIP_STAGES,
 # outputs are garbage) — what each serial stage costs the pipelined step.  Stage bits: 8 = PLL, 16 = extract, 32 = RDS.
 export GPU_MAX_HW_QUEUES=8
-O=gpurun_out/r3_bounds; mkdir -p $O; rm -f $O/table.jsonl
+O=gpurun_out/bounds; mkdir -p $O; rm -f $O/table.jsonl
 run() { FMD_DEBUG_SKIP_STAGES=$2 python bench.py $3 --no-kernel-times --no-cpu-baseline --no-other-mode --no-configs --no-host-fed 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps({'cfg': sys.argv[1], 'value': round(d['value']), 'ms': round(d['ms_per_step'],4)}))" "$1" | tee -a $O/table.jsonl; }
 for rep in 1 2; do
 run "all" 0 ""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Reduce the outputs of tools/r3_collect.sh to per-kernel averages (one JSON), on the GPU box; `tools/r3_digest.py --install`
-in the build container then copies the digests into profiles/round3/ and refreshes profiles/hbm_traffic.json /
+"""Reduce the outputs of tools/collect_round.sh to per-kernel averages (one JSON), on the GPU box; `tools/digest_round.py --install [round]`
+in the build container then copies the digests into profiles/round<N>/ and refreshes profiles/hbm_traffic.json /
 profiles/valu_instructions.json (the committed tables bench.py looks `traffic` and the VALU issue fraction up in)."""
 import collections
 import csv
@@ -28,7 +28,7 @@ def pmc_dir(d: pathlib.Path) -> dict:
             for c, v in cs.items():
                 agg[k][c].append(v)
         for k, cs in agg.items():
-            if k == "k_reset":
+            if k == "k_reset" or max(len(v) for v in cs.values()) < 3:     # (k_pll_span: a station's first 8192 samples only, not part of the steady chain)
                 continue
             out.setdefault(k, {}).update({c: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for c, v in cs.items()})   # steady-state half of the launches
     return out
@@ -64,13 +64,13 @@ def reduce(o: pathlib.Path, sfx: str) -> None:
         "trace_digest": json.loads((o / "trace_digest.json").read_text() or "{}")}, indent=1))
 
 
-def install() -> None:
-    dst = ROOT / "profiles" / "round3"
+def install(rnd: str = "4") -> None:
+    dst = ROOT / "profiles" / f"round{rnd}"
     dst.mkdir(parents=True, exist_ok=True)
     traffic_tab = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text())
     valu_tab = json.loads((ROOT / "profiles" / "valu_instructions.json").read_text())
     for sfx in ("", "_exact", "_1024k", "_1024k_u8"):
-        f = ROOT / "gpurun_out" / f"r3prof{sfx}" / "digest.json"
+        f = ROOT / "gpurun_out" / f"r{rnd}prof{sfx}" / "digest.json"
         if not f.exists():
             continue
         d = json.loads(f.read_text())
@@ -99,7 +99,7 @@ def install() -> None:
             valu_total += cs.get("SQ_INSTS_VALU", 0.0)
         algo = bench["roofline"]["algorithmic_bytes_per_launch"]
         (dst / f"hbm_traffic_pmc{sfx}.md").write_text(
-            "# HBM traffic per launch, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/r3_collect.sh)\n\n" + cfg["workload"] + f", mode: {mode}.\n"
+            "# HBM traffic per launch, rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/collect_round.sh)\n\n" + cfg["workload"] + f", mode: {mode}.\n"
             "Counter unit KiB; reads doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE = 1/2 of a 16 B/lane coalesced stream). Averages over the steady-state launches of the un-pipelined run.\n\n"
             "| kernel | FETCH_SIZE (KiB, raw) | WRITE_SIZE (KiB) | corrected HBM bytes / launch |\n|---|---|---|---|\n" + "\n".join(lines) +
             f"\n\nSum over the chain: {total / 1e6:.0f} MB per block (algorithmic: {algo / 1e6:.1f} MB, ratio {total / algo:.2f}).\n")
@@ -108,7 +108,7 @@ def install() -> None:
                 "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA",
                 "SQ_ACTIVE_INST_VMEM", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE")
         (dst / f"sq_counters_pmc{sfx}.json").write_text(json.dumps({
-            "what": "per-kernel averages per launch of the un-pipelined bench (tools/r3_collect.sh: one rocprofv3 --pmc run per counter set); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* "
+            "what": "per-kernel averages per launch of the un-pipelined bench (tools/collect_round.sh: one rocprofv3 --pmc run per counter set); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* "
                     "count quad-cycles summed over wavefronts, SQ_VALU_MFMA_BUSY_CYCLES cycles, SQ_INSTS_* wave-instructions (MI355X_MICROARCH.md)",
             "workload": cfg["workload"], "mode": mode, "valu_total_per_block": valu_total,
             "kernels": {k: {c: v for c, v in cs.items() if c in keep} for k, cs in ctr.items()}}, indent=1) + "\n")
@@ -119,6 +119,6 @@ def install() -> None:
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--install":
-        install()
+        install(sys.argv[2] if len(sys.argv) > 2 else "4")
     else:
         reduce(pathlib.Path(sys.argv[1]), sys.argv[2] if len(sys.argv) > 2 else "")

@@ -1,26 +1,34 @@
 #!/bin/bash
-# Development tool (GPU box): the configurations of DESIGN.md's measurement table, one JSON line each (gpurun_out/table.jsonl).
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out; O=gpurun_out/table.jsonl; : > $O
-run() { echo "# $*" >> $O; python3 bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 >> $O; }
-run
-run --no-kernel-times
-run --no-pipeline
-run --u8
-run --channels 1024
-run --channels 2048
-run --fs 1024000
-run --fs 1024000 --u8
-run --fs 2048000 --channels 2048
-run --channels 8192
-run --channels 16384 --steps 40
-run --channels 65536 --steps 10 --preroll 8
-run --channels 1 --fs 2048000
-run --wideband
-python3 - <<PY
-import json
-lines = open("$O").read().splitlines()
-for i in range(0, len(lines), 2):
-    d = json.loads(lines[i + 1])
-    r = d.get("roofline") or {}
-    print("%-45s %9.0f MSa/s %7.3f ms  frac %s  %s" % (lines[i], d["value"], d["ms_per_step"], ("%.3f" % r["frac"]) if r else "-", {k: round(v, 2) for k, v in (r.get("kernels_ms_per_step") or {}).items()}))
-PY
+# Measurement table: one line per configuration, on one box.  Output: gpurun_out/table/.
+export GPU_MAX_HW_QUEUES=8
+O=gpurun_out/table; mkdir -p $O
+run() { python bench.py $2 --no-cpu-baseline --no-other-mode --no-configs --no-host-fed 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps({'cfg': sys.argv[1], 'value': round(d['value']), 'ms': round(d['ms_per_step'],4), 'kernels': {k: round(v,3) for k,v in d['roofline']['kernels_ms_per_step'].items()}, 'spec': d.get('speculation', {}).get('pll', {}).get('samples_per_span')}))" "$1" | tee -a $O/table.jsonl; }
+rm -f $O/table.jsonl
+python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.json; echo
+run "fast 4096" ""
+run "exact 4096" "--exact"
+run "fast u8" "--u8"
+run "exact u8" "--exact --u8"
+for p in 0.01 0.1 1.0; do run "fast unlocked $p" "--unlocked-frac $p"; done
+for p in 0.01 0.1 1.0; do run "exact unlocked $p" "--exact --unlocked-frac $p --steps 20"; done
+run "fast unlocked 0.1 zero" "--unlocked-frac 0.1 --unlocked-kind zero"
+run "fast unlocked 0.25 detuned" "--unlocked-frac 0.25 --unlocked-kind detuned"
+run "fast unlocked 0.25 mix" "--unlocked-frac 0.25 --unlocked-kind mix"
+run "fast deemph 50" "--deemphasis 50"
+run "fast deemph 75" "--deemphasis 75"
+run "fast deemph 150 (serial stage)" "--deemphasis 150"
+run "exact deemph 50" "--exact --deemphasis 50"
+run "fast 1024" "--channels 1024"
+run "fast 2048" "--channels 2048"
+run "fast 8192" "--channels 8192"
+run "fast 16384" "--channels 16384 --steps 40"
+run "exact 8192" "--exact --channels 8192"
+run "exact 16384" "--exact --channels 16384 --steps 40"
+run "fast 1.024M" "--fs 1024000"
+run "fast 1.024M u8" "--fs 1024000 --u8"
+run "exact 1.024M" "--exact --fs 1024000"
+run "exact 1.024M u8" "--exact --fs 1024000 --u8"
+run "fast 2.048M 2048ch" "--fs 2048000 --channels 2048"
+run "fast no-pipeline" "--no-pipeline"
+run "exact no-pipeline" "--exact --no-pipeline"
+python bench.py --wideband 2>/dev/null | tail -1 | cut -c1-400
