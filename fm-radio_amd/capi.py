@@ -156,6 +156,7 @@ def load_library():
     L.fmd_get_spec_stats.argtypes = [H, C.c_void_p, C.c_int]
     L.fmd_design_pll_span.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.fmd_profile_enable.argtypes = [H, C.c_int]
+    L.fmd_debug_split_front.argtypes = [H, C.c_int]
     L.fmd_profile_read.argtypes = [H, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]
     L.fmd_chan_design.argtypes = [C.c_double, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.fmd_chan_create.argtypes = [C.POINTER(ChanConfig), C.POINTER(C.c_void_p)]

@@ -63,11 +63,12 @@ struct fmd_handle_s {
     bool lazy_extract = false, lazy_capable = false;
     bool no_fused_pll = false;               // development A/B: the deferred pilot stage as a launch of its own
     bool pll_eager = false;                  // development A/B: the pilot stage queued at submission on its own queue (round 3's arrangement)
+    bool front_with_predecim = true;         // 1.024 / 2.048 MSa/s, deferred schedule: the front end follows the first decimator on ITS queue
     // pll_pending: the block's pilot stage has not been queued either — it rides in the next block's front-end launch (k_front_mfma<FUSED>) or,
     // where that is not possible (a start-up block, the getters' per-sample streams, a flush), goes in front of the extract stage on its own;
     // front_dep: the event behind the stage that made the block's fm_out; pll_dep / pll_stream: where the pilot stage was queued (NULL event: same
     // queue as the front end, nothing to wait for)
-    struct Deferred { bool active = false, pll_pending = false, front_cross = false; SlotRef ref{}; hipEvent_t pll_dep = nullptr, front_dep = nullptr; hipStream_t pll_stream = nullptr;
+    struct Deferred { bool active = false, pll_pending = false, front_cross = false, deemph = false; SlotRef ref{}; hipEvent_t pll_dep = nullptr, front_dep = nullptr; hipStream_t pll_stream = nullptr, front_stream = nullptr;
                       int slot = 0; long block = 0; ProfiledBlock* pm = nullptr; bool prof_p = false, prof_x = false, prof_r = false; } deferred;
     hipStream_t last_x_stream = nullptr;     // where the newest extract stage was queued, and the event behind it: consecutive blocks'
     hipEvent_t last_x_event = nullptr;       // extract stages are ordered (L-R phase estimate), whichever of the two streams they take
@@ -346,7 +347,7 @@ void design_pll_span(const fmd_coeffs& k, PllSpanTab* t) {
 }
 
 // Tables of k_pll_sparse (fmd_kernels.h PllSparseTab; float64 model: tools/proto/sparse_pll.py design_sparse)
-void design_pll_sparse(const fmd_coeffs& k, PllSparseTab* t, std::vector<uint16_t>* pv_img = nullptr) {
+void design_pll_sparse(const fmd_coeffs& k, PllSparseTab* t) {
     using cd = std::complex<double>;
     constexpr int L = kSpan, D = kSparseDec, KP = kSparsePts;
     const double two_pi = 6.283185307179586476925, w0 = two_pi * 19.0 / 128.0;
@@ -366,29 +367,6 @@ void design_pll_sparse(const fmd_coeffs& k, PllSparseTab* t, std::vector<uint16_
     for (int tt = 0; tt < 2 * D; tt++) {                        // tap tt multiplies x[m' - 25 + tt], q = 23 - tt; the mixer relative to the point (m' = span + 16 k - 23)
         wcd[tt] = W[(23 - tt) + 8] * std::polar(1.0, -w0 * (double)(tt - 46));
         t->wre[tt] = (float)wcd[tt].real(); t->wim[tt] = (float)wcd[tt].imag();
-    }
-    if (pv_img) {
-        // k_front_mfma's extra operand rows: row r of the 16 x 16 x 32 tile sums v_r over a column's 16 outputs, v_0 / v_1 the new half's
-        // real / imaginary weights, v_2 / v_3 the old half's; an output is y[m] = sum_t h[t - 2 m] dem[t] (design_front_mfma), so
-        // A2[r][t] = sum_m v_r[m] h[t - 2 m], t < 96.  Rows 4-15 are zero.  Layout as toeplitz_image.
-        pv_img->assign((size_t)3 * 2 * 64 * 8, 0);
-        for (int sK = 0; sK < 3; sK++)
-            for (int l = 0; l < 64; l++)
-                for (int i = 0; i < 8; i++) {
-                    const int tt = 32 * sK + 8 * (l / 16) + i, row = l % 16;
-                    double v = 0.0;
-                    if (row < 4)
-                        for (int m = 0; m < D; m++) {
-                            const int idx = tt - 2 * m;
-                            if (idx < 0 || idx >= 64) continue;
-                            const cd w = wcd[(row < 2 ? D : 0) + m];
-                            v += ((row & 1) ? w.imag() : w.real()) * (double)k.b_fm_out[idx];
-                        }
-                    const float vf = (float)v;
-                    const uint16_t hi = bf16_rne(vf), lo = bf16_rne(vf - bf16_to_f32(hi));
-                    (*pv_img)[(((size_t)sK * 2 + 0) * 64 + l) * 8 + i] = hi;
-                    (*pv_img)[(((size_t)sK * 2 + 1) * 64 + l) * 8 + i] = lo;
-                }
     }
     const cd rho16 = std::pow(rho, D);
     for (int kk = 0; kk < KP; kk++) {
@@ -657,9 +635,14 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     }
     // The first decimator (1.024 / 2.048 MSa/s) gets a stream of its own when the PLL launches do not need own_stream: it then
     // works on block b+1 while k_front works on block b (back to back on one stream the two were the longest stage)
-    const bool predecim = h->ctx.d.m > 1;
-    hipStream_t sP = (pipe && predecim && !chained) ? h->own_stream : sF;
-    hipStream_t s_first = predecim ? sP : sF;      // the stream of the stage that reads the caller's input
+    const bool fused_pre = front_takes_capture(h->ctx);      // (tolerance mode: one kernel, k_front_pre_mfma)
+    const bool predecim = h->ctx.d.m > 1 && !fused_pre;
+    hipStream_t sP = (pipe && h->ctx.d.m > 1 && !chained) ? h->own_stream : sF;
+    // Deferred schedule at 1.024 / 2.048 MSa/s: the front end (with the previous block's pilot stage riding it) follows the first
+    // decimator on that queue, and the extract stages have the front end's queue to themselves: two queues that each run ahead,
+    // instead of one on which k_extract_mfma and the front end take turns while the decimator works beside both.
+    hipStream_t sFq = (lazy && h->ctx.d.m > 1 && sP != sF && h->ctx.fast && h->front_with_predecim) ? sP : sF;
+    hipStream_t s_first = predecim ? sP : sFq;     // the stream of the stage that reads the caller's input
     if (pipe) {
         // input is ready once everything queued so far on the caller's stream has run
         if (ordered || s) {
@@ -674,7 +657,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     }
     // the block after the last de-emphasised one: k_front maintains the Hilbert history (fo_tail) again and must not overwrite
     // what the previous block's k_hilbert, on its own stream, is still reading
-    if (pipe && !h->ctx.any_deemph && h->last_block_deemph) HIP_TRY(h, hipStreamWaitEvent(sF, h->ev_F[h->sub_slot], 0));
+    if (pipe && !h->ctx.any_deemph && h->last_block_deemph) HIP_TRY(h, hipStreamWaitEvent(sFq, h->ev_F[h->sub_slot], 0));
     hipEvent_t input_done = nullptr;               // fires when the caller's buffer has been consumed
     if (predecim) {
         SlotRef r = ref;
@@ -683,7 +666,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         input_done = r.t1 ? r.t1 : h->ev_P[slot];
         e = launch_stage_predecim(h->ctx, r, d_iq, u8, sP);
         if (e != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_predecim launch: %s", hipGetErrorString(e));
-        if (pipe && sP != sF) HIP_TRY(h, hipStreamWaitEvent(sF, input_done, 0));
+        if (pipe && sP != sFq) HIP_TRY(h, hipStreamWaitEvent(sFq, input_done, 0));
     }
     {
         SlotRef r = ref;
@@ -694,15 +677,15 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         // the previous block's pilot stage, put off with its extract stage: as the first workgroups of this launch
         const SlotRef* ride = nullptr;
         auto& q = h->deferred;
-        if (lazy && q.active && q.pll_pending && !q.ref.warm && !q.front_cross && !h->ctx.any_deemph && !h->ctx.b.fm_out_iq[q.slot] &&
+        if (lazy && q.active && q.pll_pending && !q.ref.warm && !q.deemph && q.front_stream == sFq && !h->ctx.any_deemph && !h->ctx.b.fm_out_iq[q.slot] &&
             !(h->debug_skip & ((1u << ST_PLL) | (1u << ST_FRONT))) && !h->no_fused_pll) {
             ride = &q.ref;
-            q.pll_pending = false; q.pll_dep = nullptr; q.pll_stream = sF;
-            if (h->last_p_event && h->last_p_stream != sF) HIP_TRY(h, hipStreamWaitEvent(sF, h->last_p_event, 0));
-            h->last_p_stream = sF; h->last_p_event = dep;          // (the launch's own event)
+            q.pll_pending = false; q.pll_dep = sFq != sF ? dep : nullptr; q.pll_stream = sFq;
+            if (h->last_p_event && h->last_p_stream != sFq) HIP_TRY(h, hipStreamWaitEvent(sFq, h->last_p_event, 0));
+            h->last_p_stream = sFq; h->last_p_event = dep;          // (the launch's own event)
         }
-        if (h->debug_skip & (1u << ST_FRONT)) e = pipe ? hipEventRecord(dep, sF) : hipSuccess;
-        else e = launch_stage_front(h->ctx, r, d_iq, u8, sF, ride);
+        if (h->debug_skip & (1u << ST_FRONT)) e = pipe ? hipEventRecord(dep, sFq) : hipSuccess;
+        else e = launch_stage_front(h->ctx, r, d_iq, u8, sFq, ride);
     }
     if (e != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_front launch: %s", hipGetErrorString(e));
     hipEvent_t front_dep = dep;                    // k_front itself: the caller's buffer (256 kSa/s captures) has been consumed
@@ -718,7 +701,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     if (pipe) {
         // fmd_wait_input: an event that outlives this call (a timed stage's stop event belongs to the profiling marks)
         hipEvent_t persistent = predecim ? h->ev_P[slot] : (h->ctx.any_deemph ? h->ev_D[slot] : h->ev_F[slot]);
-        if ((input_done ? input_done : front_dep) != persistent) HIP_TRY(h, hipEventRecord(persistent, predecim ? sP : sF));
+        if ((input_done ? input_done : front_dep) != persistent) HIP_TRY(h, hipEventRecord(persistent, predecim ? sP : sFq));
         h->ev_consumed = persistent;
     }
     if (!h->ctx.fast) {   // (FMD_FLAG_FAST_MATH: the pilot peak filter runs inside the PLL kernel, there is no power pass)
@@ -726,7 +709,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         if ((e = run(ST_POWER, sA, launch_stage_power, h->ev_A[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_pilot_power launch: %s", hipGetErrorString(e));
     }
     const hipEvent_t fm_out_dep = dep;              // behind this event the block's fm_out is complete
-    const bool fm_out_cross = h->ctx.any_deemph != 0;
+    const bool fm_out_cross = h->ctx.any_deemph != 0 || sFq != sF;
     const bool pll_now = !lazy || h->pll_eager;
     if (pll_now) {
     { int rc = launch_deferred_pll(h, sB); if (rc) return rc; }        // (the put-off block's pilot stage first)
@@ -746,7 +729,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     { int rc = launch_deferred(h, true); if (rc) return rc; }
     if (lazy) {
         auto& q = h->deferred;
-        q.active = true; q.pll_pending = !pll_now; q.front_cross = fm_out_cross; q.ref = ref; q.pll_dep = pll_now ? dep : nullptr; q.pll_stream = pll_now ? sB : nullptr; q.front_dep = fm_out_dep;
+        q.active = true; q.pll_pending = !pll_now; q.front_cross = fm_out_cross; q.deemph = h->ctx.any_deemph != 0; q.front_stream = sFq; q.ref = ref; q.pll_dep = pll_now ? dep : nullptr; q.pll_stream = pll_now ? sB : nullptr; q.front_dep = fm_out_dep;
         q.slot = slot; q.block = h->n_blocks; q.pm = pm;
         q.prof_p = pm && prof_stage(ST_PLL); q.prof_x = pm && prof_stage(ST_EXTRACT); q.prof_r = pm && prof_stage(ST_RDS);
     } else {
@@ -922,6 +905,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     h->lazy_extract = h->lazy_capable;
     h->no_fused_pll = dev_env("FMD_NO_FUSED_PLL") != nullptr;
     h->pll_eager = dev_env("FMD_PLL_EAGER") != nullptr;
+    if (dev_env("FMD_FRONT_OWN_QUEUE")) h->front_with_predecim = false;
 
     fmd_controls def;
     fmd_default_controls(&def);
@@ -998,12 +982,9 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
             if (!rc) rc = dev_alloc(h, &b.sparse_tab, 1);
             if (!rc) {
                 PllSparseTab sp_;
-                std::vector<uint16_t> pimg;
-                design_pll_sparse(h->base, &sp_, &pimg);
-                rc = dev_alloc(h, &b.pv_img, pimg.size() * 2 / sizeof(uint4));
-                if (!rc && (hipMemcpyAsync(b.sparse_tab, &sp_, sizeof(sp_), hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
-                            hipMemcpyAsync(b.pv_img, pimg.data(), pimg.size() * 2, hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
-                            hipStreamSynchronize(h->own_stream) != hipSuccess)) rc = fail(h, FMD_ERR_DEVICE, "sparse table upload failed");
+                design_pll_sparse(h->base, &sp_);
+                if (hipMemcpyAsync(b.sparse_tab, &sp_, sizeof(sp_), hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
+                    hipStreamSynchronize(h->own_stream) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "sparse table upload failed");
             }
             PilotFastTab tab;
             design_pilot_fast(h->base, &tab);
@@ -1458,6 +1439,14 @@ int fmd_get_spec_stats(fmd_handle h, uint64_t* out8, int reset) {
     return FMD_OK;
 }
 
+int fmd_debug_split_front(fmd_handle h, int on) {
+    if (!h) return FMD_ERR_ARG;
+    int rc = fmd_synchronize(h);
+    if (rc) return rc;
+    h->ctx.split_front = on != 0;
+    return FMD_OK;
+}
+
 int fmd_profile_enable(fmd_handle h, int on) {
     if (!h) return FMD_ERR_ARG;
     h->profiling = on < 0 ? 0 : (on > 3 ? 3 : on);
@@ -1476,6 +1465,7 @@ int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out) {
             HIP_TRY(h, hipEventElapsedTime(&ms, pm->t0[i], pm->t1[i]));
             int slot = -1;
             const char* nm = h->ctx.fast ? kStageNameFast[i] : kStageName[i];
+            if (i == ST_FRONT && front_takes_capture(h->ctx)) nm = "k_front_pre_mfma";
             for (int j = 0; j < n; j++) if (std::strncmp(out[j].name, nm, sizeof(out[j].name)) == 0) { slot = j; break; }
             if (slot < 0) {
                 if (n >= cap) continue;

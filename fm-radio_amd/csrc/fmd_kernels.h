@@ -108,8 +108,7 @@ static constexpr float kPllWarmSamples = 8192.0f;
 struct PllSparseTab {
     // points sit at n_k = 16 k + 9 of a span: a point's 32 inputs fm_out[span + 16 k - 48 + t] are then two whole 16-sample columns of the
     // front end's tiles, (k - 3) its "old" half (taps 0..15) and (k - 2) its "new" half (taps 16..31): k_front_mfma sums both halves of every
-    // column on the matrix cores (four more rows of a Toeplitz operand, Buffers::pv_img) and k_pll_sparse reads 16 bytes per column
-    // instead of the 64 bytes of fm_out
+    // column from its fp32 accumulators (front_from_phases) and k_pll_sparse reads 16 bytes per column instead of the 64 bytes of fm_out
     float wre[2 * kSparseDec], wim[2 * kSparseDec];
     float rot[kSparsePts][2];        // e^{-j w0 16 k}
     float scan[3][2];                // rho^16, rho^32, rho^64
@@ -193,7 +192,6 @@ struct Buffers {
     PllSparseTab* sparse_tab;
     float4* pv_pl[kSlots];           // [C][n_fm_out / 16] per 16-sample column of fm_out: (new.re, new.im, old.re, old.im), the two half sums of the pilot points' inputs
     float4* pv_hist[2];              // [C][4] the previous block's last four columns, by block parity (k_pll_sparse reads [par], writes [par ^ 1])
-    uint4*  pv_img;                  // operand image of those sums for k_front_mfma: rows 0-3 = (sum_m v_r[m] h[t - 2 m]), [k-step][hi/lo][lane]
     PilotFastTab* pilot_tab;         // FMD_FLAG_FAST_MATH only
     uint4*  aud_img;                 // ... of k_extract_mfma's audio FIRs, one per distinct cut-off: [slot][k-step][hi/lo][lane]
     int2*   aud_idx;                 // [C] slots of a station's L+R and L-R images
@@ -217,6 +215,7 @@ struct LaunchCtx {
     int fast;                             // FMD_FLAG_FAST_MATH: the tolerance-mode kernels
     int any_deemph;
     int deemph_in_tile;     // FMD_FLAG_FAST_MATH: the de-emphasis IIR runs inside k_front's tile (every filtering channel's pole <= 0.905, i.e. up to ~79 us)
+    int split_front;        // fmd_debug_split_front: 1.024 / 2.048 MSa/s tolerance mode with k_predecim_mfma and k_front_mfma as two kernels (the parity check of k_front_pre_mfma)
     int bytes_cap;
     int pll_time_parallel_max_channels;   // batches up to this size use the time-parallel PLL kernel, larger ones the low-work one
     int pll_k16_max_channels;             // (channels x m) up to this: 16 lanes per channel, above: 8
@@ -227,6 +226,7 @@ struct LaunchCtx {
 hipError_t launch_stage_predecim(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s);   // k_predecim (m > 1)
 // pll != NULL (tolerance mode only): the pilot stage of the block in slot pll->buf rides in the same launch (k_front_mfma<..., FUSED>)
 hipError_t launch_stage_front(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s, const SlotRef* pll = nullptr);   // k_front
+bool front_takes_capture(const LaunchCtx& ctx);    // m > 1: the first decimator runs inside launch_stage_front's kernel (no predecim stage for this block)
 hipError_t launch_stage_deemph(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                            // k_deemphasis + k_hilbert
 hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                             // k_pilot_power
 hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                               // k_pilot_pll

@@ -41,10 +41,6 @@
     } while (0)
 
 
-#ifndef FMD_PV_VARIANT
-#define FMD_PV_VARIANT 4
-#endif
-
 namespace fmd {
 
 static constexpr int kWave = 64;
@@ -271,6 +267,152 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
 // bf16 x 3 matrix product (FrontGeomM above); WU > 0: with the de-emphasis IIR inside the tile (see k_front).  The Hilbert FIR is
 // k_extract_mfma's: the analytic signal never goes through HBM, only fm_out does (4 bytes per sample instead of 8).
 // =============================================================================================
+// The operands a front-end workgroup loads once: the Toeplitz images of the decimating FIR, and this lane's weights in the pilot
+// stage's four column sums (PllSparseTab: new / old half, re / im).
+struct FrontOps { bf16x8 adh[3], adl[3]; float4 wNr, wNi, wOr, wOi; };
+template <int WU>
+__device__ __forceinline__ void load_front_ops(FrontOps& op, const uint4* __restrict__ tab, const PllSparseTab* __restrict__ sp, int lane, int lq) {
+#pragma unroll
+    for (int sK = 0; sK < 3; sK++) {
+        op.adh[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 0) * kWave + lane]);
+        op.adl[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 1) * kWave + lane]);
+    }
+    if constexpr (WU == 0) {
+        op.wNr = *reinterpret_cast<const float4*>(&sp->wre[16 + 4 * lq]); op.wNi = *reinterpret_cast<const float4*>(&sp->wim[16 + 4 * lq]);
+        op.wOr = *reinterpret_cast<const float4*>(&sp->wre[4 * lq]); op.wOi = *reinterpret_cast<const float4*>(&sp->wim[4 * lq]);
+    }
+}
+
+// The front end from the tile's phases on (k_front_mfma, k_front_pre_mfma): theta[0 .. NW) = the phases (turns) of fm_in samples
+// 2 o0 - TAIL ..., in LDS; dem32 = the 16-byte aligned start of that region, over which the discriminator output is written in place
+// (theta may start up to 8 bytes into it).  All threads of the workgroup, phases complete (a barrier behind the writer).
+template <int TT, int WU>
+__device__ __forceinline__ void front_from_phases(const Dims& d, float* smem, const float* theta, uint32_t* dem32, int c, int o0, int tid, float fm_gain,
+                                                  const float* __restrict__ deemph, const FrontOps& op, float* __restrict__ fo_pl,
+                                                  float4* __restrict__ pv_pl, const PllSparseTab* __restrict__ sp) {
+    using G = FrontGeomM<TT, WU>;
+    constexpr int T = G::T, NW = G::NW, NF = G::NF;
+    const int lane = tid & (kWave - 1), wv = tid >> 6, lrow = lane & 15, lq = lane >> 4;
+    uint32_t* dem_hi32 = dem32;                                                    // two bf16 per word
+    uint32_t* dem_lo32 = dem_hi32 + G::NWB / 2;
+    float* fo = smem + G::OFF_FO;
+    float4* pv_row = pv_pl + (size_t)c * (d.n_fm_out / 16) + o0 / 16;
+    // phase difference, wrap, scale: two samples per thread and step, split into bf16 halves, in place over the phases
+    {
+        const float gain_t = fm_gain * bits_f32(kTwoPiBits);           // the discriminator's gain per turn
+        constexpr int NPW = G::NWB / 2;                              // words per half
+        constexpr int PERP = (NPW + 255) / 256;
+        uint32_t wh[PERP], wl[PERP];
+#pragma unroll
+        for (int r = 0; r < PERP; r++) {
+            const int pw = tid + 256 * r, j = 2 * pw;
+            wh[r] = 0u; wl[r] = 0u;
+            if (j < NW - 1) {
+                const float t0 = theta[j], t1 = theta[j + 1], t2 = (j + 2 < NW) ? theta[j + 2] : t1;
+                float d0 = t1 - t0, d1 = t2 - t1;
+                d0 = d0 - rintf(d0); d1 = d1 - rintf(d1);           // reference fm_demod.cpp:36-43: the phase difference wrapped to half a turn
+                d0 *= gain_t; d1 = (j + 1 < NW - 1) ? d1 * gain_t : 0.0f;
+                uint32_t h0, l0, h1, l1;
+                split_bf16(d0, h0, l0); split_bf16(d1, h1, l1);
+                wh[r] = pack_hi16(h0, h1); wl[r] = pack_hi16(l0, l1);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PERP; r++) {
+            const int pw = tid + 256 * r;
+            if (pw < NPW) { dem_hi32[pw] = wh[r]; dem_lo32[pw] = wl[r]; }
+        }
+    }
+    __syncthreads();
+    // a3: decimate-by-2 FIR: wavefront w takes the 16-column tiles w, w + 4, ... (a column = 16 consecutive outputs).
+    // fm_out goes to its plane undelayed (the rows start with the previous block's tail, k_pll_sparse); the consumers delay it by 32
+    // for the real rail and k_extract_mfma makes the Hilbert rail from it.
+    float* fo_row = fo_pl + (size_t)c * (kFoPad + d.n_fm_out) + kFoPad + o0;
+    for (int ct = wv; ct * 16 < G::NCOL; ct += 4) {
+        const int col = ct * 16 + lrow, colr = col < G::NCOL ? col : G::NCOL - 1;
+        // (round 3, PMC: a wavefront of this kernel spent 37 % of its cycles waiting for the previous MFMA of one nine-long chain)
+        f32x4 acc, acc1, acc2;   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
+#pragma unroll
+        for (int sK = 0; sK < 3; sK++) {
+            const int e = 32 * colr + 32 * sK + 8 * lq;              // bf16 element index, a multiple of 8
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(dem_hi32 + e / 2));
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(dem_lo32 + e / 2));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op.adh[sK], bh, sK ? acc : kZero4, 0, 0, 0);      // (the first step starts from the constant 0: no registers to clear)
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op.adl[sK], bh, sK ? acc1 : kZero4, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op.adh[sK], bl, sK ? acc2 : kZero4, 0, 0, 0);
+        }
+        acc = acc + (acc1 + acc2);
+        if constexpr (WU == 0) {
+            // the pilot stage's column sums (k_pll_sparse then reads 16 bytes per column instead of fm_out's 64) from the fp32 outputs in the
+            // accumulators: a lane holds outputs 4 lq .. 4 lq + 3 of its column; its four partial sums meet their column's other three lanes
+            // (16, 32, 48 lanes on) in two swap steps that leave ONE total in each lane.  (Measured against four more rows of the Toeplitz
+            // operand on the matrix cores, bf16 x 3 / x 2 / x 1: this form costs the front end least, DESIGN.md.)
+            const float p0 = fmaf(op.wNr.x, acc[0], fmaf(op.wNr.y, acc[1], fmaf(op.wNr.z, acc[2], op.wNr.w * acc[3])));
+            const float p1 = fmaf(op.wNi.x, acc[0], fmaf(op.wNi.y, acc[1], fmaf(op.wNi.z, acc[2], op.wNi.w * acc[3])));
+            const float p2 = fmaf(op.wOr.x, acc[0], fmaf(op.wOr.y, acc[1], fmaf(op.wOr.z, acc[2], op.wOr.w * acc[3])));
+            const float p3 = fmaf(op.wOi.x, acc[0], fmaf(op.wOi.y, acc[1], fmaf(op.wOi.z, acc[2], op.wOi.w * acc[3])));
+            // v_permlane16_swap: the odd rows (of 16 lanes) of the first operand change places with the even rows of the second
+            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p0), __float_as_uint(p2), false, false);
+            const float s02 = __uint_as_float(r[0]) + __uint_as_float(r[1]);       // even rows: p0 over the row pair; odd rows: p2
+            r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p1), __float_as_uint(p3), false, false);
+            const float s13 = __uint_as_float(r[0]) + __uint_as_float(r[1]);       // even rows: p1; odd rows: p3
+            // v_permlane32_swap: the upper half of the first operand changes places with the lower half of the second
+            r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s02), __float_as_uint(s13), false, false);
+            const float tot = __uint_as_float(r[0]) + __uint_as_float(r[1]);        // rows 0-3: new.re, old.re, new.im, old.im
+            const int idx = ((lq & 1) << 1) | (lq >> 1);
+            if (col < G::NCOL) reinterpret_cast<float*>(pv_row + col)[idx] = tot;
+        }
+        if (col < G::NCOL) {
+            if constexpr (WU == 0) *reinterpret_cast<float4*>(fo_row + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);   // a wavefront: 4 KB in a row
+            else *reinterpret_cast<float4*>(fo + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+    if constexpr (WU > 0) {
+        __syncthreads();
+        // a4 in the tile (see k_front): 8 samples per thread from a zero state, end states through LDS, 16 segments of history
+        const float b0 = deemph[4 * c + 0], b1 = deemph[4 * c + 1], a0 = deemph[4 * c + 2];
+        if (deemph[4 * c + 3] != 0.0f) {
+            float* zs = smem + G::OFF_ZS;
+            constexpr int NSEG = NF / 8;
+            float yv[8];
+            if (tid < 16) zs[tid] = 0.0f;
+            if (tid < NSEG) {
+                const float4 xa = *reinterpret_cast<const float4*>(fo + 8 * tid), xb = *reinterpret_cast<const float4*>(fo + 8 * tid + 4);
+                const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                float xp = tid ? fo[8 * tid - 1] : 0.0f, z = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { z = fmaf(a0, z, fmaf(xs[k], b1, xp * b0)); yv[k] = z; xp = xs[k]; }
+                zs[16 + tid] = z;
+            }
+            __syncthreads();
+            if (tid < NSEG) {
+                const float a2 = a0 * a0, a4 = a2 * a2, a8 = a4 * a4;
+                float e = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 16; k++) e = fmaf(a8, e, zs[tid + k]);
+                float pw = a0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) { yv[k] = fmaf(pw, e, yv[k]); pw *= a0; }
+                *reinterpret_cast<float4*>(fo + 8 * tid) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+                *reinterpret_cast<float4*>(fo + 8 * tid + 4) = make_float4(yv[4], yv[5], yv[6], yv[7]);
+            }
+            __syncthreads();
+        }
+        for (int q4 = tid; q4 < T / 4; q4 += 256) *reinterpret_cast<float4*>(fo_row + 4 * q4) = *reinterpret_cast<const float4*>(fo + WU + 4 * q4);
+        // the pilot stage's column sums from the de-emphasised outputs (the reference filters fm_out in place ahead of every consumer,
+        // broadcast_fm_demod.cpp:403-406): thread = (column, one of its four sums), fp32
+        for (int cc = tid >> 2; cc < T / 16; cc += 64) {
+            const int part = tid & 3;
+            const float* w = ((part & 1) ? sp->wim : sp->wre) + ((part < 2) ? 16 : 0);
+            float a0_ = 0.0f, a1_ = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) { a0_ = fmaf(w[i], fo[WU + 16 * cc + i], a0_); a1_ = fmaf(w[i + 1], fo[WU + 16 * cc + i + 1], a1_); }
+            reinterpret_cast<float*>(pv_row + cc)[part] = a0_ + a1_;
+        }
+    }
+}
+
 // FUSED: the launch's first pf.n_wg workgroups run the pilot stage (k_pll_sparse's body) of the block BEFORE this one — on the deferred
 // schedule (fmd_api.cpp) the front end's queue then carries front(k + 1) + pilot(k), extract(k), front(k + 2) + pilot(k + 1), ... and no
 // kernel on it waits for another queue; the pilot stage's half-thousand wavefronts start first and finish inside the front end's HBM-bound time.
@@ -278,9 +420,9 @@ template <typename InT, int TT, int WU, bool FUSED = false>
 __global__ __launch_bounds__(256, FUSED ? 6 : 5) void k_front_mfma(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
                                                     float2* __restrict__ tail_out, float* __restrict__ fo_pl, float fm_gain,
                                                     const float* __restrict__ deemph, const uint4* __restrict__ tab, float4* __restrict__ pv_pl,
-                                                    const uint4* __restrict__ pv_img, const PllSparseTab* __restrict__ sp, PllFusedArgs pf) {
+                                                    const PllSparseTab* __restrict__ sp, PllFusedArgs pf) {
     using G = FrontGeomM<TT, WU>;
-    constexpr int T = G::T, NW = G::NW, NF = G::NF;
+    constexpr int T = G::T, NW = G::NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bid = (int)blockIdx.x;
     if constexpr (FUSED) {
@@ -292,41 +434,17 @@ __global__ __launch_bounds__(256, FUSED ? 6 : 5) void k_front_mfma(Dims d, const
         bid -= pf.n_wg;
     }
     float* theta = smem + G::OFF_THETA;
-    uint32_t* dem_hi32 = reinterpret_cast<uint32_t*>(smem);                        // two bf16 per word
-    uint32_t* dem_lo32 = dem_hi32 + G::NWB / 2;
-    float* fo = smem + G::OFF_FO;
 
     const int tiles = d.n_fm_out / T;
     const int c = bid / tiles, tile = bid % tiles, o0 = tile * T, tid = threadIdx.x;
     __builtin_assume(tid >= 0 && tid < 256);     // (the bounds of the unrolled staging loops are tested against it)
-    const int lane = tid & (kWave - 1), wv = tid >> 6, lrow = lane & 15, lq = lane >> 4;
+    const int lane = tid & (kWave - 1), lq = lane >> 4;
     const int g_lo = 2 * o0 - G::TAIL;                            // first input index of the tile (block relative)
     const InT* in_c = in + (size_t)c * d.N;
     const float2* tail_c = tail_in + (size_t)c * d.tail_base + (d.tail_base - G::TAIL);
 
-    // the Toeplitz operands of the decimating FIR
-    bf16x8 adh[3], adl[3];
-#pragma unroll
-    for (int sK = 0; sK < 3; sK++) {
-        adh[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 0) * kWave + lane]);
-        adl[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 1) * kWave + lane]);
-    }
-    // ... and of the pilot stage's column sums (PllSparseTab): rows 0-3 of a second tile on the same windows = the four half sums of the
-    // column's 16 outputs (k_pll_sparse then reads 16 bytes per column instead of fm_out's 64)
-    float4* pv_row = pv_pl + (size_t)c * (d.n_fm_out / 16) + o0 / 16;
-    float4 wNr, wNi, wOr, wOi;           // FMD_PV_VARIANT 4: the weights of this lane's four outputs in the four sums (with the other early loads)
-    if constexpr (WU == 0 && FMD_PV_VARIANT == 4) {
-        wNr = *reinterpret_cast<const float4*>(&sp->wre[16 + 4 * lq]); wNi = *reinterpret_cast<const float4*>(&sp->wim[16 + 4 * lq]);
-        wOr = *reinterpret_cast<const float4*>(&sp->wre[4 * lq]); wOi = *reinterpret_cast<const float4*>(&sp->wim[4 * lq]);
-    }
-    bf16x8 aph[3], apl[3];
-    if constexpr (WU == 0 && FMD_PV_VARIANT < 3) {
-#pragma unroll
-        for (int sK = 0; sK < 3; sK++) {
-            aph[sK] = __builtin_bit_cast(bf16x8, pv_img[(sK * 2 + 0) * kWave + lane]);
-            apl[sK] = __builtin_bit_cast(bf16x8, pv_img[(sK * 2 + 1) * kWave + lane]);
-        }
-    }
+    FrontOps op;                                                   // (with the other early loads)
+    load_front_ops<WU>(op, tab, sp, lane, lq);
     // a0-a2: staging, arctangent (all loads first)
     bool staged = false;
     if constexpr (sizeof(InT) == 8) {
@@ -411,135 +529,7 @@ __global__ __launch_bounds__(256, FUSED ? 6 : 5) void k_front_mfma(Dims d, const
         }
     }
     __syncthreads();
-    // phase difference, wrap, scale: two samples per thread and step, split into bf16 halves, in place over the phases
-    {
-        const float gain_t = fm_gain * bits_f32(kTwoPiBits);           // the discriminator's gain per turn
-        constexpr int NPW = G::NWB / 2;                              // words per half
-        constexpr int PERP = (NPW + 255) / 256;
-        uint32_t wh[PERP], wl[PERP];
-#pragma unroll
-        for (int r = 0; r < PERP; r++) {
-            const int pw = tid + 256 * r, j = 2 * pw;
-            wh[r] = 0u; wl[r] = 0u;
-            if (j < NW - 1) {
-                const float t0 = theta[j], t1 = theta[j + 1], t2 = (j + 2 < NW) ? theta[j + 2] : t1;
-                float d0 = t1 - t0, d1 = t2 - t1;
-                d0 = d0 - rintf(d0); d1 = d1 - rintf(d1);           // reference fm_demod.cpp:36-43: the phase difference wrapped to half a turn
-                d0 *= gain_t; d1 = (j + 1 < NW - 1) ? d1 * gain_t : 0.0f;
-                uint32_t h0, l0, h1, l1;
-                split_bf16(d0, h0, l0); split_bf16(d1, h1, l1);
-                wh[r] = pack_hi16(h0, h1); wl[r] = pack_hi16(l0, l1);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < PERP; r++) {
-            const int pw = tid + 256 * r;
-            if (pw < NPW) { dem_hi32[pw] = wh[r]; dem_lo32[pw] = wl[r]; }
-        }
-    }
-    __syncthreads();
-    // a3: decimate-by-2 FIR: wavefront w takes the 16-column tiles w, w + 4, ... (a column = 16 consecutive outputs).
-    // fm_out goes to its plane undelayed (the rows start with the previous block's tail, k_pll_span); the consumers delay it by 32
-    // for the real rail and k_extract_mfma makes the Hilbert rail from it.
-    float* fo_row = fo_pl + (size_t)c * (kFoPad + d.n_fm_out) + kFoPad + o0;
-    for (int ct = wv; ct * 16 < G::NCOL; ct += 4) {
-        const int col = ct * 16 + lrow, colr = col < G::NCOL ? col : G::NCOL - 1;
-        // (round 3, PMC: a wavefront of this kernel spent 37 % of its cycles waiting for the previous MFMA of one nine-long chain)
-        f32x4 acc, acc1, acc2;   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
-        f32x4 pc, pc1, pc2;
-#pragma unroll
-        for (int sK = 0; sK < 3; sK++) {
-            const int e = 32 * colr + 32 * sK + 8 * lq;              // bf16 element index, a multiple of 8
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(dem_hi32 + e / 2));
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(dem_lo32 + e / 2));
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bh, sK ? acc : kZero4, 0, 0, 0);      // (the first step starts from the constant 0: no registers to clear)
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adl[sK], bh, sK ? acc1 : kZero4, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bl, sK ? acc2 : kZero4, 0, 0, 0);
-            if constexpr (WU == 0 && FMD_PV_VARIANT == 0) {
-                pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aph[sK], bh, sK ? pc : kZero4, 0, 0, 0);
-                pc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(apl[sK], bh, sK ? pc1 : kZero4, 0, 0, 0);
-                pc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aph[sK], bl, sK ? pc2 : kZero4, 0, 0, 0);
-            }
-            if constexpr (WU == 0 && FMD_PV_VARIANT == 1) {
-                pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aph[sK], bh, sK ? pc : kZero4, 0, 0, 0);
-                pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(apl[sK], bh, pc, 0, 0, 0);
-            }
-            if constexpr (WU == 0 && FMD_PV_VARIANT == 2) {
-                pc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aph[sK], bh, sK ? pc : kZero4, 0, 0, 0);
-            }
-        }
-        acc = acc + (acc1 + acc2);
-        if constexpr (WU == 0 && FMD_PV_VARIANT == 4) {
-            // the pilot stage's column sums from the fp32 outputs in the accumulators: a lane holds outputs 4 lq .. 4 lq + 3 of its column; its four
-            // partial sums meet their column's other three lanes (16, 32, 48 lanes on) in two swap steps that leave ONE total in each lane
-            const float p0 = fmaf(wNr.x, acc[0], fmaf(wNr.y, acc[1], fmaf(wNr.z, acc[2], wNr.w * acc[3])));
-            const float p1 = fmaf(wNi.x, acc[0], fmaf(wNi.y, acc[1], fmaf(wNi.z, acc[2], wNi.w * acc[3])));
-            const float p2 = fmaf(wOr.x, acc[0], fmaf(wOr.y, acc[1], fmaf(wOr.z, acc[2], wOr.w * acc[3])));
-            const float p3 = fmaf(wOi.x, acc[0], fmaf(wOi.y, acc[1], fmaf(wOi.z, acc[2], wOi.w * acc[3])));
-            // v_permlane16_swap: the odd rows (of 16 lanes) of the first operand change places with the even rows of the second
-            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p0), __float_as_uint(p2), false, false);
-            const float s02 = __uint_as_float(r[0]) + __uint_as_float(r[1]);       // even rows: p0 over the row pair; odd rows: p2
-            r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p1), __float_as_uint(p3), false, false);
-            const float s13 = __uint_as_float(r[0]) + __uint_as_float(r[1]);       // even rows: p1; odd rows: p3
-            // v_permlane32_swap: the upper half of the first operand changes places with the lower half of the second
-            r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s02), __float_as_uint(s13), false, false);
-            const float tot = __uint_as_float(r[0]) + __uint_as_float(r[1]);        // rows 0-3: new.re, old.re, new.im, old.im
-            const int idx = ((lq & 1) << 1) | (lq >> 1);
-            if (col < G::NCOL) reinterpret_cast<float*>(pv_row + col)[idx] = tot;
-        }
-        if constexpr (WU == 0 && FMD_PV_VARIANT < 3) {
-            if constexpr (FMD_PV_VARIANT == 0) pc = pc + (pc1 + pc2);
-            if (col < G::NCOL && lq == 0) pv_row[col] = make_float4(pc[0], pc[1], pc[2], pc[3]);       // rows 0-3: 16 lanes, 256 bytes in a row
-        }
-        if (col < G::NCOL) {
-            if constexpr (WU == 0) *reinterpret_cast<float4*>(fo_row + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);   // a wavefront: 4 KB in a row
-            else *reinterpret_cast<float4*>(fo + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        }
-    }
-    if constexpr (WU > 0) {
-        __syncthreads();
-        // a4 in the tile (see k_front): 8 samples per thread from a zero state, end states through LDS, 16 segments of history
-        const float b0 = deemph[4 * c + 0], b1 = deemph[4 * c + 1], a0 = deemph[4 * c + 2];
-        if (deemph[4 * c + 3] != 0.0f) {
-            float* zs = smem + G::OFF_ZS;
-            constexpr int NSEG = NF / 8;
-            float yv[8];
-            if (tid < 16) zs[tid] = 0.0f;
-            if (tid < NSEG) {
-                const float4 xa = *reinterpret_cast<const float4*>(fo + 8 * tid), xb = *reinterpret_cast<const float4*>(fo + 8 * tid + 4);
-                const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-                float xp = tid ? fo[8 * tid - 1] : 0.0f, z = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 8; k++) { z = fmaf(a0, z, fmaf(xs[k], b1, xp * b0)); yv[k] = z; xp = xs[k]; }
-                zs[16 + tid] = z;
-            }
-            __syncthreads();
-            if (tid < NSEG) {
-                const float a2 = a0 * a0, a4 = a2 * a2, a8 = a4 * a4;
-                float e = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 16; k++) e = fmaf(a8, e, zs[tid + k]);
-                float pw = a0;
-#pragma unroll
-                for (int k = 0; k < 8; k++) { yv[k] = fmaf(pw, e, yv[k]); pw *= a0; }
-                *reinterpret_cast<float4*>(fo + 8 * tid) = make_float4(yv[0], yv[1], yv[2], yv[3]);
-                *reinterpret_cast<float4*>(fo + 8 * tid + 4) = make_float4(yv[4], yv[5], yv[6], yv[7]);
-            }
-            __syncthreads();
-        }
-        for (int q4 = tid; q4 < T / 4; q4 += 256) *reinterpret_cast<float4*>(fo_row + 4 * q4) = *reinterpret_cast<const float4*>(fo + WU + 4 * q4);
-        // the pilot stage's column sums from the de-emphasised outputs (the reference filters fm_out in place ahead of every consumer,
-        // broadcast_fm_demod.cpp:403-406): thread = (column, one of its four sums), fp32
-        for (int cc = tid >> 2; cc < T / 16; cc += 64) {
-            const int part = tid & 3;
-            const float* w = ((part & 1) ? sp->wim : sp->wre) + ((part < 2) ? 16 : 0);
-            float a0_ = 0.0f, a1_ = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) { a0_ = fmaf(w[i], fo[WU + 16 * cc + i], a0_); a1_ = fmaf(w[i + 1], fo[WU + 16 * cc + i + 1], a1_); }
-            reinterpret_cast<float*>(pv_row + cc)[part] = a0_ + a1_;
-        }
-    }
+    front_from_phases<TT, WU>(d, smem, theta, reinterpret_cast<uint32_t*>(smem), c, o0, tid, fm_gain, deemph, op, fo_pl, pv_pl, sp);
     if (tile == tiles - 1) {
         float2* tout = tail_out + (size_t)c * d.tail_base;
         for (int idx = tid; idx < d.tail_base; idx += 256) tout[idx] = load_iq(in_c, (unsigned)(d.N - d.tail_base + idx));
@@ -788,6 +778,185 @@ __global__ __launch_bounds__(256) void k_predecim_mfma(Dims d, const InT* __rest
     }
     // the last 64 input samples of the block are the next block's history
     if (tile == tiles - 1 && tid < G::HIST) tail_out[(size_t)c * G::HIST + tid] = load_iq(in_c, (unsigned)(d.N - G::HIST + tid));
+}
+
+// =============================================================================================
+// k_front_pre_mfma — 1.024 / 2.048 MSa/s, FMD_FLAG_FAST_MATH: k_predecim_mfma and k_front_mfma in one kernel.  fm_in (the phases at
+// 256 kSa/s) stays in LDS: the capture is read once and nothing but fm_out and the pilot stage's column sums is written, instead of
+// 4 more bytes per 256 kSa/s sample written by one kernel and read by the next (0.27 GB each way per 4096 x 64 ms).
+// One workgroup = one station x 1024 fm_out samples (k_front_mfma's tile).  It needs the 2111 phases fm_in[2 o0 - 63 .. 2 o0 + 2047];
+// it makes 2112 = 132 columns of 16, one earlier, so that every staged window starts on a multiple of 8 input samples (16-byte loads
+// of u8 captures), in NSUB sub-steps of CS columns through one staging array the size of k_predecim_mfma's (the whole input window
+// of a tile is 68 KB of cf32 at M = 4).  The loads of sub-step s + 1 are in flight while sub-step s is converted and multiplied.
+// The 64 phases in front of a tile are computed twice (3 % more of the first decimator's work; round 2's fused VALU kernel paid 19 %
+// on 512-output tiles).  Arithmetic per phase and per fm_out sample is the two kernels' own: outputs are bit-identical to theirs.
+// =============================================================================================
+template <int M, bool U8>
+struct FrontPreGeom {
+    using GF = FrontGeomM<1024, 0>;
+    static constexpr int NPH = 2112, NCOLS = NPH / 16;            // phases / columns per tile
+    static constexpr int NSUB = U8 ? (M == 4 ? 2 : 4) : (M == 4 ? 4 : 6);
+    static constexpr int CS = NCOLS / NSUB;                       // columns per sub-step
+    static constexpr int SH = 8 - M;
+    static constexpr int SEG = 16 * M;                            // input samples between two columns' windows
+    static constexpr int NBS = SEG * CS + 64;                     // input samples staged per sub-step
+    static constexpr int KS = (64 + SH + 15 * M + 31) / 32;
+    static constexpr int NEP = NBS + 8 * (NBS / SEG + 1);         // padded elements per array (see PredecimGeomM)
+    static constexpr int NH = U8 ? 1 : 2;
+    static constexpr int NWD = NEP / 2;                           // words per array
+    static constexpr int ARR_WORDS = (2 * NH * NWD + 3) & ~3;
+    static constexpr int LDS_WORDS = ARR_WORDS + GF::NWB;         // staging arrays, then the phases / discriminator output region
+    static constexpr int HIST = 64;
+    // Measured (4096 stations x 64 ms at 1.024 MSa/s, the kernel on its own / the step): cf32 with the next sub-step's loads in flight over
+    // the products and four workgroups per CU 0.45 / 0.64 ms; without 0.47 / 0.67; five per CU (96 registers, spills) 0.47 / 0.72.
+    // u8 (not bandwidth-bound: the conversion is the work): five per CU without prefetch 0.26 / 0.45 ms against 0.29 / 0.48 — at M = 4;
+    // at M = 8 (six K-steps of operands in registers) that form spills: 0.74 ms a step against 0.61.
+    // Two or more tiles per workgroup with the next tile's loads in flight over the back half: 0.56-0.60 on its own, dropped.
+    static constexpr bool PREFETCH = !(U8 && M == 4);
+    static constexpr int MINWG = (U8 && M == 4) ? 5 : 4;
+    static_assert(NCOLS % NSUB == 0 && NBS % 8 == 0 && SEG * (CS - 1) + 32 * KS <= NBS && GF::NWB >= NPH + 1, "geometry");
+};
+template <int M, typename InT, bool FUSED>
+__global__ __launch_bounds__(256, (FrontPreGeom<M, sizeof(InT) == 2>::MINWG)) void k_front_pre_mfma(Dims d, const InT* __restrict__ in, const float2* __restrict__ pre_tail_in, float2* __restrict__ pre_tail_out,
+                                                           const float2* __restrict__ tail_in, float2* __restrict__ tail_out, float* __restrict__ fo_pl, float fm_gain,
+                                                           const uint4* __restrict__ tab_pre, const uint4* __restrict__ tab, float4* __restrict__ pv_pl,
+                                                           const PllSparseTab* __restrict__ sp, PllFusedArgs pf) {
+    constexpr bool U8 = sizeof(InT) == 2;
+    using G = FrontPreGeom<M, U8>;
+    constexpr int NBS = G::NBS, KS = G::KS, SEG = G::SEG, NH = G::NH, NWD = G::NWD, CS = G::CS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int bid = (int)blockIdx.x;
+    if constexpr (FUSED) {
+        if (bid < pf.n_wg) {
+            pll_sparse_body(d, bid * 4 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & (kWave - 1)), pf.pv, pf.hist_in, pf.hist_out, pf.fo, pf.fo_next, pf.poly, pf.poly_next,
+                            pf.state, pf.k, pf.tab, 0, pf.spec_stats);
+            return;
+        }
+        bid -= pf.n_wg;
+    }
+    uint32_t* arr = reinterpret_cast<uint32_t*>(smem);                         // [rail][half][NWD]
+    float* region = smem + G::ARR_WORDS;                                       // phases of fm_in[2 o0 - 64 + i]; then the discriminator output
+    const int tiles = d.n_fm_out / 1024;
+    const int c = bid / tiles, tile = bid % tiles, o0 = tile * 1024, tid = threadIdx.x;
+    __builtin_assume(tid >= 0 && tid < 256);
+    const int lane = tid & (kWave - 1), wv = tid >> 6, lrow = lane & 15, lq = lane >> 4;
+    const int g_first = M * (2 * o0 - 64) + M - 64 - G::SH;                    // first input sample staged (block relative), a multiple of 8
+    const InT* in_c = in + (size_t)c * d.N;
+    const float2* ptail_c = pre_tail_in + (size_t)c * G::HIST;
+    auto word_of = [](int pair) { return pair + 4 * (pair / (SEG / 2)); };      // pair p = elements 2 p, 2 p + 1 -> word of the padded array
+
+    bf16x8 adh[KS], adl[KS];
+    auto load_operands = [&]() {
+#pragma unroll
+        for (int sK = 0; sK < KS; sK++) {
+            adh[sK] = __builtin_bit_cast(bf16x8, tab_pre[(sK * 2 + 0) * kWave + lane]);
+            adl[sK] = __builtin_bit_cast(bf16x8, tab_pre[(sK * 2 + 1) * kWave + lane]);
+        }
+    };
+    load_operands();
+    // items of 16 bytes: two cf32 samples / eight u8 samples.  Samples before the 64 the previous block left (first tile only) feed the
+    // phases in front of the block, which come from the phase history below: any in-bounds value does; the last tile's overhang
+    // (M = 8: 8 samples) sits under zero taps
+    constexpr int IS = U8 ? 8 : 2, ITEMS = NBS / IS, PER = (ITEMS + 255) / 256;
+    uint4 buf[PER];
+    auto issue1 = [&](int gs, int r) {
+        const int j = tid + 256 * r;
+        if (j < ITEMS) {
+            int g = gs + IS * j;
+            g = g < -G::HIST ? -G::HIST : (g < d.N - IS ? g : d.N - IS);
+            if constexpr (!U8) buf[r] = (g < 0) ? *reinterpret_cast<const uint4*>(ptail_c + (G::HIST + g)) : *reinterpret_cast<const uint4*>(in_c + g);
+            else if (g >= 0) buf[r] = *reinterpret_cast<const uint4*>(in_c + g);
+        }
+    };
+    auto convert1 = [&](int gs, int r) {
+        const int j = tid + 256 * r;
+        if (j < ITEMS) {
+            if constexpr (!U8) {
+                uint32_t h0, l0, h1, l1;
+                const int w = word_of(j);
+                split_bf16_rn(__uint_as_float(buf[r].x), h0, l0); split_bf16_rn(__uint_as_float(buf[r].z), h1, l1);
+                arr[0 * NWD + w] = pack_hi16(h0, h1); arr[1 * NWD + w] = pack_hi16(l0, l1);
+                split_bf16_rn(__uint_as_float(buf[r].y), h0, l0); split_bf16_rn(__uint_as_float(buf[r].w), h1, l1);
+                arr[2 * NWD + w] = pack_hi16(h0, h1); arr[3 * NWD + w] = pack_hi16(l0, l1);
+            } else {
+                int g = gs + 8 * j;
+                uint32_t re[8], im[8];
+                if (g < 0) {        // history, kept as cf32 (u8 captures: integers; after a cf32 block: rounded to bf16)
+                    g = g < -G::HIST ? -G::HIST : g;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const float2 v = ptail_c[G::HIST + g + u]; re[u] = f32_bits(v.x) + 0x8000u; im[u] = f32_bits(v.y) + 0x8000u; }
+                } else {
+                    const uint32_t w4[4] = {buf[r].x, buf[r].y, buf[r].z, buf[r].w};
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const uint32_t ww = w4[u >> 1] >> (16 * (u & 1));
+                        re[u] = f32_bits((float)(ww & 0xffu) - 127.0f); im[u] = f32_bits((float)((ww >> 8) & 0xffu) - 127.0f);      // reference src/app.cpp:56-62
+                    }
+                }
+                const int w = word_of(4 * j);
+                *reinterpret_cast<uint4*>(arr + 0 * NWD + w) = make_uint4(pack_hi16(re[0], re[1]), pack_hi16(re[2], re[3]), pack_hi16(re[4], re[5]), pack_hi16(re[6], re[7]));
+                *reinterpret_cast<uint4*>(arr + 1 * NWD + w) = make_uint4(pack_hi16(im[0], im[1]), pack_hi16(im[2], im[3]), pack_hi16(im[4], im[5]), pack_hi16(im[6], im[7]));
+            }
+        }
+    };
+    if constexpr (G::PREFETCH) {
+#pragma unroll
+        for (int r = 0; r < PER; r++) issue1(g_first, r);
+    }
+#pragma unroll 1
+    for (int s = 0; s < G::NSUB; s++) {
+        if (s) __syncthreads();                                    // the previous sub-step's operand reads
+        const int gs = g_first + SEG * CS * s;
+        if constexpr (!G::PREFETCH) {
+#pragma unroll
+            for (int r = 0; r < PER; r++) issue1(gs, r);
+        }
+#pragma unroll
+        for (int r = 0; r < PER; r++) convert1(gs, r);
+        if (G::PREFETCH && s + 1 < G::NSUB) {                      // the next sub-step's loads: in flight over this one's products
+#pragma unroll
+            for (int r = 0; r < PER; r++) issue1(gs + SEG * CS, r);
+        }
+        __syncthreads();
+        for (int ct = wv; ct * 16 < CS; ct += 4) {
+            const int col = 16 * ct + lrow, colr = col < CS ? col : CS - 1;
+            f32x4 acc[2][3];
+#pragma unroll
+            for (int sK = 0; sK < KS; sK++) {
+                const int e = SEG * colr + 32 * sK + 8 * lq;             // element index, a multiple of 8
+                const int w = (e + 8 * (e / SEG)) / 2;
+#pragma unroll
+                for (int rail = 0; rail < 2; rail++) {
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(arr + (rail * NH) * NWD + w));
+                    acc[rail][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bh, sK ? acc[rail][0] : kZero4, 0, 0, 0);
+                    acc[rail][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adl[sK], bh, sK ? acc[rail][1] : kZero4, 0, 0, 0);
+                    if constexpr (!U8) {
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(arr + (rail * NH + 1) * NWD + w));
+                        acc[rail][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adh[sK], bl, sK ? acc[rail][2] : kZero4, 0, 0, 0);
+                    }
+                }
+            }
+            f32x4 yr, yi;
+            if constexpr (U8) { yr = acc[0][0] + acc[0][1]; yi = acc[1][0] + acc[1][1]; }
+            else { yr = acc[0][0] + (acc[0][1] + acc[0][2]); yi = acc[1][0] + (acc[1][1] + acc[1][2]); }
+            if (col < CS)
+                *reinterpret_cast<float4*>(region + 16 * (CS * s + col) + 4 * lq) = make_float4(fast_atan2_turns(yi[0], yr[0]), fast_atan2_turns(yi[1], yr[1]),
+                                                                                                fast_atan2_turns(yi[2], yr[2]), fast_atan2_turns(yi[3], yr[3]));
+        }
+    }
+    FrontOps op;
+    load_front_ops<0>(op, tab, sp, lane, lq);
+    if (tile == 0) {           // the 64 phases in front of the block: the previous block's last ones
+        __syncthreads();
+        if (tid < 64) region[tid] = tail_in[(size_t)c * d.tail_base + d.tail_base - 64 + tid].x;
+    }
+    __syncthreads();
+    if (tile == tiles - 1) {   // the histories the next block starts from: the last 64 input samples, the last tail_base phases
+        if (tid < G::HIST) pre_tail_out[(size_t)c * G::HIST + tid] = load_iq(in_c, (unsigned)(d.N - G::HIST + tid));
+        float2* tout = tail_out + (size_t)c * d.tail_base;
+        for (int idx = tid; idx < d.tail_base; idx += 256) tout[idx] = make_float2(region[G::NPH - d.tail_base + idx], 0.0f);
+    }
+    front_from_phases<1024, 0>(d, region, region + 1, reinterpret_cast<uint32_t*>(region), c, o0, tid, fm_gain, nullptr, op, fo_pl, pv_pl, sp);
 }
 
 // =============================================================================================
@@ -2693,15 +2862,15 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
         if (ctx.deemph_in_tile) {
             using GM = FrontGeomM<TT, kDeemphWarmup>;
             if (pll) FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, kDeemphWarmup, true>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
-                                ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, ctx.b.pv_pl[r.buf], ctx.b.pv_img, ctx.b.sparse_tab, pf);
+                                ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, ctx.b.pv_pl[r.buf], ctx.b.sparse_tab, pf);
             else FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, kDeemphWarmup, false>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
-                            ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, ctx.b.pv_pl[r.buf], ctx.b.pv_img, ctx.b.sparse_tab, pf);
+                            ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, ctx.b.pv_pl[r.buf], ctx.b.sparse_tab, pf);
         } else {
             using GM = FrontGeomM<TT, 0>;
             if (pll) FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, 0, true>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
-                                ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, ctx.b.pv_pl[r.buf], ctx.b.pv_img, ctx.b.sparse_tab, pf);
+                                ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, ctx.b.pv_pl[r.buf], ctx.b.sparse_tab, pf);
             else FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, 0, false>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
-                            ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, ctx.b.pv_pl[r.buf], ctx.b.pv_img, ctx.b.sparse_tab, pf);
+                            ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, ctx.b.pv_pl[r.buf], ctx.b.sparse_tab, pf);
         }
         return hipGetLastError();
     }
@@ -2746,8 +2915,44 @@ hipError_t launch_stage_predecim(const LaunchCtx& ctx, SlotRef r, const void* d_
     return m == 4 ? launch_predecim<4, float2>(ctx, r, p, s) : launch_predecim<8, float2>(ctx, r, p, s);
 }
 
+// 1.024 / 2.048 MSa/s, tolerance mode: the first decimator inside the front end's kernel (k_front_pre_mfma) — the block then has no
+// predecim stage and launch_stage_front takes the capture.  Not with a de-emphasised station (k_front_mfma's WU form stays on fm_in).
+bool front_takes_capture(const LaunchCtx& ctx) {
+    static const bool off = dev_env("FMD_NO_FRONT_PRE") != nullptr;      // (A/B hook)
+    return ctx.d.m > 1 && ctx.fast && !ctx.any_deemph && !ctx.deemph_in_tile && ctx.d.n_fm_out % 1024 == 0 && !off && !ctx.split_front;
+}
+
+template <int M, typename InT>
+static hipError_t launch_front_pre(const LaunchCtx& ctx, SlotRef r, const InT* d_iq, hipStream_t s, const SlotRef* pll) {
+    using G = FrontPreGeom<M, sizeof(InT) == 2>;
+    const Dims& d = ctx.d;
+    PllFusedArgs pf{};
+    if (pll) {
+        const int nxt = (pll->buf + 1) % kSlots;
+        pf = PllFusedArgs{(d.C + 31) / 32, ctx.b.pv_pl[pll->buf], ctx.b.pv_hist[pll->par], ctx.b.pv_hist[pll->par ^ 1], ctx.b.fo_pl[pll->buf], ctx.b.fo_pl[nxt],
+                          ctx.b.pll_poly[pll->buf], ctx.b.pll_poly[nxt], ctx.b.state, ctx.loops, ctx.b.sparse_tab, ctx.b.spec_stats};
+    }
+    const unsigned grid = (unsigned)(d.n_fm_out / 1024 * d.C + pf.n_wg);
+    if (pll) FMD_LAUNCH(r, true, true, (k_front_pre_mfma<M, InT, true>), dim3(grid), dim3(256), sizeof(float) * G::LDS_WORDS, s, d, d_iq, ctx.b.pre_tail[r.par], ctx.b.pre_tail[r.par ^ 1],
+                        ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.front_mfma + kFrontImgU4, ctx.b.front_mfma,
+                        ctx.b.pv_pl[r.buf], ctx.b.sparse_tab, pf);
+    else FMD_LAUNCH(r, true, true, (k_front_pre_mfma<M, InT, false>), dim3(grid), dim3(256), sizeof(float) * G::LDS_WORDS, s, d, d_iq, ctx.b.pre_tail[r.par], ctx.b.pre_tail[r.par ^ 1],
+                    ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.front_mfma + kFrontImgU4, ctx.b.front_mfma,
+                    ctx.b.pv_pl[r.buf], ctx.b.sparse_tab, pf);
+    return hipGetLastError();
+}
+
 // k_front on the 256 kSa/s stream: the capture itself (m == 1) or fm_in[slot]
 hipError_t launch_stage_front(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s, const SlotRef* pll) {
+    if (front_takes_capture(ctx)) {
+        const int m = ctx.d.m;
+        if (u8) {
+            const uchar2* p = static_cast<const uchar2*>(d_iq);
+            return m == 4 ? launch_front_pre<4, uchar2>(ctx, r, p, s, pll) : launch_front_pre<8, uchar2>(ctx, r, p, s, pll);
+        }
+        const float2* p = static_cast<const float2*>(d_iq);
+        return m == 4 ? launch_front_pre<4, float2>(ctx, r, p, s, pll) : launch_front_pre<8, float2>(ctx, r, p, s, pll);
+    }
     if (ctx.d.m > 1) {
         LaunchCtx c1 = ctx;
         c1.d.N = ctx.d.n_fm_in; c1.d.m = 1;

@@ -60,6 +60,10 @@ int fmd_get_spec_stats(fmd_handle h, uint64_t* out8, int reset);
 /* on = 0: off; 1: timing events on every kernel of every block; 2: the dominant kernel every block, the others every 4th;
  * 3: every kernel of every 4th block plus the dominant kernel of the block behind it (what bench.py uses: ~1 % of the step) */
 int fmd_profile_enable(fmd_handle h, int on);
+/* 1.024 / 2.048 MSa/s, tolerance mode: on = 1 runs the first decimator and the front end as the two kernels they were (k_predecim_mfma,
+ * k_front_mfma with fm_in through HBM) instead of k_front_pre_mfma; results are bit-identical either way (tests/test_gpu_fast.py).
+ * Between blocks only. */
+int fmd_debug_split_front(fmd_handle h, int on);
 int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out);
 
 #ifdef __cplusplus

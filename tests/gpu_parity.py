@@ -26,11 +26,13 @@ def oracle_controls(ctl) -> O.Controls:
 
 
 def run_gpu(pkg, caps: np.ndarray, block_size: int, fs: int, use_torch: bool = False, controls=None, per_channel_controls=None,
-            pll_kernel: str = "auto", fast_math: bool = False):
+            pll_kernel: str = "auto", fast_math: bool = False, split_front: bool = False):
     """caps: [C, n, 2] float32 or uint8.  Returns dict of per-block concatenated streams [C, ...]."""
     n_ch = caps.shape[0]
     nb = caps.shape[1] // block_size
     dm = pkg.BatchDemod(n_ch, block_size, fs, keep_taps=True, pll_kernel=pll_kernel, fast_math=fast_math)
+    if split_front:       # (include/fmdemod_debug.h: the first decimator and the front end as two kernels)
+        assert dm.L.fmd_debug_split_front(dm.h, 1) == 0
     if controls is not None:
         dm.set_controls(controls)
     if per_channel_controls:

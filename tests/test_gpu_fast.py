@@ -218,6 +218,26 @@ def test_fast_mode_is_within_the_north_star_tolerance_of_the_oracle(pkg, fs, u8)
     record_parity_metrics(f"fast_vs_oracle_12_blocks_fs{fs}_{'u8' if u8 else 'cf32'}", {k: float(v) for k, v in worst.items()})
 
 
+@pytest.mark.parametrize("fs,u8", [(1_024_000, False), (1_024_000, True), (2_048_000, False), (2_048_000, True)])
+def test_fast_mode_fused_first_decimator_is_bit_identical_to_the_two_kernels(pkg, fs, u8):
+    """k_front_pre_mfma (first decimator + front end in one kernel, fm_in in LDS) against k_predecim_mfma + k_front_mfma with fm_in
+    through HBM (fmd_debug_split_front): the same arithmetic per phase and per fm_out sample, so EVERY output stream is bit-identical,
+    over several blocks (the histories both forms keep: 64 input samples, 319 phases) and for one- and many-tile blocks."""
+    for bs in (fs * 64 // 1000, 8192 * (fs // 256_000)):        # 8 tiles of 1024 fm_out samples / one tile
+        nb = 5
+        caps = _caps(3, nb * bs, float(fs), seed=9400 + (1 if u8 else 0), u8=u8)
+        a = run_gpu(pkg, caps, bs, fs, fast_math=True)
+        b = run_gpu(pkg, caps, bs, fs, fast_math=True, split_front=True)
+        for k in a:
+            if k == "coeffs":
+                continue
+            if isinstance(a[k], np.ndarray):
+                assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), (k, bs)
+            else:
+                for x, y in zip(a[k], b[k]):
+                    assert np.array_equal(np.asarray(x).view(np.uint8), np.asarray(y).view(np.uint8)), (k, bs)
+
+
 def test_fast_mode_first_decimator_small_tile_and_format_switch(pkg):
     """k_predecim_mfma's 256-output tiles (u8 blocks that are no multiple of its 2048-output tile: 12288 samples at 1.024 MSa/s), and a
     handle fed u8 blocks and cf32 blocks in turn (the first decimator's history is kept as cf32 whatever the capture's format):

@@ -229,20 +229,23 @@ def test_release_outputs_holds_a_slot_for_a_slow_consumer(pkg, fast, n_ch, submi
     dm.close()
 
 
-def test_submit_schedule_and_output_lag_in_the_tolerance_mode(pkg):
-    """fmd_submit_*_dev on a batch large enough for the deferred schedule (the extract stage of block k queued behind the front end of
+@pytest.mark.parametrize("fs,n_ch,bs,u8", [(256_000, 3072, 16384, False), (1_024_000, 1024, 65536, False), (1_024_000, 1024, 65536, True)])
+def test_submit_schedule_and_output_lag_in_the_tolerance_mode(pkg, fs, n_ch, bs, u8):
+    """(1.024 MSa/s: the schedule with the front end — k_front_pre_mfma, the previous block's pilot stage riding it — on the capture's
+    queue and the extract stages on the front end's.)
+    fmd_submit_*_dev on a batch large enough for the deferred schedule (the extract stage of block k queued behind the front end of
     block k + 1, include/fmdemod.h fmd_set_output_lag): every block's outputs equal those of the block-by-block run, whichever way the
     caller asks for them —
       default: wait_outputs right after submit(k) gives block k (and switches the handle to queue-at-submission);
       a free-running caller gets the last block after synchronize();
       fmd_set_output_lag(1): the device views after submit(k) are block k - 1's, block k's after synchronize()."""
     import torch
-    n_ch, bs, nb = 3072, 16384, 9
-    base = _caps(4, nb * bs, 256_000.0, seed=6300)
+    nb = 9
+    base = _caps(4, nb * bs, float(fs), seed=6300, u8=u8)
     idx = torch.from_numpy(np.arange(n_ch) % 4).cuda()
     dbase = torch.from_numpy(base).cuda()
     blocks = [dbase[:, b * bs:(b + 1) * bs][idx].contiguous() for b in range(nb)]
-    ref = pkg.BatchDemod(n_ch, bs, 256_000, pipelined=False, fast_math=True)
+    ref = pkg.BatchDemod(n_ch, bs, fs, pipelined=False, fast_math=True)
     want, want_bytes = [], []
     for b in range(nb):
         ref.process(blocks[b])
@@ -255,7 +258,7 @@ def test_submit_schedule_and_output_lag_in_the_tolerance_mode(pkg):
         return np.array_equal(t.cpu().numpy().view(np.uint32), want[b].view(np.uint32))
 
     # free-running: nothing asked for until the end
-    dm = pkg.BatchDemod(n_ch, bs, 256_000, fast_math=True)
+    dm = pkg.BatchDemod(n_ch, bs, fs, fast_math=True)
     for b in range(nb):
         dm.submit(blocks[b])
     dm.synchronize()
@@ -264,7 +267,7 @@ def test_submit_schedule_and_output_lag_in_the_tolerance_mode(pkg):
     assert np.array_equal(cnt, want_bytes[-1][1]) and np.array_equal(by, want_bytes[-1][0])
     dm.close()
     # default: the newest block's outputs on request
-    dm = pkg.BatchDemod(n_ch, bs, 256_000, fast_math=True)
+    dm = pkg.BatchDemod(n_ch, bs, fs, fast_math=True)
     kept = {}
     for b in range(nb):
         dm.submit(blocks[b])
@@ -278,7 +281,7 @@ def test_submit_schedule_and_output_lag_in_the_tolerance_mode(pkg):
         assert same(t, b), b
     dm.close()
     # lag: the newest queued outputs, never forcing
-    dm = pkg.BatchDemod(n_ch, bs, 256_000, fast_math=True)
+    dm = pkg.BatchDemod(n_ch, bs, fs, fast_math=True)
     dm.set_output_lag(True)
     kept = {}
     for b in range(nb):
@@ -296,7 +299,7 @@ def test_submit_schedule_and_output_lag_in_the_tolerance_mode(pkg):
     assert np.array_equal(dm.audio().view(np.uint32), want[-1].view(np.uint32))
     dm.close()
     # fmd_submit_* and fmd_process_* mixed, a control change and a state snapshot in between: the put-off stages are queued first
-    dm = pkg.BatchDemod(n_ch, bs, 256_000, fast_math=True)
+    dm = pkg.BatchDemod(n_ch, bs, fs, fast_math=True)
     for b in range(nb):
         if b in (2, 5, 6):
             dm.process(blocks[b])
