@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -118,6 +119,78 @@ __global__ __launch_bounds__(256) void k_channelize16(ChanDims d, const float2* 
     }
 }
 
+// L == 16 on the matrix cores (round 4).  The 16 consecutive outputs o = 16 g + m of a "group" g use each polyphase branch once
+// (p = m M mod 16) and read the input window x[g M - (T - 1) + tau], tau < K = floor(15 M / 16) + T (1225 at 625 / 640):
+//     y[16 g + m] = sum_tau A[m][tau] x[g M - (T - 1) + tau],   A[m][tau] = h[p(m) + 16 t],  t = floor(m M / 16) + T - 1 - tau  (0 <= t < T, else 0)
+// — one banded 16 x K operand for EVERY group of every station (52 % dense).  D = A X with X's columns = the windows of a tile's 8 groups,
+// real rail in columns 0-7 and imaginary rail in 8-15: v_mfma_f32_16x16x4_f32 (fp32 operands, fp32 accumulation: the arithmetic of the
+// VALU form, no bf16 split; a column's window starts at any sample, operand reads are single floats).  Wavefront w holds its quarter of
+// A's K-steps in registers (77 floats per lane) for every tile the workgroup takes; the four partial tiles meet in LDS.
+// The VALU form above read every staged sample from LDS once per tap (2 FMAs per 8-byte read, 2-4-way bank conflicts): here a read
+// feeds 16 rows, and the rails' column strides (M = 625 floats, rails 5608 apart) put a wavefront's 32-lane passes on distinct banks.
+constexpr int kMG = 8;                      // groups (of 16 outputs) per tile: kTile outputs
+constexpr int kMKW = 77;                    // K-steps of 4 per wavefront: K <= 4 * 4 * 77 = 1232
+constexpr int kMK = 16 * kMKW;              // 1232
+constexpr int kMRail = 5608;                // floats per rail: (kMG - 1) M + kMK <= 5608, and 5608 mod 32 == 8 (bank offset between the rails)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 3) void k_channelize16_mfma(ChanDims d, const float2* __restrict__ win, const float* __restrict__ atab /* [4][77][64] */,
+                                                           const unsigned long long* __restrict__ phase_inc, float2* __restrict__ out, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xr = smem;                       // mixed window, real rail: xr[i] = Re x_k[n_lo + i]
+    float* xi = smem + kMRail;
+    float* part = smem + 2 * kMRail;        // [wavefront][column][row]
+    const int k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 15, kq = lane >> 4;
+    float a[kMKW];
+#pragma unroll
+    for (int j = 0; j < kMKW; j++) a[j] = atab[(size_t)(wv * kMKW + j) * 64 + lane];
+    const unsigned long long inc = phase_inc[k];
+    // the phase advance between a thread's consecutive samples (stride 256): see stage_mixed
+    float ss, cs;
+    sincospif((float)(unsigned int)((256ull * inc) >> 32) * 4.656612873077393e-10f, &ss, &cs);
+    const float* xb = ((col >> 3) ? xi : xr) + d.M * (col & 7) + kq + 4 * kMKW * wv;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long tile0 = (long long)tile * kTile;
+        const int n_tile = (int)((d.n_out - tile0) < kTile ? (d.n_out - tile0) : kTile);
+        const unsigned long long o_first = d.o0 + (unsigned long long)tile0;                  // a multiple of 16
+        const unsigned long long n_lo = (o_first * (unsigned long long)d.M) / 16ull - (unsigned long long)(d.T - 1);
+        const int n_valid = (int)(((o_first + (unsigned long long)(n_tile - 1)) * (unsigned long long)d.M) / 16ull - n_lo) + 1;   // samples that exist
+        {
+            float s, c;
+            sincospif((float)(unsigned int)(((n_lo + (unsigned long long)tid) * inc) >> 32) * 4.656612873077393e-10f, &s, &c);
+            const float2* src = win + (n_lo - d.n_base);
+            constexpr int PER = (kMRail + 255) / 256;
+            float2 x[PER];
+#pragma unroll
+            for (int r = 0; r < PER; r++) { const int i = tid + 256 * r; x[r] = (i < n_valid) ? src[i] : make_float2(0.f, 0.f); }
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+                const int i = tid + 256 * r;
+                if (i < kMRail) { xr[i] = fmaf(x[r].x, c, x[r].y * s); xi[i] = fmaf(x[r].y, c, -(x[r].x * s)); }   // x * (cos - j sin)
+                const float cn = fmaf(c, cs, -(s * ss)), sn = fmaf(s, cs, c * ss);
+                c = cn; s = sn;
+            }
+        }
+        __syncthreads();
+        f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < kMKW; j++) {
+            if (j & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], xb[4 * j], acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], xb[4 * j], acc0, 0, 0, 0);
+        }
+        acc0 = acc0 + acc1;
+        *reinterpret_cast<float4*>(part + (wv * 16 + col) * 16 + 4 * kq) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+        __syncthreads();
+        if (tid < n_tile) {
+            const int g = tid >> 4, m = tid & 15;
+            float re = 0.f, im = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; w++) { re += part[(w * 16 + g) * 16 + m]; im += part[(w * 16 + 8 + g) * 16 + m]; }
+            out[(size_t)k * d.out_stride + tile0 + tid] = make_float2(re, im);
+        }
+    }
+}
+
 // any L <= 64: one output per thread (the first 128 threads), taps read from global memory
 __global__ __launch_bounds__(256) void k_channelize(ChanDims d, const float2* __restrict__ win, const float* __restrict__ taps /* [T][L] */,
                                                     const unsigned long long* __restrict__ phase_inc /* [C], turns * 2^64 per input sample */,
@@ -173,6 +246,7 @@ struct fmd_channelizer_s {
     hipEvent_t done = nullptr;        // end of the previous call's work, for callers that change streams between calls
     bool have_done = false;
     float* taps = nullptr;            // [T][L]
+    float* atab = nullptr;            // k_channelize16_mfma's operand A, per wavefront, K-step and lane; null: that form does not apply
     unsigned long long* inc = nullptr;
     std::vector<float> h_taps;
     std::string err;
@@ -247,6 +321,20 @@ int fmd_chan_create(const fmd_chan_config* cfg, fmd_channelizer* out) {
     for (int i = 0; i < 2; i++) ok = ok && hipMemset(h->win[i], 0, sizeof(float2) * (h->max_in + (size_t)T)) == hipSuccess;
     ok = ok && hipMemcpy(h->taps, h->h_taps.data(), sizeof(float) * h->h_taps.size(), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(h->inc, inc.data(), sizeof(unsigned long long) * h->C, hipMemcpyHostToDevice) == hipSuccess;
+    // the matrix-core form: L == 16 and the operand / window sizes it is built for (10 MSa/s -> 256 kSa/s with 640 taps per phase)
+    if (ok && L == 16 && (15 * M) / 16 + T <= kMK && (kMG - 1) * M + kMK <= kMRail && !getenv("FMD_CHAN_VALU")) {
+        std::vector<float> at((size_t)4 * kMKW * 64, 0.0f);
+        for (int w = 0; w < 4; w++)
+            for (int j = 0; j < kMKW; j++)
+                for (int l = 0; l < 64; l++) {
+                    const int m = l & 15, tau = 4 * (kMKW * w + j) + (l >> 4);
+                    const int t = (m * M) / 16 + (T - 1) - tau, p = (m * M) % 16;
+                    if (t >= 0 && t < T) at[((size_t)w * kMKW + j) * 64 + l] = h->h_taps[(size_t)t * L + p];
+                }
+        ok = hipMalloc(&h->atab, sizeof(float) * at.size()) == hipSuccess &&
+             hipMemcpy(h->atab, at.data(), sizeof(float) * at.size(), hipMemcpyHostToDevice) == hipSuccess &&
+             hipFuncSetAttribute(reinterpret_cast<const void*>(k_channelize16_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * (2 * kMRail + 4 * 256))) == hipSuccess;
+    }
     if (!ok) { fmd_chan_destroy(h); return chan_fail(nullptr, FMD_ERR_DEVICE, "device allocation failed"); }
     *out = h;
     return FMD_OK;
@@ -258,6 +346,7 @@ int fmd_chan_destroy(fmd_channelizer h) {
     for (int i = 0; i < 2; i++) if (h->win[i]) (void)hipFree(h->win[i]);
     if (h->done) (void)hipEventDestroy(h->done);
     if (h->taps) (void)hipFree(h->taps);
+    if (h->atab) (void)hipFree(h->atab);
     if (h->inc) (void)hipFree(h->inc);
     delete h;
     return FMD_OK;
@@ -304,7 +393,14 @@ int fmd_chan_process_cf32_dev(fmd_channelizer h, const float* d_wide, size_t n_i
     if (hipMemcpyAsync(win + (T - 1), d_wide, sizeof(float2) * n_in, hipMemcpyDeviceToDevice, s) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "staging copy failed");
     ChanDims d{h->L, h->M, T, h->C, (long long)no, (long long)out_capacity_per_station, h->o_abs, h->n_abs - (unsigned long long)(T - 1)};
     // outputs o0 .. o0+no-1 need inputs up to floor((o0+no-1) M / L) <= n_abs + n_in - 1 by construction
-    if (h->L == 16 && T % 64 == 0 && T <= 1024)
+    if (h->atab) {
+        // every workgroup keeps its operand registers over several tiles: about three workgroups per CU in all
+        const int n_tiles = (int)((no + kTile - 1) / kTile);
+        int gx = (3 * 256) / h->C;
+        gx = gx < 1 ? 1 : (gx > n_tiles ? n_tiles : gx);
+        hipLaunchKernelGGL(k_channelize16_mfma, dim3((unsigned)gx, (unsigned)h->C), dim3(256), sizeof(float) * (2 * kMRail + 4 * 256), s, d, win, h->atab, h->inc,
+                           reinterpret_cast<float2*>(d_out), n_tiles);
+    } else if (h->L == 16 && T % 64 == 0 && T <= 1024)
         hipLaunchKernelGGL(k_channelize16, dim3((unsigned)((no + kTile - 1) / kTile), (unsigned)h->C), dim3(256), 0, s, d, win, h->taps, h->inc,
                            reinterpret_cast<float2*>(d_out));
     else
