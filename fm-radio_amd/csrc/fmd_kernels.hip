@@ -21,7 +21,7 @@
 //                              (fmd_kernels_fast.inc)                                          -> one cubic per span (pll_poly)
 //   k_extract_mfma [parallel]  a5 Hilbert FIR, a9 mixers, a10 / a12 decimating FIRs (matrix cores), a11, a15, the RDS AGC's
 //                              block power as per-tile partial sums                            -> audio, rds, lmr_est, rds_pow
-//   k_rds_sync3    [serial]    a13, a14, Manchester decode: the loop pipelined over three wavefronts (fmd_kernels_fast.inc)
+//   k_rds_sync3    [serial]    a13, a14, Manchester decode: the loop pipelined over four wavefronts (fmd_kernels_fast.inc)
 //
 // Arithmetic contract of the EXACT mode: this file is compiled with -ffp-contract=off; every fused multiply-add is an
 // explicit fmaf() and every sum is associated exactly as the reference's AVX2+FMA build associates it
@@ -3073,6 +3073,13 @@ hipError_t launch_lmr_phase_peek(const LaunchCtx& ctx, int par, float* out_row, 
     return hipGetLastError();
 }
 
+#ifdef FMD_RDS_PROBE
+}  // namespace fmd
+extern "C" int fmd_debug_read_rds_probe(unsigned long long* out16) {
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(fmd::g_rds_probe), 16 * sizeof(unsigned long long));
+}
+namespace fmd {
+#endif
 hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
@@ -3080,7 +3087,7 @@ hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
         const bool partials = d.n_audio % 256 == 0;       // k_extract_mfma ran and left the block's power as 2 partial sums per tile
         static const bool two_waves = dev_env("FMD_RDS_TWO_WAVES") != nullptr;      // (A/B hook: the two-wavefront form)
         if (partials && !two_waves) {      // the loop split over mixer, clock and dump wavefronts (fmd_kernels_fast.inc)
-            FMD_LAUNCH(r, true, true, k_rds_sync3, dim3(serial_waves(d)), dim3(4 * kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
+            FMD_LAUNCH(r, true, true, k_rds_sync3, dim3(serial_waves(d)), dim3(5 * kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
                        b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps,
                        b.rds_pow[r.buf], 2 * (d.n_audio / 256));
             return hipGetLastError();
