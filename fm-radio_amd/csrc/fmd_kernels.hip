@@ -2142,11 +2142,12 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
                 for (int u = 0; u < 2; u++) {
                     const float xr = u ? re2.y : re2.x, xi = u ? im2.y : im2.x, t = u ? dv[r].y : dv[r].x;
                     const float c1 = fast_cos_turns(t), s1 = fast_sin_turns(t);
+                    // x e^{j 2 t} once; the 38 kHz rail turns it by the L-R offset, the 57 kHz rail by e^{j t} once more (16 operations a
+                    // sample instead of the 20 of forming e^{j(2 t + off)} and e^{j 3 t} first)
                     const float c2 = fmaf(c1, c1, -(s1 * s1)), s2 = (c1 + c1) * s1;
-                    const float c2o = fmaf(c2, co, -(s2 * so)), s2o = fmaf(s2, co, c2 * so);
-                    const float c3 = fmaf(c2, c1, -(s2 * s1)), s3 = fmaf(s2, c1, c2 * s1);
-                    m2r[u] = fmaf(c2o, xr, -(xi * s2o)); m2i[u] = fmaf(c2o, xi, xr * s2o);
-                    m3r[u] = fmaf(c3, xr, -(xi * s3)); m3i[u] = fmaf(c3, xi, xr * s3);
+                    const float yr = fmaf(c2, xr, -(xi * s2)), yi = fmaf(c2, xi, xr * s2);
+                    m2r[u] = fmaf(co, yr, -(yi * so)); m2i[u] = fmaf(co, yi, yr * so);
+                    m3r[u] = fmaf(c1, yr, -(yi * s1)); m3i[u] = fmaf(c1, yi, yr * s1);
                 }
                 uint32_t h0, l0, h1, l1;
                 if (e < XSP) {
