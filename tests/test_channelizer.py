@@ -106,6 +106,30 @@ def test_kernel_matches_float64_definition_and_streams(pkg):
 
 
 @pytest_gpu
+@pytest.mark.parametrize("fs_out,tpp,form", [(256e3, 512, "16 branches on the VALU (k_channelize16)"), (200e3, 128, "one output per thread (k_channelize)")])
+def test_the_other_kernel_forms_match_the_float64_definition(pkg, fs_out, tpp, form):
+    """The default configuration (16 / 625, 640 taps per phase) runs k_channelize16_mfma; other tap counts and rate pairs keep the
+    VALU forms.  Same check as above, incl. a call that ends in a partial tile."""
+    import torch
+    rng = np.random.default_rng(4)
+    taps, L, M = pkg.chan_design(FS_IN, fs_out, tpp)
+    n_in = M * (200 // L + 3) * (16 // np.gcd(16, L))
+    x = (rng.standard_normal(n_in) + 1j * rng.standard_normal(n_in)).astype(np.complex64)
+    centers = np.array([-3.1e6, 0.0, 2.2e6])
+    ch = pkg.Channelizer(FS_IN, centers, fs_out=fs_out, max_input_samples=n_in, taps_per_phase=tpp)
+    assert (ch.interp, ch.decim) == (L, M)
+    xt = torch.from_numpy(np.ascontiguousarray(x).view(np.float32).reshape(-1, 2)).cuda()
+    y = ch.process(xt).cpu().numpy()
+    y = y[..., 0] + 1j * y[..., 1]
+    for k, f in enumerate(centers):
+        ref = ref_channelize(x, f, ch.taps(), L, M)
+        assert y.shape[1] == ref.size
+        err = np.abs(y[k] - ref).max() / np.abs(ref).max()
+        assert err < 2e-5, (form, k, err)
+    ch.close()
+
+
+@pytest_gpu
 def test_tone_lands_only_in_its_station(pkg):
     import torch
     n_in = 625 * 128
