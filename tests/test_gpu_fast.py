@@ -316,12 +316,15 @@ def test_fast_mode_de_emphasis_inside_the_front_tile(pkg, fs, bs):
             assert same_bits_once_in_lock(g["rds_bytes"][c], o["rds_bytes"], skip_bits=12 * 76), (sorted(per), c)   # (a symbol slipped during acquisition re-pairs the Manchester decoder 0.5 s later)
 
 
-def test_fast_mode_de_emphasis_switched_on_and_off_between_blocks(pkg):
-    """Controls take effect at the next block boundary; the in-tile filter has no state of its own, so on L+R (no loop in its
+@pytest.mark.parametrize("fs,bs", [(256_000, 16384), (1_024_000, 32768)])
+def test_fast_mode_de_emphasis_switched_on_and_off_between_blocks(pkg, fs, bs):
+    """(1.024 MSa/s: the blocks with the filter on run the two kernels k_predecim_mfma + k_front_mfma, the others k_front_pre_mfma —
+    both keep both histories, 64 input samples and 319 phases, so a handle changes form between any two blocks.)
+    Controls take effect at the next block boundary; the in-tile filter has no state of its own, so on L+R (no loop in its
     path: the pilot PLL and the L-R phase offset, which see the filtered multiplex, take many blocks to move over) a channel that
     switches it on (or off) mid-stream is, from that block on, what a run with the filter always on (off) gives."""
     from fm_radio_amd.capi import default_controls
-    bs, fs, nb = 16384, 256_000, 6
+    nb = 6
     caps = _caps(2, nb * bs, float(fs), seed=9600)
     on = default_controls(); on.use_deemphasis = 1; on.deemphasis_tus = 50
     off = default_controls()
