@@ -1997,6 +1997,14 @@ struct ExtractGeomM {
     static_assert(WNP % 32 == 0 && WNP >= 16 * 79 + 64 + 24 + 8, "reach of the Hilbert operand");
 };
 
+#ifdef FMD_X_PROBE
+// development probe (tools/dbg/x_probe.py): cycles between the barriers of k_extract_mfma, summed over sampled workgroups (wavefronts 0 and 3), and their count
+__device__ unsigned long long g_x_probe[16];
+#define X_STAMP(i_) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (xp_on && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 3)) \
+    atomicAdd(&g_x_probe[(i_) + ((threadIdx.x >> 6) ? 8 : 0)], t_ - xp_t); xp_t = t_; } while (0)
+#else
+#define X_STAMP(i_)
+#endif
 __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __restrict__ fo_pl, const uint4* __restrict__ hil_img,
                                                       const float4* __restrict__ pll_poly,
                                                       const uint4* __restrict__ aud_img, const int2* __restrict__ aud_idx, const uint4* __restrict__ rds_img,
@@ -2025,6 +2033,11 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
     const int lane = tid & (kWave - 1), wv = tid >> 6, lrow = lane & 15, lq = lane >> 4;
     const int s_lo = 4 * i0 - 124;               // first analytic sample staged (block relative), even
     const int n = d.n_fm_out;
+#ifdef FMD_X_PROBE
+    const bool xp_on = (blockIdx.x % 61) == 0;
+    unsigned long long xp_t = __builtin_readcyclecounter();
+    if (xp_on && threadIdx.x == 0) atomicAdd(&g_x_probe[7], 1ull);
+#endif
     // the plane's rows carry the previous block's tail in front (k_pll_span): history and block are addressed alike.
     // Analytic signal: re[s] = fm_out[s - 32], im[s] = sum_k b[k] fm_out[s - 64 + k] (reference hilbert FIR, broadcast_fm_demod.cpp:261-275
     // as k_front makes it in exact mode); NCO phase: the span's cubic (PllSpanTab)
@@ -2049,16 +2062,18 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
             const int e = 2 * (tid + 256 * r);
             if (e + 32 < G::WN) wv2[r] = *reinterpret_cast<const float2*>(fo_c + (s_lo - 32 + e));
         }
-        if (tid < 16) wh2 = *reinterpret_cast<const float2*>(fo_c + (s_lo - 64 + 2 * tid));
+        // (the odd jobs of the staging and of the next phase are spread over the wavefronts: with all of them on wavefront 0 the other
+        //  three waited ~1000 cycles at each of the first two barriers, tools/dbg/x_probe.py)
+        if (wv == 1 && lane < 16) wh2 = *reinterpret_cast<const float2*>(fo_c + (s_lo - 64 + 2 * lane));
 #pragma unroll
         for (int r = 0; r < PERP; r++) {
             const int e = 2 * (tid + 256 * r);
             if (e < XS) pv[r] = po_c[(s_lo + e) >> 7];          // (span -1: the previous block's last)
         }
-        if (lmr_est_prev && tid < kWave) {
+        if (lmr_est_prev && wv == 3) {
 #pragma unroll
             for (int k = 0; k < kLmrInlineMax / kWave; k++)
-                ev[k] = (tid + kWave * k < d.n_est) ? lmr_est_prev[(size_t)c * d.n_est + tid + kWave * k] : 0.0f;
+                ev[k] = (lane + kWave * k < d.n_est) ? lmr_est_prev[(size_t)c * d.n_est + lane + kWave * k] : 0.0f;
         }
         uint32_t h0, l0, h1, l1;
 #pragma unroll
@@ -2070,11 +2085,14 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
                 fow_h[w] = pack_hi16(h0, h1); fow_l[w] = pack_hi16(l0, l1);
             }
         }
-        if (tid < 16) { split_bf16(wh2.x, h0, l0); split_bf16(wh2.y, h1, l1); fow_h[tid] = pack_hi16(h0, h1); fow_l[tid] = pack_hi16(l0, l1); }
+        if (wv == 1 && lane < 16) { split_bf16(wh2.x, h0, l0); split_bf16(wh2.y, h1, l1); fow_h[lane] = pack_hi16(h0, h1); fow_l[lane] = pack_hi16(l0, l1); }
         // zeros behind the window, up to the reach of the Toeplitz operands
-        if (tid < (G::WNP - G::WN) / 2) { const int w = G::pad(G::WN + 2 * tid) >> 1; fow_h[w] = 0u; fow_l[w] = 0u; }
+        static_assert((G::WNP - G::WN) / 2 <= 128, "two wavefronts fill the zeros");
+        if (wv >= 2 && tid - 128 < (G::WNP - G::WN) / 2) { const int w = G::pad(G::WN + 2 * (tid - 128)) >> 1; fow_h[w] = 0u; fow_l[w] = 0u; }
     }
+    X_STAMP(0);
     __syncthreads();
+    X_STAMP(1);
     // the Hilbert FIR (FrontGeomM's form: Y[m][col] = im[16 col + m] = sum_t A[m][t] W[16 col + t], t < 80): 72 columns, five 16-column tiles
     {
         bf16x8 ahh[3], ahl[3];
@@ -2083,8 +2101,8 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
             ahh[sK] = __builtin_bit_cast(bf16x8, hil_img[(sK * 2 + 0) * kWave + lane]);
             ahl[sK] = __builtin_bit_cast(bf16x8, hil_img[(sK * 2 + 1) * kWave + lane]);
         }
-        for (int ct = wv; ct < 5; ct += 4) {
-            const int col = ct * 16 + lrow;
+        for (int it = 0; it < (wv == 2 ? 2 : 1); it++) {           // wavefront 2 takes the fifth (half) tile: 1 and 3 have jobs of their own around this phase
+            const int ct = wv + 2 * it, col = ct * 16 + lrow;
             f32x4 acc, acc1, acc2;
 #pragma unroll
             for (int sK = 0; sK < 3; sK++) {
@@ -2109,16 +2127,18 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
         dv[r] = make_float2(fmaf(fmaf(fmaf(pv[r].w, ua, pv[r].z), ua, pv[r].y), ua, pv[r].x) - fa_,
                             fmaf(fmaf(fmaf(pv[r].w, ub, pv[r].z), ub, pv[r].y), ub, pv[r].x) - fb_);
     }
-    if (lmr_est_prev && tid < kWave) {
+    if (lmr_est_prev && wv == 3) {
         float part = 0.0f;
 #pragma unroll
         for (int k = 0; k < kLmrInlineMax / kWave; k++) part += ev[k];
         float nxt = fmaf(wave_sum_f32(part) * __builtin_amdgcn_rcpf((float)d.n_est), 0.1f, off_prev);
         const float two_pi = bits_f32(kTwoPiBits);
         nxt = (nxt >= two_pi) ? nxt - two_pi : ((nxt <= -two_pi) ? nxt + two_pi : nxt);
-        if (tid == 0) { off_s = nxt; if (tile == 0) st(state, field_cur, d.C, c) = nxt; }
+        if (lane == 0) { off_s = nxt; if (tile == 0) st(state, field_cur, d.C, c) = nxt; }
     }
+    X_STAMP(2);
     __syncthreads();
+    X_STAMP(3);
     if (lmr_est_prev) off_cur = off_s;
     // the zero padding behind the staged samples, up to the reach of the Toeplitz operands
     if (tid < (XSP + 4 - XS) / 2) {
@@ -2163,7 +2183,9 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
             }
         }
     }
+    X_STAMP(4);
     __syncthreads();
+    X_STAMP(5);
 
     const float* taps_lmr = b_lmr + (size_t)c * 128;
     const int est_first = (10 - (i0 % 10)) % 10;   // first output of this tile whose block index is a multiple of 10
@@ -2222,6 +2244,7 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
             res_est_re[u] = (a[0] + a[2]) + (a[1] + a[3]);
         }
     }
+    X_STAMP(6);
     __syncthreads();
 
     {
@@ -3074,6 +3097,13 @@ hipError_t launch_lmr_phase_peek(const LaunchCtx& ctx, int par, float* out_row, 
     return hipGetLastError();
 }
 
+#ifdef FMD_X_PROBE
+}  // namespace fmd
+extern "C" int fmd_debug_read_x_probe(unsigned long long* out16) {
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(fmd::g_x_probe), 16 * sizeof(unsigned long long));
+}
+namespace fmd {
+#endif
 #ifdef FMD_RDS_PROBE
 }  // namespace fmd
 extern "C" int fmd_debug_read_rds_probe(unsigned long long* out16) {
