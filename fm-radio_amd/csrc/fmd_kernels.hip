@@ -1790,9 +1790,20 @@ __device__ __forceinline__ float lmr_phase_finish(float sum, int n_est, float cu
     return fmodf(acc, bits_f32(kTwoPiBits));
 }
 // sum over the 64 lanes of a wavefront, the same value in every lane
+// (the xor butterfly 32, 16, 8, 4, 2, 1 of six __shfl_xor steps — same partner in every step, so the same sum bit for bit — without their
+//  six LDS round trips (ds_bpermute: ~130 cycles each on a lone dependent chain, tools/dbg/x_probe.py): lane-swap and DPP moves)
 __device__ __forceinline__ float wave_sum_f32(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);       // halves of the wavefront change places
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);                                                      // v[i] + v[i ^ 32]
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);            // odd rows of 16 <-> even rows
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);                                                      // + v[i ^ 16]
+    v += dpp0<0x128>(v);                                                                                    // row_ror:8: + v[i ^ 8]
+    {   // + v[i ^ 4]: row_shl:4 into lanes 0-3 and 8-11 of a row, row_shr:4 into the others
+        const int up = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0x5, true);
+        v += __int_as_float(__builtin_amdgcn_update_dpp(up, __float_as_int(v), 0x114, 0xf, 0xA, false));
+    }
+    v += dpp0<0x4E>(v);                                                                                     // quad_perm [2,3,0,1]: + v[i ^ 2]
+    v += dpp0<0xB1>(v);                                                                                     // quad_perm [1,0,3,2]: + v[i ^ 1]
     return v;
 }
 
@@ -2000,6 +2011,9 @@ struct ExtractGeomM {
 #ifdef FMD_X_PROBE
 // development probe (tools/dbg/x_probe.py): cycles between the barriers of k_extract_mfma, summed over sampled workgroups (wavefronts 0 and 3), and their count
 __device__ unsigned long long g_x_probe[16];
+__device__ unsigned long long g_x_probe2[16];
+#define X_STAMP2(i_) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (xp_on && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 3)) \
+    atomicAdd(&g_x_probe2[(i_) + ((threadIdx.x >> 6) ? 8 : 0)], t_ - xp_t2); xp_t2 = t_; } while (0)
 #define X_STAMP(i_) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (xp_on && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 3)) \
     atomicAdd(&g_x_probe[(i_) + ((threadIdx.x >> 6) ? 8 : 0)], t_ - xp_t); xp_t = t_; } while (0)
 #else
@@ -2035,7 +2049,7 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
     const int n = d.n_fm_out;
 #ifdef FMD_X_PROBE
     const bool xp_on = (blockIdx.x % 61) == 0;
-    unsigned long long xp_t = __builtin_readcyclecounter();
+    unsigned long long xp_t = __builtin_readcyclecounter(), xp_t2 = xp_t;
     if (xp_on && threadIdx.x == 0) atomicAdd(&g_x_probe[7], 1ull);
 #endif
     // the plane's rows carry the previous block's tail in front (k_pll_span): history and block are addressed alike.
@@ -2056,11 +2070,25 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
     // the RDS arrays' pad(e - 4) / 2 = w8b + 320 r (floor shifts: also right where 2 tid - 4 < 0 and r > 0)
     const int w4b = G::pad(2 * tid) >> 1, w8b = ((2 * tid - 4) + 8 * ((2 * tid - 4) >> 5)) >> 1;
     float2 wv2[PERP], wh2;
+    bf16x8 ahh[3], ahl[3];      // the Hilbert FIR's operand image: asked for with the other early loads (behind the first barrier its trip to L2 took
+                                // 1000 of the 1700 cycles a tile of that FIR cost, tools/dbg/x_probe.py)
     {
+        // last block's phase estimates FIRST: loads return in order, and these (from HBM: nothing has touched them for a block) were what the
+        // wavefront that integrates them still waited for 3500 cycles later when they were the last ones issued
+        if (lmr_est_prev && wv == 3) {
+#pragma unroll
+            for (int k = 0; k < kLmrInlineMax / kWave; k++)
+                ev[k] = (lane + kWave * k < d.n_est) ? lmr_est_prev[(size_t)c * d.n_est + lane + kWave * k] : 0.0f;
+        }
 #pragma unroll
         for (int r = 0; r < PERP; r++) {
             const int e = 2 * (tid + 256 * r);
             if (e + 32 < G::WN) wv2[r] = *reinterpret_cast<const float2*>(fo_c + (s_lo - 32 + e));
+        }
+#pragma unroll
+        for (int sK = 0; sK < 3; sK++) {
+            ahh[sK] = __builtin_bit_cast(bf16x8, hil_img[(sK * 2 + 0) * kWave + lane]);
+            ahl[sK] = __builtin_bit_cast(bf16x8, hil_img[(sK * 2 + 1) * kWave + lane]);
         }
         // (the odd jobs of the staging and of the next phase are spread over the wavefronts: with all of them on wavefront 0 the other
         //  three waited ~1000 cycles at each of the first two barriers, tools/dbg/x_probe.py)
@@ -2069,11 +2097,6 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
         for (int r = 0; r < PERP; r++) {
             const int e = 2 * (tid + 256 * r);
             if (e < XS) pv[r] = po_c[(s_lo + e) >> 7];          // (span -1: the previous block's last)
-        }
-        if (lmr_est_prev && wv == 3) {
-#pragma unroll
-            for (int k = 0; k < kLmrInlineMax / kWave; k++)
-                ev[k] = (lane + kWave * k < d.n_est) ? lmr_est_prev[(size_t)c * d.n_est + lane + kWave * k] : 0.0f;
         }
         uint32_t h0, l0, h1, l1;
 #pragma unroll
@@ -2093,14 +2116,11 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
     X_STAMP(0);
     __syncthreads();
     X_STAMP(1);
+#ifdef FMD_X_PROBE
+    xp_t2 = __builtin_readcyclecounter();
+#endif
     // the Hilbert FIR (FrontGeomM's form: Y[m][col] = im[16 col + m] = sum_t A[m][t] W[16 col + t], t < 80): 72 columns, five 16-column tiles
     {
-        bf16x8 ahh[3], ahl[3];
-#pragma unroll
-        for (int sK = 0; sK < 3; sK++) {
-            ahh[sK] = __builtin_bit_cast(bf16x8, hil_img[(sK * 2 + 0) * kWave + lane]);
-            ahl[sK] = __builtin_bit_cast(bf16x8, hil_img[(sK * 2 + 1) * kWave + lane]);
-        }
         for (int it = 0; it < (wv == 2 ? 2 : 1); it++) {           // wavefront 2 takes the fifth (half) tile: 1 and 3 have jobs of their own around this phase
             const int ct = wv + 2 * it, col = ct * 16 + lrow;
             f32x4 acc, acc1, acc2;
@@ -2117,6 +2137,9 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
             if (col < XSP / 16) *reinterpret_cast<float4*>(im_f + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
     }
+#ifdef FMD_X_PROBE
+    X_STAMP2(0);
+#endif
     // NCO phases of the pairs: c0 + c1 u + c2 u^2 + c3 u^3 - frac(19 (u + 1) / 128), u = sample within its span (both samples of a pair share one)
     float2 dv[PERP];
 #pragma unroll
@@ -2127,6 +2150,9 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
         dv[r] = make_float2(fmaf(fmaf(fmaf(pv[r].w, ua, pv[r].z), ua, pv[r].y), ua, pv[r].x) - fa_,
                             fmaf(fmaf(fmaf(pv[r].w, ub, pv[r].z), ub, pv[r].y), ub, pv[r].x) - fb_);
     }
+#ifdef FMD_X_PROBE
+    X_STAMP2(1);
+#endif
     if (lmr_est_prev && wv == 3) {
         float part = 0.0f;
 #pragma unroll
@@ -2136,6 +2162,9 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
         nxt = (nxt >= two_pi) ? nxt - two_pi : ((nxt <= -two_pi) ? nxt + two_pi : nxt);
         if (lane == 0) { off_s = nxt; if (tile == 0) st(state, field_cur, d.C, c) = nxt; }
     }
+#ifdef FMD_X_PROBE
+    X_STAMP2(2);
+#endif
     X_STAMP(2);
     __syncthreads();
     X_STAMP(3);
@@ -3101,6 +3130,9 @@ hipError_t launch_lmr_phase_peek(const LaunchCtx& ctx, int par, float* out_row, 
 }  // namespace fmd
 extern "C" int fmd_debug_read_x_probe(unsigned long long* out16) {
     return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(fmd::g_x_probe), 16 * sizeof(unsigned long long));
+}
+extern "C" int fmd_debug_read_x_probe2(unsigned long long* out16) {
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(fmd::g_x_probe2), 16 * sizeof(unsigned long long));
 }
 namespace fmd {
 #endif

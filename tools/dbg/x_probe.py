@@ -23,3 +23,8 @@ for w, off in (("wavefront 0", 0), ("wavefront 3", 8)):
     for i, nme in enumerate(names):
         print(f"   {nme:34s} {v[off + i] / cnt:8.0f} cycles")
 print("sampled workgroups:", cnt)
+out2 = (C.c_ulonglong * 16)()
+if hasattr(dm.L, "fmd_debug_read_x_probe2") and dm.L.fmd_debug_read_x_probe2(out2) == 0:
+    w = list(out2)
+    for nme, off in (("wavefront 0", 0), ("wavefront 3", 8)):
+        print(nme, "inside phase 1: Hilbert tile(s) %.0f, NCO phases %.0f, L-R offset %.0f cycles" % (w[off] / cnt, w[off + 1] / cnt, w[off + 2] / cnt))
