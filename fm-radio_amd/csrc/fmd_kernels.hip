@@ -2215,6 +2215,9 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
     X_STAMP(4);
     __syncthreads();
     X_STAMP(5);
+#ifdef FMD_X_PROBE
+    xp_t2 = __builtin_readcyclecounter();
+#endif
 
     const float* taps_lmr = b_lmr + (size_t)c * 128;
     const int est_first = (10 - (i0 % 10)) % 10;   // first output of this tile whose block index is a multiple of 10
@@ -2222,6 +2225,10 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
         // L+R / L-R: one 16 x 16 tile = the 256 outputs of the workgroup
         const int2 slot = aud_idx[c];
         const uint4* img = aud_img + (size_t)(wv ? slot.y : slot.x) * (6 * 2 * kWave);
+#ifdef FMD_X_PROBE
+        asm volatile("" :: "s"(slot.x), "s"(slot.y));
+        X_STAMP2(3);
+#endif
         // (L+R is the real rail itself: the fm_out window 32 samples on, i.e. one padded group of 40 elements)
         const uint32_t* sh = wv ? lmr_h : fow_h + 20;
         const uint32_t* sl = wv ? lmr_l : fow_l + 20;
@@ -2236,9 +2243,15 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, sK ? acc : kZero4, 0, 0, 0);      // (the first step starts from the constant 0: no registers to clear)
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, sK ? acc1 : kZero4, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, sK ? acc2 : kZero4, 0, 0, 0);
+#ifdef FMD_X_PROBE
+            if (sK == 0) { asm volatile("" :: "v"(acc[0])); X_STAMP2(4); }
+#endif
         }
         acc = acc + (acc1 + acc2);
         *reinterpret_cast<float4*>((wv ? res_lmr : res_lpr) + 16 * lrow + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#ifdef FMD_X_PROBE
+        X_STAMP2(5);
+#endif
     } else if (wv == 2) {
         // RDS: columns 0-7 the real rail's 128 outputs, 8-15 the imaginary rail's
         const int rail = lrow >> 3, colr = lrow & 7;
@@ -2303,6 +2316,9 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
             lmr_est[(size_t)c * d.n_est + (i0 + ii) / 10] = (ph > 0.0f) ? (half_pi - ph) : (-half_pi - ph);
         }
     }
+#ifdef FMD_X_PROBE
+    xp_t2 = xp_t; X_STAMP2(6);
+#endif
 }
 
 // Tolerance mode, FMD_FLAG_KEEP_TAPS (the "fm_out_iq" getter) and block lengths whose audio blocks are not multiples of 256 (those run
