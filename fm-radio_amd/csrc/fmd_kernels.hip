@@ -283,6 +283,13 @@ __device__ __forceinline__ void load_front_ops(FrontOps& op, const uint4* __rest
     }
 }
 
+#ifdef FMD_F_PROBE
+// development probe (tools/dbg/f_probe.py): cycles of the front end's workgroups between their barriers (wavefront 0 of every 61st workgroup)
+__device__ unsigned long long g_f_probe[16];
+#define F_STAMP(i_) do { const unsigned long long t_ = __builtin_readcyclecounter(); if ((blockIdx.x % 61) == 0 && threadIdx.x == 0) atomicAdd(&g_f_probe[i_], t_ - fp_t); fp_t = t_; } while (0)
+#else
+#define F_STAMP(i_)
+#endif
 // The front end from the tile's phases on (k_front_mfma, k_front_pre_mfma): theta[0 .. NW) = the phases (turns) of fm_in samples
 // 2 o0 - TAIL ..., in LDS; dem32 = the 16-byte aligned start of that region, over which the discriminator output is written in place
 // (theta may start up to 8 bytes into it).  All threads of the workgroup, phases complete (a barrier behind the writer).
@@ -297,6 +304,9 @@ __device__ __forceinline__ void front_from_phases(const Dims& d, float* smem, co
     uint32_t* dem_lo32 = dem_hi32 + G::NWB / 2;
     float* fo = smem + G::OFF_FO;
     float4* pv_row = pv_pl + (size_t)c * (d.n_fm_out / 16) + o0 / 16;
+#ifdef FMD_F_PROBE
+    unsigned long long fp_t = __builtin_readcyclecounter();
+#endif
     // phase difference, wrap, scale: two samples per thread and step, split into bf16 halves, in place over the phases
     {
         const float gain_t = fm_gain * bits_f32(kTwoPiBits);           // the discriminator's gain per turn
@@ -317,6 +327,7 @@ __device__ __forceinline__ void front_from_phases(const Dims& d, float* smem, co
                 wh[r] = pack_hi16(h0, h1); wl[r] = pack_hi16(l0, l1);
             }
         }
+        F_STAMP(2);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < PERP; r++) {
@@ -324,7 +335,9 @@ __device__ __forceinline__ void front_from_phases(const Dims& d, float* smem, co
             if (pw < NPW) { dem_hi32[pw] = wh[r]; dem_lo32[pw] = wl[r]; }
         }
     }
+    F_STAMP(3);
     __syncthreads();
+    F_STAMP(4);
     // a3: decimate-by-2 FIR: wavefront w takes the 16-column tiles w, w + 4, ... (a column = 16 consecutive outputs).
     // fm_out goes to its plane undelayed (the rows start with the previous block's tail, k_pll_sparse); the consumers delay it by 32
     // for the real rail and k_extract_mfma makes the Hilbert rail from it.
@@ -368,6 +381,7 @@ __device__ __forceinline__ void front_from_phases(const Dims& d, float* smem, co
             else *reinterpret_cast<float4*>(fo + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
     }
+    F_STAMP(5);
     if constexpr (WU > 0) {
         __syncthreads();
         // a4 in the tile (see k_front): 8 samples per thread from a zero state, end states through LDS, 16 segments of history
@@ -445,6 +459,10 @@ __global__ __launch_bounds__(256, FUSED ? 6 : 5) void k_front_mfma(Dims d, const
 
     FrontOps op;                                                   // (with the other early loads)
     load_front_ops<WU>(op, tab, sp, lane, lq);
+#ifdef FMD_F_PROBE
+    unsigned long long fp_t = __builtin_readcyclecounter();
+    if ((blockIdx.x % 61) == 0 && threadIdx.x == 0) atomicAdd(&g_f_probe[7], 1ull);
+#endif
     // a0-a2: staging, arctangent (all loads first)
     bool staged = false;
     if constexpr (sizeof(InT) == 8) {
@@ -528,7 +546,9 @@ __global__ __launch_bounds__(256, FUSED ? 6 : 5) void k_front_mfma(Dims d, const
             }
         }
     }
+    F_STAMP(0);
     __syncthreads();
+    F_STAMP(1);
     front_from_phases<TT, WU>(d, smem, theta, reinterpret_cast<uint32_t*>(smem), c, o0, tid, fm_gain, deemph, op, fo_pl, pv_pl, sp);
     if (tile == tiles - 1) {
         float2* tout = tail_out + (size_t)c * d.tail_base;
@@ -2050,6 +2070,7 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
 #ifdef FMD_X_PROBE
     const bool xp_on = (blockIdx.x % 61) == 0;
     unsigned long long xp_t = __builtin_readcyclecounter(), xp_t2 = xp_t;
+    const unsigned long long xp_c0 = xp_t, xp_w0 = wall_clock64();
     if (xp_on && threadIdx.x == 0) atomicAdd(&g_x_probe[7], 1ull);
 #endif
     // the plane's rows carry the previous block's tail in front (k_pll_span): history and block are addressed alike.
@@ -2318,6 +2339,7 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
     }
 #ifdef FMD_X_PROBE
     xp_t2 = xp_t; X_STAMP2(6);
+    if (xp_on && threadIdx.x == 0) { atomicAdd(&g_x_probe2[7], __builtin_readcyclecounter() - xp_c0); atomicAdd(&g_x_probe2[15], wall_clock64() - xp_w0); }   // shader cycles / 100 MHz ticks: the clock under this load
 #endif
 }
 
@@ -3142,6 +3164,13 @@ hipError_t launch_lmr_phase_peek(const LaunchCtx& ctx, int par, float* out_row, 
     return hipGetLastError();
 }
 
+#ifdef FMD_F_PROBE
+}  // namespace fmd
+extern "C" int fmd_debug_read_f_probe(unsigned long long* out16) {
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(fmd::g_f_probe), 16 * sizeof(unsigned long long));
+}
+namespace fmd {
+#endif
 #ifdef FMD_X_PROBE
 }  // namespace fmd
 extern "C" int fmd_debug_read_x_probe(unsigned long long* out16) {

@@ -29,3 +29,4 @@ if hasattr(dm.L, "fmd_debug_read_x_probe2") and dm.L.fmd_debug_read_x_probe2(out
     for nme, off in (("wavefront 0", 0), ("wavefront 3", 8)):
         print(nme, "inside phase 1: Hilbert tile(s) %.0f, NCO phases %.0f, L-R offset %.0f cycles" % (w[off] / cnt, w[off + 1] / cnt, w[off + 2] / cnt))
     print("wavefront 0 inside phase 3: the station's image slot %.0f, first product (image + LDS operands there) %.0f, the other 17 products + result store %.0f; barrier 4 + epilogue (both wavefronts) %.0f / %.0f" % (w[3] / cnt, w[4] / cnt, w[5] / cnt, w[6] / cnt, w[14] / cnt))
+    print("workgroup lifetime %.0f cycles = %.2f us: shader clock %.0f MHz under this load" % (w[7] / cnt, w[15] / cnt / 100.0, 100.0 * w[7] / max(w[15], 1)))
