@@ -13,15 +13,18 @@
 //   k_lmr_phase    [tiny]      a11 phase integrate (the next block's k_extract needs it)
 //   k_rds_sync     [serial]    a13 AGC, a14 BPSK synchroniser, Manchester decode   (own stream)
 //
-// Tolerance mode (FMD_FLAG_FAST_MATH) — the same path on four kernels (five at 1.024 / 2.048 MSa/s):
+// Tolerance mode (FMD_FLAG_FAST_MATH) — the same path on four kernels:
 //
-//   k_predecim_mfma [parallel] a0, a1 (first decimator on the matrix cores), a2's arctangent               -> fm_in (phases in turns)
-//   k_front_mfma   [parallel]  a0-a3 (arctangent in turns, decimating FIR on the matrix cores), optional a4 inside the tile -> fm_out plane
-//   k_pll_span     [serial]    a6 peak filter as a scan on the real rail, a7 AGC state, a8 the loop 128 samples at a time
-//                              (fmd_kernels_fast.inc)                                          -> one cubic per span (pll_poly)
+//   k_front_mfma   [parallel]  a0-a3 (arctangent in turns, decimating FIR on the matrix cores), optional a4 inside the tile, the pilot
+//                              stage's column sums                                             -> fm_out plane, pv_pl
+//   k_front_pre_mfma           1.024 / 2.048 MSa/s: a0, a1 (first decimator on the matrix cores, phases kept in LDS), then the same
+//                              (k_predecim_mfma + k_front_mfma<float> with fm_in through HBM when a station is de-emphasised)
+//   k_pll_sparse   [serial]    a6 peak filter as a decimated one-pole, a7 AGC state, a8 the loop at eight points per 128-sample span
+//                              (fmd_kernels_sparse.inc; the first workgroups of the next block's front-end launch on the deferred
+//                              schedule; k_pll_span of fmd_kernels_fast.inc for a station's first 8192 samples)  -> one cubic per span
 //   k_extract_mfma [parallel]  a5 Hilbert FIR, a9 mixers, a10 / a12 decimating FIRs (matrix cores), a11, a15, the RDS AGC's
 //                              block power as per-tile partial sums                            -> audio, rds, lmr_est, rds_pow
-//   k_rds_sync3    [serial]    a13, a14, Manchester decode: the loop pipelined over four wavefronts (fmd_kernels_fast.inc)
+//   k_rds_sync3    [serial]    a13, a14, Manchester decode: the loop pipelined over five wavefronts (fmd_kernels_fast.inc)
 //
 // Arithmetic contract of the EXACT mode: this file is compiled with -ffp-contract=off; every fused multiply-add is an
 // explicit fmaf() and every sum is associated exactly as the reference's AVX2+FMA build associates it
