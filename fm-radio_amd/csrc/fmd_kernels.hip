@@ -270,9 +270,9 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
 // bf16 x 3 matrix product (FrontGeomM above); WU > 0: with the de-emphasis IIR inside the tile (see k_front).  The Hilbert FIR is
 // k_extract_mfma's: the analytic signal never goes through HBM, only fm_out does (4 bytes per sample instead of 8).
 // =============================================================================================
-// The operands a front-end workgroup loads once: the Toeplitz images of the decimating FIR, and this lane's weights in the pilot
-// stage's four column sums (PllSparseTab: new / old half, re / im).
-struct FrontOps { bf16x8 adh[3], adl[3]; float4 wNr, wNi, wOr, wOi; };
+// The operands a front-end workgroup loads once: the Toeplitz images of the decimating FIR, and this lane's element of the operand that
+// makes the pilot stage's four column sums from a tile of outputs (below): rows 0-3 = new.re, new.im, old.re, old.im weights (PllSparseTab)
+struct FrontOps { bf16x8 adh[3], adl[3]; float4 wA; };
 template <int WU>
 __device__ __forceinline__ void load_front_ops(FrontOps& op, const uint4* __restrict__ tab, const PllSparseTab* __restrict__ sp, int lane, int lq) {
 #pragma unroll
@@ -281,8 +281,9 @@ __device__ __forceinline__ void load_front_ops(FrontOps& op, const uint4* __rest
         op.adl[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 1) * kWave + lane]);
     }
     if constexpr (WU == 0) {
-        op.wNr = *reinterpret_cast<const float4*>(&sp->wre[16 + 4 * lq]); op.wNi = *reinterpret_cast<const float4*>(&sp->wim[16 + 4 * lq]);
-        op.wOr = *reinterpret_cast<const float4*>(&sp->wre[4 * lq]); op.wOi = *reinterpret_cast<const float4*>(&sp->wim[4 * lq]);
+        const int r = lane & 15;                 // operand row: which of the four sums (rows 4-15: zero)
+        const float* w = ((r & 1) ? sp->wim : sp->wre) + ((r & 2) ? 0 : 16) + 4 * lq;
+        op.wA = r < 4 ? *reinterpret_cast<const float4*>(w) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -360,24 +361,16 @@ __device__ __forceinline__ void front_from_phases(const Dims& d, float* smem, co
         }
         acc = acc + (acc1 + acc2);
         if constexpr (WU == 0) {
-            // the pilot stage's column sums (k_pll_sparse then reads 16 bytes per column instead of fm_out's 64) from the fp32 outputs in the
-            // accumulators: a lane holds outputs 4 lq .. 4 lq + 3 of its column; its four partial sums meet their column's other three lanes
-            // (16, 32, 48 lanes on) in two swap steps that leave ONE total in each lane.  (Measured against four more rows of the Toeplitz
-            // operand on the matrix cores, bf16 x 3 / x 2 / x 1: this form costs the front end least, DESIGN.md.)
-            const float p0 = fmaf(op.wNr.x, acc[0], fmaf(op.wNr.y, acc[1], fmaf(op.wNr.z, acc[2], op.wNr.w * acc[3])));
-            const float p1 = fmaf(op.wNi.x, acc[0], fmaf(op.wNi.y, acc[1], fmaf(op.wNi.z, acc[2], op.wNi.w * acc[3])));
-            const float p2 = fmaf(op.wOr.x, acc[0], fmaf(op.wOr.y, acc[1], fmaf(op.wOr.z, acc[2], op.wOr.w * acc[3])));
-            const float p3 = fmaf(op.wOi.x, acc[0], fmaf(op.wOi.y, acc[1], fmaf(op.wOi.z, acc[2], op.wOi.w * acc[3])));
-            // v_permlane16_swap: the odd rows (of 16 lanes) of the first operand change places with the even rows of the second
-            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p0), __float_as_uint(p2), false, false);
-            const float s02 = __uint_as_float(r[0]) + __uint_as_float(r[1]);       // even rows: p0 over the row pair; odd rows: p2
-            r = __builtin_amdgcn_permlane16_swap(__float_as_uint(p1), __float_as_uint(p3), false, false);
-            const float s13 = __uint_as_float(r[0]) + __uint_as_float(r[1]);       // even rows: p1; odd rows: p3
-            // v_permlane32_swap: the upper half of the first operand changes places with the lower half of the second
-            r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s02), __float_as_uint(s13), false, false);
-            const float tot = __uint_as_float(r[0]) + __uint_as_float(r[1]);        // rows 0-3: new.re, old.re, new.im, old.im
-            const int idx = ((lq & 1) << 1) | (lq >> 1);
-            if (col < G::NCOL) reinterpret_cast<float*>(pv_row + col)[idx] = tot;
+            // the pilot stage's column sums (k_pll_sparse then reads 16 bytes per column instead of fm_out's 64): S = W Y, W = the four weight
+            // rows (16 x 16, rows 4-15 zero), Y = this tile of fp32 outputs as it lies in the accumulators — four v_mfma_f32_16x16x4_f32
+            // steps, step j taking output rows 4 k + j (lane (column, k) holds exactly acc[j]); the four sums of a column land in ONE lane.
+            // (Was 16 fp32 FMAs per lane and two lane-swap reductions: 26 VALU instructions a tile and the swaps' latency on a kernel that is
+            // HBM- and VALU-limited together; the matrix pipe is idle here.  fp32 operands and accumulation.)
+            f32x4 sv = __builtin_amdgcn_mfma_f32_16x16x4f32(op.wA.x, acc[0], kZero4, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_16x16x4f32(op.wA.y, acc[1], sv, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_16x16x4f32(op.wA.z, acc[2], sv, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_16x16x4f32(op.wA.w, acc[3], sv, 0, 0, 0);
+            if (col < G::NCOL && lq == 0) pv_row[col] = make_float4(sv[0], sv[1], sv[2], sv[3]);       // 16 lanes, 256 bytes in a row
         }
         if (col < G::NCOL) {
             if constexpr (WU == 0) *reinterpret_cast<float4*>(fo_row + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);   // a wavefront: 4 KB in a row
