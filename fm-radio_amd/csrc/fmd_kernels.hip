@@ -280,7 +280,7 @@ __device__ __forceinline__ void load_front_ops(FrontOps& op, const uint4* __rest
         op.adh[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 0) * kWave + lane]);
         op.adl[sK] = __builtin_bit_cast(bf16x8, tab[(sK * 2 + 1) * kWave + lane]);
     }
-    if constexpr (WU == 0) {
+    {
         const int r = lane & 15;                 // operand row: which of the four sums (rows 4-15: zero)
         const float* w = ((r & 1) ? sp->wim : sp->wre) + ((r & 2) ? 0 : 16) + 4 * lq;
         op.wA = r < 4 ? *reinterpret_cast<const float4*>(w) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -411,14 +411,16 @@ __device__ __forceinline__ void front_from_phases(const Dims& d, float* smem, co
         }
         for (int q4 = tid; q4 < T / 4; q4 += 256) *reinterpret_cast<float4*>(fo_row + 4 * q4) = *reinterpret_cast<const float4*>(fo + WU + 4 * q4);
         // the pilot stage's column sums from the de-emphasised outputs (the reference filters fm_out in place ahead of every consumer,
-        // broadcast_fm_demod.cpp:403-406): thread = (column, one of its four sums), fp32
-        for (int cc = tid >> 2; cc < T / 16; cc += 64) {
-            const int part = tid & 3;
-            const float* w = ((part & 1) ? sp->wim : sp->wre) + ((part < 2) ? 16 : 0);
-            float a0_ = 0.0f, a1_ = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) { a0_ = fmaf(w[i], fo[WU + 16 * cc + i], a0_); a1_ = fmaf(w[i + 1], fo[WU + 16 * cc + i + 1], a1_); }
-            reinterpret_cast<float*>(pv_row + cc)[part] = a0_ + a1_;
+        // broadcast_fm_demod.cpp:403-406): the same fp32 matrix product as above, the tile of outputs read back from LDS in the
+        // accumulators' layout (lane (column, k): outputs 4 k .. 4 k + 3 of the column)
+        for (int ct = wv; ct * 16 < T / 16; ct += 4) {
+            const int col = ct * 16 + lrow;
+            const float4 y = *reinterpret_cast<const float4*>(fo + WU + 16 * col + 4 * lq);
+            f32x4 sv = __builtin_amdgcn_mfma_f32_16x16x4f32(op.wA.x, y.x, kZero4, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_16x16x4f32(op.wA.y, y.y, sv, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_16x16x4f32(op.wA.z, y.z, sv, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_16x16x4f32(op.wA.w, y.w, sv, 0, 0, 0);
+            if (lq == 0) pv_row[col] = make_float4(sv[0], sv[1], sv[2], sv[3]);
         }
     }
 }
