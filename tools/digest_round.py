@@ -69,7 +69,7 @@ def install(rnd: str = "4") -> None:
     dst.mkdir(parents=True, exist_ok=True)
     traffic_tab = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text())
     valu_tab = json.loads((ROOT / "profiles" / "valu_instructions.json").read_text())
-    for sfx in ("", "_exact", "_1024k", "_1024k_u8", "_8192"):
+    for sfx in ("", "_exact", "_1024k", "_1024k_u8", "_8192", "_1ch"):
         f = ROOT / "gpurun_out" / f"r{rnd}prof{sfx}" / "digest.json"
         if not f.exists():
             continue
