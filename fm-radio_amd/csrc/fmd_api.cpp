@@ -2,6 +2,7 @@
 // controls, device buffers and the per-block kernel launch sequence.  Host side only; the kernels are
 // in fmd_kernels.hip.  There is no CPU fallback: without a gfx950 device every call fails loudly.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -63,6 +64,7 @@ struct fmd_handle_s {
     bool lazy_extract = false, lazy_capable = false;
     bool no_fused_pll = false;               // development A/B: the deferred pilot stage as a launch of its own
     bool pll_eager = false;                  // development A/B: the pilot stage queued at submission on its own queue (round 3's arrangement)
+    bool split_queues = false;               // the front end's and the extract stage's queues on disjoint sets of CUs (hipExtStreamCreateWithCUMask): the two run side by side
     bool front_with_predecim = true;         // 1.024 / 2.048 MSa/s, deferred schedule: the front end follows the first decimator on ITS queue
     // pll_pending: the block's pilot stage has not been queued either — it rides in the next block's front-end launch (k_front_mfma<FUSED>) or,
     // where that is not possible (a start-up block, the getters' per-sample streams, a flush), goes in front of the extract stage on its own;
@@ -179,6 +181,60 @@ void toeplitz_image(const float* taps, int n_taps, int stride, int ksteps, uint1
 }
 constexpr size_t kAudImgU16 = (size_t)6 * 2 * 64 * 8, kRdsImgU16 = (size_t)8 * 2 * 64 * 8;
 
+// k_extract_bp (fmd_kernels_bp.inc): the harmonic mixer folded into the decimating FIR.  The reference's L-R / RDS rails are
+//   sum_tau h[tau] a[t0 + tau] e^{j 2 pi H dt[t0 + tau]},  a[t] = x[t - 32] + j sum_n b_hil[n] x[t - 64 + n]   (broadcast_fm_demod.cpp:463-536)
+// and the NCO's carrier part e^{-j 2 pi H 19 (t + 1) / 128} with the Hilbert FIR is ONE complex FIR of 192 taps on the real signal x:
+//   G[u] = sum_tau h[tau] e^{-j 2 pi H 19 tau / 128} (delta[u - tau - 32] + j b_hil[u - tau]),     S[m] = sum_u G[u] x[M m - 188 + 4 (M / 8) + u]
+// (in double; the phase of the carrier through its exact period of 128 samples)
+constexpr int kBpTaps = 192;
+void bandpass_taps(const float* h, const float* b_hil, int H, float* g_re, float* g_im) {
+    double re[kBpTaps] = {0.0}, im[kBpTaps] = {0.0};
+    const double two_pi = 6.283185307179586476925;
+    for (int tau = 0; tau < 128; tau++) {
+        const int k = (H * 19 * tau) % 128;
+        const double cr = std::cos(two_pi * k / 128.0), ci = -std::sin(two_pi * k / 128.0), hv = h[tau];
+        re[tau + 32] += hv * cr; im[tau + 32] += hv * ci;
+        for (int n = 0; n < 65; n++) {
+            const double b = b_hil[n];
+            if (b == 0.0) continue;
+            re[tau + n] += hv * (-ci) * b;        // j (cr + j ci) = -ci + j cr
+            im[tau + n] += hv * cr * b;
+        }
+    }
+    for (int u = 0; u < kBpTaps; u++) { g_re[u] = (float)re[u]; g_im[u] = (float)im[u]; }
+}
+// k_extract_bp's operands are banded Toeplitz — lane (row, k) of K-step s holds 8 consecutive taps — so the kernel reads them from zero-padded
+// TAP TABLES in LDS: kBpTL bf16 each, tap i at element kBpPadL + i (fmd_kernels_bp.inc), every fp32 tap as hi + lo (round to nearest even)
+void tap_table(const float* taps, int n_taps, uint16_t* hi, uint16_t* lo) {
+    for (int i = 0; i < kBpTL; i++) { hi[i] = 0; if (lo) lo[i] = 0; }
+    for (int i = 0; i < n_taps; i++) {
+        const uint16_t h = bf16_rne(taps[i]);
+        hi[kBpPadL + i] = h;
+        if (lo) lo[kBpPadL + i] = bf16_rne(taps[i] - bf16_to_f32(h));
+    }
+}
+constexpr size_t kBpSlotU16 = (size_t)kBpSlotTabs * kBpTL, kBpRdsTabU16 = (size_t)6 * kBpTL;
+static_assert(kBpTL >= kBpPadL + kBpTaps + 8, "the composite taps fit their table");
+// a cut-off slot: L+R hi, lo; L-R composite re hi, re lo, im hi, im lo
+void bp_slot_tables(const float* taps, const float* b_hil, uint16_t* dst) {
+    tap_table(taps, 128, dst, dst + kBpTL);
+    float gr[kBpTaps], gi[kBpTaps];
+    bandpass_taps(taps, b_hil, 2, gr, gi);
+    tap_table(gr, kBpTaps, dst + 2 * kBpTL, dst + 3 * kBpTL);
+    tap_table(gi, kBpTaps, dst + 4 * kBpTL, dst + 5 * kBpTL);
+}
+// RDS: S0 re hi, re lo, im hi, im lo; the first-order term's S1 (taps (tau - 63.5) h[tau]) re hi, im hi
+void bp_rds_tables(const float* b_rds, const float* b_hil, uint16_t* dst) {
+    float gr[kBpTaps], gi[kBpTaps], h1[128];
+    bandpass_taps(b_rds, b_hil, 3, gr, gi);
+    tap_table(gr, kBpTaps, dst, dst + kBpTL);
+    tap_table(gi, kBpTaps, dst + 2 * kBpTL, dst + 3 * kBpTL);
+    for (int i = 0; i < 128; i++) h1[i] = (float)(((double)i - 63.5) * (double)b_rds[i]);
+    bandpass_taps(h1, b_hil, 3, gr, gi);
+    tap_table(gr, kBpTaps, dst + 4 * kBpTL, nullptr);
+    tap_table(gi, kBpTaps, dst + 5 * kBpTL, nullptr);
+}
+
 const std::vector<float>& lpf_taps(fmd_handle h, int hz) {
     auto it = h->lpf_cache.find(hz);
     if (it != h->lpf_cache.end()) return it->second;
@@ -230,11 +286,19 @@ int upload_controls(fmd_handle h, hipStream_t s) {
                 int rc = dev_alloc(h, &q, cap * kAudImgU16 * 2 / sizeof(uint4));
                 if (rc) return rc;
                 b.aud_img = q;       // the old table stays on the handle's allocation list until fmd_destroy
+                uint4* q2 = nullptr;
+                rc = dev_alloc(h, &q2, cap * kBpSlotU16 * 2 / sizeof(uint4));
+                if (rc) return rc;
+                b.bp_img = q2;
                 h->img_capacity = cap;
             }
             std::vector<uint16_t> imgs(n_slots * kAudImgU16);
             for (const auto& kv : h->img_slot) toeplitz_image(lpf_taps(h, kv.first).data(), 128, 4, 6, imgs.data() + (size_t)kv.second * kAudImgU16);
             HIP_TRY(h, hipMemcpyAsync(b.aud_img, imgs.data(), imgs.size() * 2, hipMemcpyHostToDevice, s));
+            // k_extract_bp: per cut-off the tap tables of the L+R FIR and of the L-R composite (mixer + Hilbert FIR folded into the taps)
+            std::vector<uint16_t> bimgs(n_slots * kBpSlotU16);
+            for (const auto& kv : h->img_slot) bp_slot_tables(lpf_taps(h, kv.first).data(), h->base.b_hilbert, bimgs.data() + (size_t)kv.second * kBpSlotU16);
+            HIP_TRY(h, hipMemcpyAsync(b.bp_img, bimgs.data(), bimgs.size() * 2, hipMemcpyHostToDevice, s));
             HIP_TRY(h, hipStreamSynchronize(s));
         }
         HIP_TRY(h, hipMemcpyAsync(b.aud_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, s));
@@ -506,7 +570,7 @@ int launch_deferred_pll(fmd_handle h, hipStream_t sP) {
 int launch_deferred(fmd_handle h, bool behind_front) {
     auto& q = h->deferred;
     if (!q.active) return FMD_OK;
-    hipStream_t sXq = behind_front ? h->sF : h->sX, sR = h->sR;
+    hipStream_t sXq = (behind_front && !h->split_queues) ? h->sF : h->sX, sR = h->sR;
     if (h->consumer_pending[q.slot]) {       // fmd_release_outputs: a consumer still reads this slot's old outputs
         HIP_TRY(h, hipStreamWaitEvent(sXq, h->ev_C[q.slot], 0));
         HIP_TRY(h, hipStreamWaitEvent(sR, h->ev_C[q.slot], 0));
@@ -680,7 +744,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         if (lazy && q.active && q.pll_pending && !q.ref.warm && !q.deemph && q.front_stream == sFq && !h->ctx.any_deemph && !h->ctx.b.fm_out_iq[q.slot] &&
             !(h->debug_skip & ((1u << ST_PLL) | (1u << ST_FRONT))) && !h->no_fused_pll) {
             ride = &q.ref;
-            q.pll_pending = false; q.pll_dep = sFq != sF ? dep : nullptr; q.pll_stream = sFq;
+            q.pll_pending = false; q.pll_dep = (sFq != sF || h->split_queues) ? dep : nullptr; q.pll_stream = sFq;
             if (h->last_p_event && h->last_p_stream != sFq) HIP_TRY(h, hipStreamWaitEvent(sFq, h->last_p_event, 0));
             h->last_p_stream = sFq; h->last_p_event = dep;          // (the launch's own event)
         }
@@ -847,7 +911,14 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     auto bail = [&](int rc) { g_create_error = h->err; fmd_destroy(h); return rc; };
     if (hipSetDevice(dev) != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "hipSetDevice failed"));
     { hipError_t e = prepare_kernels(); if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "prepare_kernels: %s", hipGetErrorString(e))); }
-    { hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking); if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e))); }
+    // development switch FMD_CU_MASK_F / FMD_CU_MASK_X (hex words, 8 x 32 bits, e.g. ffff-ffff-...): the front end's queues and the extract
+    // stage's queue restricted to those CUs (tools/cumask_ab.sh)
+    std::vector<uint32_t> mask_f, mask_x;
+    auto parse_mask = [](const char* e, std::vector<uint32_t>& m) { while (e && *e) { char* end = nullptr; const unsigned long v = strtoul(e, &end, 16); if (!end || end == e) break; m.push_back((uint32_t)v); e = *end ? end + 1 : end; } };   // (any one non-hex character separates the words)
+    parse_mask(dev_env("FMD_CU_MASK_F"), mask_f); parse_mask(dev_env("FMD_CU_MASK_X"), mask_x);
+    h->split_queues = !mask_f.empty() && !mask_x.empty();
+    { hipError_t e = h->split_queues ? hipExtStreamCreateWithCUMask(&h->own_stream, (uint32_t)mask_f.size(), mask_f.data()) : hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+      if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e))); }
 
     h->pipelined = (cfg->flags & FMD_FLAG_NO_PIPELINE) == 0;
     if (h->pipelined) warn_hw_queues_once();
@@ -867,7 +938,9 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
         int i = 0;
         for (hipStream_t* st : {&h->sF, &h->sD, &h->sA, &h->sB, &h->sX, &h->sR}) {
             const int p = std::min(least, std::max(greatest, prio[i++]));
-            hipError_t e = p ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, p) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+            hipError_t e;
+            if (h->split_queues && (st == &h->sF || st == &h->sX)) { const auto& mk = st == &h->sF ? mask_f : mask_x; e = hipExtStreamCreateWithCUMask(st, (uint32_t)mk.size(), mk.data()); }
+            else e = p ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, p) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
             if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e)));
         }
         if (dev_env("FMD_STREAM_PRIORITIES")) std::fprintf(stderr, "fmdemod: stream priority range [%d (least) .. %d (greatest)]\n", least, greatest);
@@ -906,6 +979,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     h->no_fused_pll = dev_env("FMD_NO_FUSED_PLL") != nullptr;
     h->pll_eager = dev_env("FMD_PLL_EAGER") != nullptr;
     if (dev_env("FMD_FRONT_OWN_QUEUE")) h->front_with_predecim = false;
+    h->ctx.extract_mix = dev_env("FMD_EXTRACT_MIX") != nullptr;    // development A/B: round 4's k_extract_mfma (mixers at 128 kHz) instead of k_extract_bp
 
     fmd_controls def;
     fmd_default_controls(&def);
@@ -970,6 +1044,17 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
                 std::vector<uint16_t> rimg(kRdsImgU16);
                 toeplitz_image(h->base.b_rds, 128, 8, 8, rimg.data());
                 if (hipMemcpyAsync(b.rds_img, rimg.data(), rimg.size() * 2, hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
+                    hipStreamSynchronize(h->own_stream) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "operand table upload failed");
+            }
+            if (!rc) rc = dev_alloc(h, &b.rds_bp_img, kBpRdsTabU16 * 2 / sizeof(uint4));
+            if (!rc) rc = dev_alloc(h, &b.hil_odd, 32);
+            if (!rc) {
+                std::vector<uint16_t> rtab(kBpRdsTabU16);
+                float ho[32];
+                bp_rds_tables(h->base.b_rds, h->base.b_hilbert, rtab.data());
+                for (int i = 0; i < 32; i++) ho[i] = h->base.b_hilbert[2 * i + 1];
+                if (hipMemcpyAsync(b.rds_bp_img, rtab.data(), rtab.size() * 2, hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
+                    hipMemcpyAsync(b.hil_odd, ho, sizeof(ho), hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
                     hipStreamSynchronize(h->own_stream) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "operand table upload failed");
             }
             if (!rc) rc = dev_alloc(h, &b.span_tab, 1);
@@ -1427,6 +1512,18 @@ int fmd_design_pll_sparse(int fs_baseband, float* taps, float* cplx, float* rows
     std::memcpy(sw, t.sw, sizeof(t.sw));
     const float m[8] = {t.phi0, t.inv_s2, t.nbar, t.kappa, t.pw_scale, t.kap2[0], t.kap2[1], 0.f};
     std::memcpy(misc8, m, sizeof(m));
+    return FMD_OK;
+}
+
+int fmd_design_extract_bp(int fs_baseband, int cutoff_hz, float* g2, float* g3) {
+    if (!g2 || !g3) return FMD_ERR_ARG;
+    fmd_controls c;
+    fmd_default_controls(&c);
+    c.lmr_cutoff_hz = cutoff_hz;
+    fmd_coeffs k{};
+    design_all(&k, fs_baseband, &c);
+    bandpass_taps(k.b_lmr, k.b_hilbert, 2, g2, g2 + kBpTaps);
+    bandpass_taps(k.b_rds, k.b_hilbert, 3, g3, g3 + kBpTaps);
     return FMD_OK;
 }
 

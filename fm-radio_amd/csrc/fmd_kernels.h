@@ -127,6 +127,8 @@ struct PllSparseTab {
 // rows of the fast-mode planes carry the previous block's last samples in front (written by k_pll_span of that block), so the
 // consumers address history and block uniformly
 static constexpr int kFrontImgU4 = 2 * 3 * 2 * 64;   // uint4s of k_front_mfma's two operand images in Buffers::front_mfma; k_predecim_mfma's image follows them
+// k_extract_bp's tap tables (fmd_kernels_bp.inc): kBpTL bf16 each, tap i at element kBpPadL + i
+static constexpr int kBpPadL = 64, kBpTL = 336, kBpSlotTabs = 6;
 static constexpr int kFoPad = 192;   // fm_out: k_extract_mfma reaches back 124 + 64 samples (its Hilbert FIR), k_pll_span 33 (65 while a station warms up)
 
 struct Dims {
@@ -196,6 +198,9 @@ struct Buffers {
     uint4*  aud_img;                 // ... of k_extract_mfma's audio FIRs, one per distinct cut-off: [slot][k-step][hi/lo][lane]
     int2*   aud_idx;                 // [C] slots of a station's L+R and L-R images
     uint4*  rds_img;                 // ... of the RDS FIR
+    uint4*  bp_img;                  // k_extract_bp: per distinct cut-off the tap tables of the L+R FIR and of the L-R composite band-pass FIR (kBpSlotU4 uint4s a slot)
+    uint4*  rds_bp_img;              // ... of the RDS composite band-pass FIR and of its first-order term
+    float*  hil_odd;                 // [32] the Hilbert FIR's non-zero taps b[1], b[3], ... (k_extract_bp's block-edge sums)
     uint4*  front_mfma;              // FMD_FLAG_FAST_MATH only: Toeplitz operand images of k_front_mfma's two FIRs, [fir][k-step][hi/lo][lane]; m > 1: then k_predecim_mfma's
     unsigned int* pll_chain;         // [wavefronts of k_pilot_pll + 1] last block number each wavefront completed; [last] = watchdog flag
     unsigned long long* spec_stats;  // [8] speculation counters: pll {chunks, general, replayed, -}, rds {chunks, general, replayed, -}
@@ -215,6 +220,7 @@ struct LaunchCtx {
     int fast;                             // FMD_FLAG_FAST_MATH: the tolerance-mode kernels
     int any_deemph;
     int deemph_in_tile;     // FMD_FLAG_FAST_MATH: the de-emphasis IIR runs inside k_front's tile (every filtering channel's pole <= 0.905, i.e. up to ~79 us)
+    int extract_mix;        // development A/B (FMD_EXTRACT_MIX): k_extract_mfma, the extract stage with the mixers at 128 kHz (round 4), instead of k_extract_bp
     int split_front;        // fmd_debug_split_front: 1.024 / 2.048 MSa/s tolerance mode with k_predecim_mfma and k_front_mfma as two kernels (the parity check of k_front_pre_mfma)
     int bytes_cap;
     int pll_time_parallel_max_channels;   // batches up to this size use the time-parallel PLL kernel, larger ones the low-work one

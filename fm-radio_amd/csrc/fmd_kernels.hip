@@ -2341,6 +2341,8 @@ __global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __res
 #endif
 }
 
+#include "fmd_kernels_bp.inc"
+
 // Tolerance mode, FMD_FLAG_KEEP_TAPS (the "fm_out_iq" getter) and block lengths whose audio blocks are not multiples of 256 (those run
 // k_extract<128, true> on the interleaved stream, with the history tails it keeps for itself): the analytic signal from the fm_out plane,
 // Hilbert rail as k_hilbert makes it.
@@ -3127,6 +3129,14 @@ static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
         if (ctx.fast) return launch_extract_ta<TA, true>(ctx, r, s);
     }
     if constexpr (FAST && TA == 256) {   // tolerance mode: the FIRs on the matrix cores
+        if (!ctx.extract_mix) {          // round 5: the mixers behind the FIRs (fmd_kernels_bp.inc)
+            const int tiles = d.n_audio / TA, nt = (tiles % 4 == 0) ? 4 : ((tiles % 2 == 0) ? 2 : 1);     // tiles per workgroup: its operand images stay in registers
+            FMD_LAUNCH(r, true, true, k_extract_bp, dim3((unsigned)(tiles / nt * d.C)), dim3(TA), 0, s, d, nt, b.fo_pl[r.buf], b.pll_poly[r.buf],
+                       b.bp_img, b.aud_idx, b.rds_bp_img, b.b_lmr, b.mix,
+                       b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est[r.par], b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps,
+                       lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr, lmr_field(r.par), lmr_field(r.par ^ 1), b.rds_pow[r.buf], b.hil_odd);
+            return;
+        }
         FMD_LAUNCH(r, true, true, k_extract_mfma, dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fo_pl[r.buf], b.front_mfma + 6 * kWave, b.pll_poly[r.buf],
                    b.aud_img, b.aud_idx, b.rds_img, b.b_lmr, b.mix,
                    b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est[r.par], b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps,

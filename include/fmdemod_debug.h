@@ -49,6 +49,11 @@ int fmd_design_pll_span(int fs_baseband, float* w, float* s, float* minv, float*
  * tests/test_span_design.py checks them against a float64 model of the reference's peak filter and loop. */
 int fmd_design_pll_sparse(int fs_baseband, float* taps, float* cplx, float* rows, float* sw, float* misc8);
 
+/* Taps of k_extract_bp's composite band-pass FIRs (fmd_kernels_bp.inc: the harmonic mixer's carrier and the Hilbert FIR folded into the
+ * decimating FIR): g2 [2][192] = (real, imaginary) taps of the L-R FIR for an L-R cut-off of cutoff_hz, g3 [2][192] of the RDS FIR.
+ * tests/test_bandpass_design.py checks them against the reference's order of operations in float64. */
+int fmd_design_extract_bp(int fs_baseband, int cutoff_hz, float* g2, float* g3);
+
 /* Counters of k_pilot_pll's frequency speculation since creation / the last reset (DESIGN.md "Pilot PLL"):
  * out8[0] = 128-sample chunks, summed over wavefronts (4 channels each); out8[1] = of those, chunks run with the plain serial
  * iteration (wavefront out of lock); out8[2] = spans redone with the reference forms (a short form outside its domain);

@@ -8,7 +8,9 @@
 //   Pass 1, lock-step: after every block the gathered audio / RDS bytes / counts on the collector must equal what every rank's own
 //   fmd_get_audio / fmd_get_rds_bytes return (PCM16: the reference scraper's conversion of it, fm_scraper.cpp:79-82).
 //   Pass 2, fresh handles, two blocks in flight ahead of the collector: the gathered blocks must equal pass 1's bit for bit.
+//   failrank: a third pass in which one rank's submission fails: Collect() throws and the host tears down (abort path).
 //   Prints one JSON line; exit code 0 only if everything matched.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -28,8 +30,8 @@ int main(int argc, char** argv) {
     const std::string path = argv[1];
     const int R = atoi(argv[2]), C = atoi(argv[3]), N = atoi(argv[4]), fs = atoi(argv[5]), nb = atoi(argv[6]);
     const bool pcm = std::string(argv[7]) == "pcm16", loopback = atoi(argv[8]) != 0;
-    bool fast = false, rotate = false;
-    for (int i = 9; i < argc; i++) { fast = fast || std::string(argv[i]) == "fast"; rotate = rotate || std::string(argv[i]) == "rotate"; }
+    bool fast = false, rotate = false, failrank = false;
+    for (int i = 9; i < argc; i++) { fast = fast || std::string(argv[i]) == "fast"; rotate = rotate || std::string(argv[i]) == "rotate"; failrank = failrank || std::string(argv[i]) == "failrank"; }
     FILE* fp = fopen(path.c_str(), "rb");
     if (!fp) return 2;
     std::vector<uint8_t> data((size_t)R * C * nb * N * 2);
@@ -121,7 +123,28 @@ int main(int argc, char** argv) {
                 collected++;
             }
         }
-        printf("{\"ranks\": %d, \"devices\": %d, \"stations_per_rank\": %d, \"blocks\": %d, \"format\": \"%s\", \"loopback_rccl\": %s, \"rotate\": %s, \"lockstep_mismatches\": %ld, "
+        // Pass 3 (failrank): the last rank's submission of block 2 fails (a null block): Collect() must throw that rank's error instead of
+        // waiting for a block that never comes, and the host's destructor (abort, join, fmd_gather_destroy: communicators aborted before the
+        // rank streams are drained) must return.
+        double teardown_ms = -1.0; int threw = 0;
+        if (failrank) {
+            const auto t0 = std::chrono::steady_clock::now();
+            {
+                MultiGpuHost host(devs, C, N, fs, dflags, fmt, gflags, 0);
+                try {
+                    for (int b = 0; b < nb; b++) {
+                        std::vector<const uint8_t*> ptrs((size_t)R);
+                        for (int r = 0; r < R; r++) ptrs[(size_t)r] = (b == 2 && r == R - 1) ? nullptr : d_in[(size_t)r][(size_t)b];
+                        host.SubmitU8(ptrs);
+                        (void)host.Collect();
+                    }
+                } catch (const std::exception& e) { threw = std::string(e.what()).find("fmd_submit") != std::string::npos ? 1 : -1; }
+            }
+            teardown_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (threw != 1) mismatches2 += 1000;
+        }
+        printf("{\"failed_rank_threw\": %d, \"failed_rank_run_ms\": %.1f, ", threw, teardown_ms);
+        printf("\"ranks\": %d, \"devices\": %d, \"stations_per_rank\": %d, \"blocks\": %d, \"format\": \"%s\", \"loopback_rccl\": %s, \"rotate\": %s, \"lockstep_mismatches\": %ld, "
                "\"pipelined_mismatches\": %ld, \"rds_bytes_gathered\": %ld, \"remote_bytes_per_block\": %zu}\n",
                R, ndev, C, nb, pcm ? "pcm16" : "f32", loopback ? "true" : "false", rotate ? "true" : "false", mismatches, mismatches2, bytes_total, remote);
         return (mismatches == 0 && mismatches2 == 0 && bytes_total > 0) ? 0 : 3;

@@ -1,0 +1,26 @@
+"""CPU tests (no GPU, no RCCL) of the multi-GPU gather's bookkeeping (fm-radio_amd/csrc/fmd_gather_plan.h, the HIP-free half of
+libfmdgather.so): who collects block k under FMD_GATHER_ROTATE, which shards cross RCCL and which are copies, the back-pressure on the
+collector's three buffer sets, and that fmd_gather_abort's host side releases every waiter (reference anchor: one
+demodulator wired to an audio observer and an RDS byte chain per station, src/app.cpp:19-34)."""
+import json
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    exe = tmp_path_factory.mktemp("gather_plan") / "gather_plan_main"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", f"-I{ROOT / 'fm-radio_amd' / 'csrc'}", str(ROOT / "tests" / "cpp" / "gather_plan_main.cpp"),
+                    "-lpthread", "-o", str(exe)], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("args", [["plan"], ["run", "2", "150"], ["run", "4", "300"], ["run", "8", "120"], ["abort"]])
+def test_gather_bookkeeping(driver, args):
+    r = subprocess.run([str(driver), *args], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["failed_checks"] == 0

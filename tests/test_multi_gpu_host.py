@@ -47,15 +47,14 @@ def test_gather_library_builds_and_exports_its_header(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ranks,fmt,loopback,fast,rotate", [(2, "pcm16", 0, True, False), (2, "f32", 0, False, False), (1, "pcm16", 1, True, False), (1, "f32", 1, False, False),
-                                                             (2, "pcm16", 0, True, True)])
+                                                             (2, "pcm16", 0, True, True), (3, "f32", 0, True, True)])
 def test_multi_gpu_host_gathers_audio_and_rds_bytes(tmp_path, ranks, fmt, loopback, fast, rotate):
     """With as many GPUs as ranks the driver puts every rank on its own device (everything crosses RCCL); `rotate`: the collector moves
-    from GPU to GPU block by block (FMD_GATHER_ROTATE) — needs >= 2 devices, skipped on a one-GPU box."""
+    from rank to rank block by block (FMD_GATHER_ROTATE) — from GPU to GPU with one rank per device, between the ranks' buffer sets on the
+    one device of a one-GPU box (every hand-over a copy: the rotation's bookkeeping runs either way)."""
     import fmradio_loader
     import torch
     fmradio_loader.load().load_library()
-    if rotate and torch.cuda.device_count() < ranks:
-        pytest.skip("FMD_GATHER_ROTATE needs one GPU per rank")
     exe = build_driver(tmp_path)
     c_local, bs, fs, nb = 6, 16384, 256_000, 10                   # 0.64 s: the Manchester decoder has handed on bytes by then
     base = np.stack([synth.to_u8(synth.fm_capture(nb * bs, fs=float(fs), seed=5600, channel=c)["iq"]) for c in range(4)])
@@ -68,3 +67,23 @@ def test_multi_gpu_host_gathers_audio_and_rds_bytes(tmp_path, ranks, fmt, loopba
     info = json.loads(r.stdout.strip().splitlines()[-1])
     assert info["lockstep_mismatches"] == 0 and info["pipelined_mismatches"] == 0
     assert info["rds_bytes_gathered"] >= 16 * ranks * c_local     # the RDS part of the comparison is not vacuous
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,loopback,rotate", [(2, 0, True), (1, 1, False)])
+def test_a_failed_rank_turns_into_an_error_not_a_hang(tmp_path, ranks, loopback, rotate):
+    """a rank whose fmd_submit fails never posts its part of the gather.  Collect() must throw that rank's error, and the
+    host's destructor — fmd_gather_abort, join, fmd_gather_destroy, which aborts the communicators BEFORE it drains the rank streams —
+    must return (the driver runs under a timeout)."""
+    import fmradio_loader
+    fmradio_loader.load().load_library()
+    exe = build_driver(tmp_path)
+    c_local, bs, fs, nb = 4, 16384, 256_000, 6
+    base = np.stack([synth.to_u8(synth.fm_capture(nb * bs, fs=float(fs), seed=5700, channel=c)["iq"]) for c in range(2)])
+    caps = base[np.arange(ranks * c_local) % 2]
+    f = tmp_path / "caps.u8"
+    np.ascontiguousarray(caps).tofile(f)
+    r = subprocess.run([str(exe), str(f), str(ranks), str(c_local), str(bs), str(fs), str(nb), "pcm16", str(loopback), "fast", "failrank"] + (["rotate"] if rotate else []),
+                       capture_output=True, text=True, timeout=120)
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["failed_rank_threw"] == 1 and info["failed_rank_run_ms"] < 60_000, (info, r.stderr[-1000:])
