@@ -18,6 +18,7 @@
 
 #include "fmd_design.h"
 #include "fmd_kernels.h"
+#include "fmd_math.h"
 #include "fmdemod.h"
 #include "fmdemod_debug.h"
 
@@ -203,36 +204,73 @@ void bandpass_taps(const float* h, const float* b_hil, int H, float* g_re, float
     }
     for (int u = 0; u < kBpTaps; u++) { g_re[u] = (float)re[u]; g_im[u] = (float)im[u]; }
 }
-// k_extract_bp's operands are banded Toeplitz — lane (row, k) of K-step s holds 8 consecutive taps — so the kernel reads them from zero-padded
-// TAP TABLES in LDS: kBpTL bf16 each, tap i at element kBpPadL + i (fmd_kernels_bp.inc), every fp32 tap as hi + lo (round to nearest even)
-void tap_table(const float* taps, int n_taps, uint16_t* hi, uint16_t* lo) {
-    for (int i = 0; i < kBpTL; i++) { hi[i] = 0; if (lo) lo[i] = 0; }
-    for (int i = 0; i < n_taps; i++) {
-        const uint16_t h = bf16_rne(taps[i]);
-        hi[kBpPadL + i] = h;
-        if (lo) lo[kBpPadL + i] = bf16_rne(taps[i] - bf16_to_f32(h));
-    }
+// image of a complex FIR with rows (output o, rail): A[2 o + rail][t] = g_rail[t - shift - stride o], 8 outputs x 2 rails per 16-row tile
+void toeplitz_image_rails(const float* g_re, const float* g_im, int n_taps, int stride, int ksteps, uint16_t* img, int shift) {
+    for (int sK = 0; sK < ksteps; sK++)
+        for (int l = 0; l < 64; l++)
+            for (int i = 0; i < 8; i++) {
+                const int row = l % 16, t = 32 * sK + 8 * (l / 16) + i, idx = t - shift - stride * (row >> 1);
+                const float v = (idx >= 0 && idx < n_taps) ? ((row & 1) ? g_im[idx] : g_re[idx]) : 0.0f;
+                const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
+                img[(((size_t)sK * 2 + 0) * 64 + l) * 8 + i] = hi;
+                img[(((size_t)sK * 2 + 1) * 64 + l) * 8 + i] = lo;
+            }
 }
-constexpr size_t kBpSlotU16 = (size_t)kBpSlotTabs * kBpTL, kBpRdsTabU16 = (size_t)6 * kBpTL;
-static_assert(kBpTL >= kBpPadL + kBpTaps + 8, "the composite taps fit their table");
-// a cut-off slot: L+R hi, lo; L-R composite re hi, re lo, im hi, im lo
-void bp_slot_tables(const float* taps, const float* b_hil, uint16_t* dst) {
-    tap_table(taps, 128, dst, dst + kBpTL);
+// k_extract_bp's operand images (fmd_kernels_bp.inc): every family on 8 K-steps of a column's window W[64 c .. 64 c + 255]
+constexpr size_t kBpFamU16 = (size_t)8 * 2 * 64 * 8, kBpSlotU16 = 3 * kBpFamU16, kBpRdsU16 = kBpFamU16 + kBpFamU16 / 2;
+// a cut-off slot: L+R (rows = 16 outputs, taps 32 samples into the window: the analytic signal's real rail is fm_out delayed by 32), L-R composite re, im
+void bp_slot_images(const float* taps, const float* b_hil, uint16_t* dst) {
+    toeplitz_image(taps, 128, 4, 8, dst, 32);
     float gr[kBpTaps], gi[kBpTaps];
     bandpass_taps(taps, b_hil, 2, gr, gi);
-    tap_table(gr, kBpTaps, dst + 2 * kBpTL, dst + 3 * kBpTL);
-    tap_table(gi, kBpTaps, dst + 4 * kBpTL, dst + 5 * kBpTL);
+    toeplitz_image(gr, kBpTaps, 4, 8, dst + kBpFamU16, 0);
+    toeplitz_image(gi, kBpTaps, 4, 8, dst + 2 * kBpFamU16, 0);
 }
-// RDS: S0 re hi, re lo, im hi, im lo; the first-order term's S1 (taps (tau - 63.5) h[tau]) re hi, im hi
-void bp_rds_tables(const float* b_rds, const float* b_hil, uint16_t* dst) {
+// The block's first 31 L-R outputs, the part of their sums that lies in the PREVIOUS block (mixed with its L-R offset, reference
+// broadcast_fm_demod.cpp:485-517): S_old[m] = sum_{tau < 124 - 4 m} h[tau] e^{-j 2 pi 38 tau / 128} a[4 m - 124 + tau] = sum_u K_m[u] W[u],
+// W[u] = fm_out[u - 188], K_m[u] = (composite of the TRUNCATED taps)[u - 4 m].  Layout [m][lane p of 8][24 columns][re, im], fp16.
+constexpr size_t kBpEdgeHalves = (size_t)31 * 8 * 24 * 2;
+static uint16_t f32_to_f16_rne(float x) {       // IEEE binary16, round to nearest even (the matrix entries are < 1: no overflow; denormals kept)
+    uint32_t u; std::memcpy(&u, &x, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const int e = (int)((u >> 23) & 0xffu) - 127 + 15;
+    uint32_t m = u & 0x7fffffu;
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        m |= 0x800000u;
+        const int sh = 14 - e;
+        const uint32_t r = m >> sh, rem = m & ((1u << sh) - 1u), half = 1u << (sh - 1);
+        return (uint16_t)(sign | (r + ((rem > half || (rem == half && (r & 1u))) ? 1u : 0u)));
+    }
+    const uint32_t r = ((uint32_t)e << 10) | (m >> 13), rem = m & 0x1fffu;
+    return (uint16_t)(sign | (r + ((rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ? 1u : 0u)));
+}
+void bp_edge_matrix(const float* taps, const float* b_hil, uint16_t* dst) {
+    std::memset(dst, 0, sizeof(uint16_t) * kBpEdgeHalves);
+    for (int m = 0; m < 31; m++) {
+        float ht[128], gr[kBpTaps], gi[kBpTaps];
+        for (int i = 0; i < 128; i++) ht[i] = i < 124 - 4 * m ? taps[i] : 0.0f;
+        bandpass_taps(ht, b_hil, 2, gr, gi);
+        for (int u = 0; u < 192; u++) {
+            const int idx = u - 4 * m;
+            if (idx < 0 || idx >= kBpTaps) continue;
+            uint16_t* e = dst + (((size_t)m * 8 + u / 24) * 24 + u % 24) * 2;
+            e[0] = f32_to_f16_rne(gr[idx]); e[1] = f32_to_f16_rne(gi[idx]);
+        }
+    }
+}
+
+// RDS: S0 (rows = 8 outputs x rail); then the first-order term's S1 (taps (tau - 63.5) h[tau]), hi halves only, [K-step][lane]
+void bp_rds_images(const float* b_rds, const float* b_hil, uint16_t* dst) {
     float gr[kBpTaps], gi[kBpTaps], h1[128];
     bandpass_taps(b_rds, b_hil, 3, gr, gi);
-    tap_table(gr, kBpTaps, dst, dst + kBpTL);
-    tap_table(gi, kBpTaps, dst + 2 * kBpTL, dst + 3 * kBpTL);
+    toeplitz_image_rails(gr, gi, kBpTaps, 8, 8, dst, 4);
     for (int i = 0; i < 128; i++) h1[i] = (float)(((double)i - 63.5) * (double)b_rds[i]);
     bandpass_taps(h1, b_hil, 3, gr, gi);
-    tap_table(gr, kBpTaps, dst + 4 * kBpTL, nullptr);
-    tap_table(gi, kBpTaps, dst + 5 * kBpTL, nullptr);
+    std::vector<uint16_t> full(kBpFamU16);
+    toeplitz_image_rails(gr, gi, kBpTaps, 8, 8, full.data(), 4);
+    for (int sK = 0; sK < 8; sK++) std::memcpy(dst + kBpFamU16 + (size_t)sK * 64 * 8, full.data() + (size_t)sK * 2 * 64 * 8, sizeof(uint16_t) * 64 * 8);
 }
 
 const std::vector<float>& lpf_taps(fmd_handle h, int hz) {
@@ -290,15 +328,22 @@ int upload_controls(fmd_handle h, hipStream_t s) {
                 rc = dev_alloc(h, &q2, cap * kBpSlotU16 * 2 / sizeof(uint4));
                 if (rc) return rc;
                 b.bp_img = q2;
+                uint4* q3 = nullptr;
+                rc = dev_alloc(h, &q3, cap * kBpEdgeHalves * 2 / sizeof(uint4));
+                if (rc) return rc;
+                b.bp_edge = q3;
                 h->img_capacity = cap;
             }
             std::vector<uint16_t> imgs(n_slots * kAudImgU16);
             for (const auto& kv : h->img_slot) toeplitz_image(lpf_taps(h, kv.first).data(), 128, 4, 6, imgs.data() + (size_t)kv.second * kAudImgU16);
             HIP_TRY(h, hipMemcpyAsync(b.aud_img, imgs.data(), imgs.size() * 2, hipMemcpyHostToDevice, s));
-            // k_extract_bp: per cut-off the tap tables of the L+R FIR and of the L-R composite (mixer + Hilbert FIR folded into the taps)
+            // k_extract_bp: per cut-off the operand images of the L+R FIR and of the L-R composite (mixer + Hilbert FIR folded into the taps)
             std::vector<uint16_t> bimgs(n_slots * kBpSlotU16);
-            for (const auto& kv : h->img_slot) bp_slot_tables(lpf_taps(h, kv.first).data(), h->base.b_hilbert, bimgs.data() + (size_t)kv.second * kBpSlotU16);
+            for (const auto& kv : h->img_slot) bp_slot_images(lpf_taps(h, kv.first).data(), h->base.b_hilbert, bimgs.data() + (size_t)kv.second * kBpSlotU16);
             HIP_TRY(h, hipMemcpyAsync(b.bp_img, bimgs.data(), bimgs.size() * 2, hipMemcpyHostToDevice, s));
+            std::vector<uint16_t> edges(n_slots * kBpEdgeHalves);
+            for (const auto& kv : h->img_slot) bp_edge_matrix(lpf_taps(h, kv.first).data(), h->base.b_hilbert, edges.data() + (size_t)kv.second * kBpEdgeHalves);
+            HIP_TRY(h, hipMemcpyAsync(b.bp_edge, edges.data(), edges.size() * 2, hipMemcpyHostToDevice, s));
             HIP_TRY(h, hipStreamSynchronize(s));
         }
         HIP_TRY(h, hipMemcpyAsync(b.aud_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, s));
@@ -476,6 +521,23 @@ void design_pll_sparse(const fmd_coeffs& k, PllSparseTab* t) {
         t->wsum[rr] = (float)ws; t->wmom[rr] = (float)wm;
         for (int i = 0; i < 5; i++) t->s[rr][i] = (float)rows[rr][(size_t)i];
     }
+}
+
+// PllSparseTab::wrap_tie (fmd_kernels.hip wrap_tie_u8): for every u8 sample (x, y) the sign of the reference's wrapped phase difference to a
+// sample in exactly the opposite direction — fm_demod.cpp:36-43 on glibc's atan2f, restated bit for bit (fmd_math.h fmd_atan2f_full)
+void design_wrap_tie(uint32_t* bits2048) {
+    std::memset(bits2048, 0, sizeof(uint32_t) * 2048);
+    const float pi = fmd::bits_f32(fmd::kPiBits), two_pi = fmd::bits_f32(fmd::kTwoPiBits);
+    for (int yr = 0; yr < 256; yr++)
+        for (int xr = 0; xr < 256; xr++) {
+            const float x = (float)xr - 127.0f, y = (float)yr - 127.0f;
+            if (x == 0.0f && y == 0.0f) continue;
+            float dl = fmd::fmd_atan2f_full(0.0f - y, 0.0f - x) - fmd::fmd_atan2f_full(y, x);       // (0 - v: the opposite sample is (float)u8 - 127 too, never -0)
+            if (dl >= pi) dl = dl - two_pi;
+            else if (dl <= -pi) dl = dl + two_pi;
+            const unsigned key = ((unsigned)yr << 8) | (unsigned)xr;
+            if (dl > 0.0f) bits2048[key >> 5] |= 1u << (key & 31u);
+        }
 }
 
 void design_front_mfma(const fmd_coeffs& k, int m, std::vector<uint16_t>& img) {
@@ -1046,15 +1108,11 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
                 if (hipMemcpyAsync(b.rds_img, rimg.data(), rimg.size() * 2, hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
                     hipStreamSynchronize(h->own_stream) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "operand table upload failed");
             }
-            if (!rc) rc = dev_alloc(h, &b.rds_bp_img, kBpRdsTabU16 * 2 / sizeof(uint4));
-            if (!rc) rc = dev_alloc(h, &b.hil_odd, 32);
+            if (!rc) rc = dev_alloc(h, &b.rds_bp_img, kBpRdsU16 * 2 / sizeof(uint4));
             if (!rc) {
-                std::vector<uint16_t> rtab(kBpRdsTabU16);
-                float ho[32];
-                bp_rds_tables(h->base.b_rds, h->base.b_hilbert, rtab.data());
-                for (int i = 0; i < 32; i++) ho[i] = h->base.b_hilbert[2 * i + 1];
+                std::vector<uint16_t> rtab(kBpRdsU16);
+                bp_rds_images(h->base.b_rds, h->base.b_hilbert, rtab.data());
                 if (hipMemcpyAsync(b.rds_bp_img, rtab.data(), rtab.size() * 2, hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
-                    hipMemcpyAsync(b.hil_odd, ho, sizeof(ho), hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
                     hipStreamSynchronize(h->own_stream) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "operand table upload failed");
             }
             if (!rc) rc = dev_alloc(h, &b.span_tab, 1);
@@ -1068,6 +1126,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
             if (!rc) {
                 PllSparseTab sp_;
                 design_pll_sparse(h->base, &sp_);
+                design_wrap_tie(sp_.wrap_tie);
                 if (hipMemcpyAsync(b.sparse_tab, &sp_, sizeof(sp_), hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
                     hipStreamSynchronize(h->own_stream) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "sparse table upload failed");
             }
@@ -1512,6 +1571,12 @@ int fmd_design_pll_sparse(int fs_baseband, float* taps, float* cplx, float* rows
     std::memcpy(sw, t.sw, sizeof(t.sw));
     const float m[8] = {t.phi0, t.inv_s2, t.nbar, t.kappa, t.pw_scale, t.kap2[0], t.kap2[1], 0.f};
     std::memcpy(misc8, m, sizeof(m));
+    return FMD_OK;
+}
+
+int fmd_design_wrap_tie(uint32_t* bits2048) {
+    if (!bits2048) return FMD_ERR_ARG;
+    design_wrap_tie(bits2048);
     return FMD_OK;
 }
 

@@ -123,12 +123,14 @@ struct PllSparseTab {
     float wsum[8], wmom[8];          // sum_n w[r][n], sum_n w[r][n] (n - nbar): the rows applied to a + b (n - nbar)
     float s[kSpanRows][8];           // weights of (lpf, I, e1, e2, r0)
     float sw[kSpanRows][kSpan + 4];  // sw[r][n] = sum_{n' >= n} w[r][n'] (the rare span in which the error crosses half a turn)
+    // (carried here for the front end, which has this table's pointer) u8 captures: the reference's wrap of a phase difference of exactly pi
+    // between two samples in opposite directions, one bit per first sample (y_raw << 8 | x_raw): 1 = the wrapped difference is +pi
+    // (fmd_kernels.hip wrap_tie_u8)
+    uint32_t wrap_tie[2048];
 };
 // rows of the fast-mode planes carry the previous block's last samples in front (written by k_pll_span of that block), so the
 // consumers address history and block uniformly
 static constexpr int kFrontImgU4 = 2 * 3 * 2 * 64;   // uint4s of k_front_mfma's two operand images in Buffers::front_mfma; k_predecim_mfma's image follows them
-// k_extract_bp's tap tables (fmd_kernels_bp.inc): kBpTL bf16 each, tap i at element kBpPadL + i
-static constexpr int kBpPadL = 64, kBpTL = 336, kBpSlotTabs = 6;
 static constexpr int kFoPad = 192;   // fm_out: k_extract_mfma reaches back 124 + 64 samples (its Hilbert FIR), k_pll_span 33 (65 while a station warms up)
 
 struct Dims {
@@ -198,9 +200,9 @@ struct Buffers {
     uint4*  aud_img;                 // ... of k_extract_mfma's audio FIRs, one per distinct cut-off: [slot][k-step][hi/lo][lane]
     int2*   aud_idx;                 // [C] slots of a station's L+R and L-R images
     uint4*  rds_img;                 // ... of the RDS FIR
-    uint4*  bp_img;                  // k_extract_bp: per distinct cut-off the tap tables of the L+R FIR and of the L-R composite band-pass FIR (kBpSlotU4 uint4s a slot)
+    uint4*  bp_img;                  // k_extract_bp: per distinct cut-off the operand images of the L+R FIR and of the L-R composite band-pass FIR's two rails (kBpSlotU4 uint4s a slot)
     uint4*  rds_bp_img;              // ... of the RDS composite band-pass FIR and of its first-order term
-    float*  hil_odd;                 // [32] the Hilbert FIR's non-zero taps b[1], b[3], ... (k_extract_bp's block-edge sums)
+    uint4*  bp_edge;                 // ... per cut-off slot [31 outputs][8 lanes][6] (fp16 pairs): the matrix of the block's first outputs' sums over the previous block's samples
     uint4*  front_mfma;              // FMD_FLAG_FAST_MATH only: Toeplitz operand images of k_front_mfma's two FIRs, [fir][k-step][hi/lo][lane]; m > 1: then k_predecim_mfma's
     unsigned int* pll_chain;         // [wavefronts of k_pilot_pll + 1] last block number each wavefront completed; [last] = watchdog flag
     unsigned long long* spec_stats;  // [8] speculation counters: pll {chunks, general, replayed, -}, rds {chunks, general, replayed, -}

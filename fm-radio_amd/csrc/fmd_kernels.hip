@@ -297,10 +297,30 @@ __device__ unsigned long long g_f_probe[16];
 // The front end from the tile's phases on (k_front_mfma, k_front_pre_mfma): theta[0 .. NW) = the phases (turns) of fm_in samples
 // 2 o0 - TAIL ..., in LDS; dem32 = the 16-byte aligned start of that region, over which the discriminator output is written in place
 // (theta may start up to 8 bytes into it).  All threads of the workgroup, phases complete (a barrier behind the writer).
-template <int TT, int WU>
+// u8 captures at 256 kSa/s: the discriminator's wrap at EXACTLY half a turn.  Two consecutive integer samples in exactly opposite directions
+// (a deep fade: a few LSB of signal), or a zero sample next to one on the negative real axis, differ by pi, and the reference's
+//   if (d >= pi) d -= 2 pi; else if (d <= -pi) d += 2 pi                                   (fm_demod.cpp:36-43)
+// then turns on the last bit of glibc's atan2f: its result is +pi or -pi, one full turn of the discriminator's range apart (a click of
+// either sign).  The pair's outcome depends only on the first sample's direction: PllSparseTab::wrap_tie, one bit per u8 sample,
+// made on the host with the exact restatement of atan2f (fmd_api.cpp).  Found by tests/test_gpu_realistic.py (fading captures).
+__device__ __forceinline__ float wrap_tie_u8(float dflt, int x0, int y0, int x1, int y1, const uint32_t* __restrict__ tie) {
+    const int cross = x1 * y0 - y1 * x0, dot = x1 * x0 + y1 * y0;
+    if (cross == 0 && dot < 0) { const unsigned key = ((unsigned)(y0 + 127) << 8) | (unsigned)(x0 + 127); return ((tie[key >> 5] >> (key & 31u)) & 1u) ? 0.5f : -0.5f; }
+    if ((x0 | y0) == 0 && y1 == 0 && x1 < 0) return -0.5f;       // atan2f(0, 0) = 0, atan2f(+0, x < 0) = +pi: a difference of +pi wraps to -pi
+    if ((x1 | y1) == 0 && y0 == 0 && x0 < 0) return 0.5f;
+    return dflt;
+}
+__device__ __forceinline__ int2 raw_u8(const uchar2* __restrict__ in_c, const float2* __restrict__ tail_c, int tail, int g) {
+    if (g < 0) { const float2 v = tail_c[tail + g]; return make_int2((int)v.x, (int)v.y); }
+    const uchar2 v = in_c[g];
+    return make_int2((int)v.x - 127, (int)v.y - 127);
+}
+
+template <int TT, int WU, bool TIES = false>
 __device__ __forceinline__ void front_from_phases(const Dims& d, float* smem, const float* theta, uint32_t* dem32, int c, int o0, int tid, float fm_gain,
                                                   const float* __restrict__ deemph, const FrontOps& op, float* __restrict__ fo_pl,
-                                                  float4* __restrict__ pv_pl, const PllSparseTab* __restrict__ sp) {
+                                                  float4* __restrict__ pv_pl, const PllSparseTab* __restrict__ sp,
+                                                  const uchar2* __restrict__ raw_c = nullptr, const float2* __restrict__ raw_tail = nullptr, int raw_tail_len = 0, int g_lo = 0) {
     using G = FrontGeomM<TT, WU>;
     constexpr int T = G::T, NW = G::NW, NF = G::NF;
     const int lane = tid & (kWave - 1), wv = tid >> 6, lrow = lane & 15, lq = lane >> 4;
@@ -325,6 +345,16 @@ __device__ __forceinline__ void front_from_phases(const Dims& d, float* smem, co
                 const float t0 = theta[j], t1 = theta[j + 1], t2 = (j + 2 < NW) ? theta[j + 2] : t1;
                 float d0 = t1 - t0, d1 = t2 - t1;
                 d0 = d0 - rintf(d0); d1 = d1 - rintf(d1);           // reference fm_demod.cpp:36-43: the phase difference wrapped to half a turn
+                if constexpr (TIES) {
+                    if (__builtin_expect(fabsf(fabsf(d0) - 0.5f) < 2.0e-6f || fabsf(fabsf(d1) - 0.5f) < 2.0e-6f, 0)) {      // (wrap_tie_u8 above)
+                        const int2 s0 = raw_u8(raw_c, raw_tail, raw_tail_len, g_lo + j), s1 = raw_u8(raw_c, raw_tail, raw_tail_len, g_lo + j + 1);
+                        if (fabsf(fabsf(d0) - 0.5f) < 2.0e-6f) d0 = wrap_tie_u8(d0, s0.x, s0.y, s1.x, s1.y, sp->wrap_tie);
+                        if (j + 2 < NW && fabsf(fabsf(d1) - 0.5f) < 2.0e-6f) {
+                            const int2 s2 = raw_u8(raw_c, raw_tail, raw_tail_len, g_lo + j + 2);
+                            d1 = wrap_tie_u8(d1, s1.x, s1.y, s2.x, s2.y, sp->wrap_tie);
+                        }
+                    }
+                }
                 d0 *= gain_t; d1 = (j + 1 < NW - 1) ? d1 * gain_t : 0.0f;
                 uint32_t h0, l0, h1, l1;
                 split_bf16(d0, h0, l0); split_bf16(d1, h1, l1);
@@ -547,7 +577,9 @@ __global__ __launch_bounds__(256, FUSED ? 6 : 5) void k_front_mfma(Dims d, const
     F_STAMP(0);
     __syncthreads();
     F_STAMP(1);
-    front_from_phases<TT, WU>(d, smem, theta, reinterpret_cast<uint32_t*>(smem), c, o0, tid, fm_gain, deemph, op, fo_pl, pv_pl, sp);
+    if constexpr (sizeof(InT) == 2) front_from_phases<TT, WU, true>(d, smem, theta, reinterpret_cast<uint32_t*>(smem), c, o0, tid, fm_gain, deemph, op, fo_pl, pv_pl, sp,
+                                                                    in_c, tail_c, G::TAIL, g_lo);
+    else front_from_phases<TT, WU>(d, smem, theta, reinterpret_cast<uint32_t*>(smem), c, o0, tid, fm_gain, deemph, op, fo_pl, pv_pl, sp);
     if (tile == tiles - 1) {
         float2* tout = tail_out + (size_t)c * d.tail_base;
         for (int idx = tid; idx < d.tail_base; idx += 256) tout[idx] = load_iq(in_c, (unsigned)(d.N - d.tail_base + idx));
@@ -3130,11 +3162,18 @@ static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     }
     if constexpr (FAST && TA == 256) {   // tolerance mode: the FIRs on the matrix cores
         if (!ctx.extract_mix) {          // round 5: the mixers behind the FIRs (fmd_kernels_bp.inc)
-            const int tiles = d.n_audio / TA, nt = (tiles % 4 == 0) ? 4 : ((tiles % 2 == 0) ? 2 : 1);     // tiles per workgroup: its operand images stay in registers
-            FMD_LAUNCH(r, true, true, k_extract_bp, dim3((unsigned)(tiles / nt * d.C)), dim3(TA), 0, s, d, nt, b.fo_pl[r.buf], b.pll_poly[r.buf],
-                       b.bp_img, b.aud_idx, b.rds_bp_img, b.b_lmr, b.mix,
+            const int tiles = d.n_audio / TA;
+            // tiles per workgroup (its operand images are loaded once): the whole block when that still leaves two rounds of workgroups for
+            // the chip (3 per CU: measured 4096 stations x 8 tiles: 0.119 ms with 8 tiles per workgroup, 0.137 with 4, 0.15 with 1), else the
+            // largest divisor that does
+            int nt = 1;
+            for (int v = tiles; v >= 1; v--) if (tiles % v == 0 && (long)(tiles / v) * d.C >= 1536) { nt = v; break; }
+            if (const char* e = dev_env("FMD_BP_NT")) { const int v = atoi(e); if (v > 0 && tiles % v == 0) nt = v; }      // (development A/B)
+            if (dev_env("FMD_BP_NOEDGE")) nt |= 0x100;                       // (development, timing only: the first tile's sums over the previous block skipped)
+            FMD_LAUNCH(r, true, true, k_extract_bp, dim3((unsigned)(tiles / (nt & 0xff) * d.C)), dim3(TA), 0, s, d, nt, b.fo_pl[r.buf], b.pll_poly[r.buf],
+                       b.bp_img, b.aud_idx, b.rds_bp_img, b.bp_edge, b.mix,
                        b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est[r.par], b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps,
-                       lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr, lmr_field(r.par), lmr_field(r.par ^ 1), b.rds_pow[r.buf], b.hil_odd);
+                       lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr, lmr_field(r.par), lmr_field(r.par ^ 1), b.rds_pow[r.buf]);
             return;
         }
         FMD_LAUNCH(r, true, true, k_extract_mfma, dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fo_pl[r.buf], b.front_mfma + 6 * kWave, b.pll_poly[r.buf],

@@ -127,16 +127,27 @@ private:
             const int rc = t.u8 ? fmd_submit_u8_dev(handles[(size_t)r], t.iq, C, N, nullptr)
                                 : fmd_submit_cf32_dev(handles[(size_t)r], reinterpret_cast<const float*>(t.iq), C, N, nullptr);
             // (a failed rank aborts the gather: the collector and the other ranks must not wait for its block)
-            if (rc != FMD_OK) { { std::lock_guard<std::mutex> lk(k.mu); k.error = std::string("fmd_submit: ") + fmd_last_error(handles[(size_t)r]); } fmd_gather_abort(gather); continue; }
+            if (rc != FMD_OK) {
+                const std::string e = "rank " + std::to_string(r) + ": fmd_submit: " + fmd_last_error(handles[(size_t)r]);
+                note_first(e);
+                { std::lock_guard<std::mutex> lk(k.mu); k.error = e; }
+                fmd_gather_abort(gather);
+                continue;
+            }
             if (fmd_gather_submit(gather, r) != FMD_OK) {
-                { std::lock_guard<std::mutex> lk(k.mu); if (!k.stop) k.error = std::string("fmd_gather_submit: ") + fmd_gather_last_error(gather); }
+                const std::string e = "rank " + std::to_string(r) + ": fmd_gather_submit: " + fmd_gather_last_error(gather);
+                note_first(e);
+                { std::lock_guard<std::mutex> lk(k.mu); if (!k.stop) k.error = e; }
                 fmd_gather_abort(gather);
             }
         }
     }
     void rethrow() {
+        // the FIRST failure is the cause: the other ranks' "gather aborted" errors follow from it
+        { std::lock_guard<std::mutex> lk(first_mu); if (!first_error.empty()) throw std::runtime_error("MultiGpuHost: " + first_error); }
         for (Rank& k : ranks) { std::lock_guard<std::mutex> lk(k.mu); if (!k.error.empty()) throw std::runtime_error("MultiGpuHost: " + k.error); }
     }
+    void note_first(const std::string& e) { std::lock_guard<std::mutex> lk(first_mu); if (first_error.empty()) first_error = e; }
     void cleanup() {
         if (gather) { fmd_gather_destroy(gather); gather = nullptr; }
         for (fmd_handle& h : handles) if (h) { fmd_destroy(h); h = nullptr; }
@@ -149,6 +160,8 @@ private:
     long submitted = 0, collected = 0;   // blocks (caller thread only)
     fmd_rates rates{};
     std::vector<Rank> ranks;
+    std::mutex first_mu;
+    std::string first_error;
 };
 
 }  // namespace fmd_host

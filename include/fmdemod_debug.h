@@ -54,6 +54,11 @@ int fmd_design_pll_sparse(int fs_baseband, float* taps, float* cplx, float* rows
  * tests/test_bandpass_design.py checks them against the reference's order of operations in float64. */
 int fmd_design_extract_bp(int fs_baseband, int cutoff_hz, float* g2, float* g3);
 
+/* The tolerance mode's table for the discriminator's wrap at exactly half a turn on u8 captures (fmd_kernels.hip wrap_tie_u8): 65536 bits,
+ * bit (y_raw << 8 | x_raw) = 1 when the reference's wrapped phase difference from sample (x_raw, y_raw) to one in exactly the opposite direction
+ * is +pi.  tests/test_wrap_tie.py checks it against glibc's atan2f. */
+int fmd_design_wrap_tie(uint32_t* bits2048);
+
 /* Counters of k_pilot_pll's frequency speculation since creation / the last reset (DESIGN.md "Pilot PLL"):
  * out8[0] = 128-sample chunks, summed over wavefronts (4 channels each); out8[1] = of those, chunks run with the plain serial
  * iteration (wavefront out of lock); out8[2] = spans redone with the reference forms (a short form outside its domain);
