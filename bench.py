@@ -73,6 +73,20 @@ def lookup_traffic(kernel: str, C: int, fs: int, block: int, u8: bool, fast: boo
         return None
 
 
+def chain_traffic(C: int, fs: int, block: int, u8: bool, fast: bool):
+    """HBM bytes ONE STEP moves — the sum over the steady chain's kernels of the committed PMC table — or None when one of them was not
+    profiled in this configuration.  (The chain of a steady block: the front end (with the first decimator at 1.024 / 2.048 MSa/s), the pilot
+    stage, the extract stage, the RDS stage; the exact mode's five kernels.)"""
+    if fast:
+        names = ["k_front_mfma" if fs == 256_000 else "k_front_pre_mfma", "k_pll_sparse", "k_extract_bp", "k_rds_sync"]
+    else:
+        names = (["k_predecim"] if fs != 256_000 else []) + ["k_front", "k_pilot_power", "k_pilot_pll", "k_extract", "k_rds_sync"]
+    per = {n: lookup_traffic(n, C, fs, block, u8, fast) for n in names}
+    if any(v is None for v in per.values()):
+        return None, per
+    return float(sum(per.values())), per
+
+
 def dominant_kernel(avg_ms: dict, ms_per_step: float, fast: bool):
     """The kernel `roofline` is quoted on: the longest average launch.  Tolerance mode: its two throughput kernels (k_front_mfma,
     k_extract_mfma) take turns on one queue while the serial stages (k_rds_sync: 64 workgroups; the pilot stage rides in the front end's launch) run
@@ -347,7 +361,9 @@ def measure_config(torch, pkg, device, label: str, C: int, fs: int, u8: bool, fa
             "mode": MODE_TEXT[fast], "steps": steps, "ms_per_step": el / steps * 1e3, "value": value, "unit": "MSa/s",
             "channels_at_realtime": value * 1e6 / fs, "algorithmic_bytes_per_sample": bps,
             "roofline": {"kernel": dom[0], "avg_launch_ms": dom[1], "frac": (bps * C * block / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom[1] else None,
-                         "whole_step_frac": bps * value * 1e6 / 1e9 / HBM_PEAK_GBS, "traffic": lookup_traffic(dom[0], C, fs, block, u8, fast) if dom[0] else None,
+                         "whole_step_frac": bps * value * 1e6 / 1e9 / HBM_PEAK_GBS,
+                         "traffic": chain_traffic(C, fs, block, u8, fast)[0],       # the chain's HBM bytes per step (committed PMC table), None if not profiled
+                         "traffic_ratio": (lambda t: None if t is None else t / (bps * C * block))(chain_traffic(C, fs, block, u8, fast)[0]),
                          "kernels_ms_per_step": kt}}
 
 
@@ -407,8 +423,10 @@ def main() -> None:
     ap.add_argument("--config3", action="store_true", help="BASELINE configs[3] literally: 8192 stations per GPU (65 536 on 8 GPUs); the default for "
                     "every N is configs[2]'s 4096 per GPU, so that the per-N values the driver compares are one workload (weak scaling)")
     ap.add_argument("--gather", default="rotate", choices=["rotate", "root", "all", "none"],
-                    help="N>1: per-step audio collective — 'root': every rank sends its block to rank 0 (point-to-point over the "
-                         "direct xGMI links; default), 'all': all-gather to every rank, 'none': no collective")
+                    help="N>1: per-step output collective — 'rotate' (default): block k is gathered on rank (k mod N), point-to-point over the "
+                         "direct xGMI links, every GPU's PCIe link takes 1/N of the hand-over; 'root': every rank sends its block to rank 0; "
+                         "'all': all-gather to every rank; 'none': no collective.  The mode is recorded in the result's `gather` object and in "
+                         "`config.gather_mode`: per-link figures of 'rotate' and 'root' runs are not comparable")
     ap.add_argument("--gather-format", default="pcm16", choices=["pcm16", "f32"],
                     help="payload of the audio collective: the 16-bit PCM frames the reference's scraper writes (default) or raw f32")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
@@ -599,7 +617,10 @@ def main() -> None:
         avg_ms = dom[1]
         algo_bytes = bps * C * block  # per launch: every kernel launch covers one block of all local channels
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = lookup_traffic(dom[0], C, fs, block, args.u8, args.fast_math)
+        traffic_dom = lookup_traffic(dom[0], C, fs, block, args.u8, args.fast_math)
+        traffic, traffic_per_kernel = chain_traffic(C, fs, block, args.u8, args.fast_math)
+        all_avg = {k: v[0] / max(v[1], 1) for k, v in ktimes.items()}
+        longest = max(all_avg, key=all_avg.get) if all_avg else None
         # second roof: the chain is fp32-VALU work; profiles/valu_instructions.json holds the PMC count of VALU
         # wave-instructions one block costs (tools/collect_profiles.sh), the chip issues 1024 SIMDs x clock / 4 of them per second
         valu = None
@@ -619,9 +640,15 @@ def main() -> None:
             except Exception:
                 valu = None
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": achieved / HBM_PEAK_GBS,
+                    # HBM bytes one step really moves: the CHAIN's (every kernel of a steady block), beside the algorithmic bytes `achieved` is made of
+                    "traffic": traffic, "traffic_ratio": None if traffic is None else traffic / algo_bytes,
+                    "traffic_per_kernel": traffic_per_kernel, "traffic_dominant_kernel": traffic_dom,
                     "traffic_source": None if traffic is None else "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                       "configuration (tools/collect_round.sh), committed; not re-measured by this run",
+                    # the longest launch of the step whatever its queue (the serial RDS stage runs beside the two throughput kernels on a queue of its own)
+                    "kernel_longest": None if longest is None else {"kernel": longest, "avg_launch_ms": all_avg[longest],
+                                                                    "frac": algo_bytes / (all_avg[longest] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                     "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_launch": algo_bytes,
                     "whole_step_frac": (bps * C * block * K / el / 1e9) / HBM_PEAK_GBS if world == 1 else None,
@@ -655,7 +682,8 @@ def main() -> None:
                    "mode": MODE_TEXT[args.fast_math],
                    "unlocked_frac": args.unlocked_frac, "unlocked_kind": args.unlocked_kind if args.unlocked_frac > 0 else None,
                    "deemphasis_us": args.deemphasis or None,
-                   "parallelism": f"channel-sharded x{world}" + gather_note},
+                   "parallelism": f"channel-sharded x{world}" + gather_note,
+                   "gather_mode": args.gather if do_gather else None},
         "gather_verified": gather_verified,
         # what the per-step gather asks of the collector's xGMI links (one direct link per peer): at throughput-mode rates this, not the
         # demodulation, can bound the multi-GPU step

@@ -9,7 +9,8 @@ The directory name contains a hyphen, so import it through `fmradio_loader.load(
 `importlib` with the module name `fm_radio_amd`.
 """
 from .capi import (  # noqa: F401
+    FMD_FLAG_FAST_MATH,
     FMD_AUDIO_LMR, FMD_AUDIO_LPR, FMD_AUDIO_STEREO, FMD_FLAG_KEEP_TAPS, FMD_FLAG_NO_PIPELINE, BatchDemod, Coeffs, Config, Controls, FmdError,
-    Channelizer, Rates, build_library, chan_design, declared_symbols, default_controls, lib_path, load_library, selftest_atan2, selftest_atan2_small, selftest_fast_math,
+    Channelizer, Rates, build_library, chan_design, declared_symbols, default_config, default_controls, lib_path, load_library, selftest_atan2, selftest_atan2_small, selftest_fast_math,
 )
 from .sharding import AudioGather, channel_range, padded_shard  # noqa: F401,E402

@@ -118,6 +118,7 @@ def load_library():
     L.fmd_status_string.argtypes = [C.c_int]
     L.fmd_device_count.restype = C.c_int
     L.fmd_default_controls.argtypes = [C.POINTER(Controls)]
+    L.fmd_default_config.argtypes = [C.POINTER(Config), C.c_int, C.c_int]
     L.fmd_create.argtypes = [C.POINTER(Config), C.POINTER(H)]
     L.fmd_destroy.argtypes = [H]
     L.fmd_reset.argtypes = [H]
@@ -214,6 +215,15 @@ def default_controls() -> Controls:
     c = Controls()
     load_library().fmd_default_controls(C.byref(c))
     return c
+
+
+def default_config(n_channels: int, fs_baseband: int = 1_024_000) -> "Config":
+    """fmd_default_config: 64 ms blocks, the tolerance mode (what a many-station deployment wants; flags = 0 is the bit-exact mode)."""
+    cfg = Config()
+    rc = load_library().fmd_default_config(C.byref(cfg), n_channels, fs_baseband)
+    if rc != FMD_OK:
+        raise FmdError(rc, "unsupported configuration")
+    return cfg
 
 
 class BatchDemod:

@@ -951,6 +951,16 @@ void fmd_default_controls(fmd_controls* c) {
     c->lmr_cutoff_hz = 15000;
 }
 
+int fmd_default_config(fmd_config* cfg, int n_channels, int fs_baseband) {
+    if (!cfg || n_channels <= 0 || (fs_baseband != 256000 && fs_baseband != 1024000 && fs_baseband != 2048000)) return FMD_ERR_ARG;
+    cfg->n_channels = n_channels;
+    cfg->block_size = 16384 * (fs_baseband / 256000);     // 64 ms: the reference's 65536 samples at 1.024 MSa/s
+    cfg->fs_baseband = fs_baseband;
+    cfg->device = -1;
+    cfg->flags = FMD_FLAG_FAST_MATH;
+    return FMD_OK;
+}
+
 int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     if (!out) return FMD_ERR_ARG;
     *out = nullptr;
@@ -978,8 +988,8 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     std::vector<uint32_t> mask_f, mask_x;
     auto parse_mask = [](const char* e, std::vector<uint32_t>& m) { while (e && *e) { char* end = nullptr; const unsigned long v = strtoul(e, &end, 16); if (!end || end == e) break; m.push_back((uint32_t)v); e = *end ? end + 1 : end; } };   // (any one non-hex character separates the words)
     parse_mask(dev_env("FMD_CU_MASK_F"), mask_f); parse_mask(dev_env("FMD_CU_MASK_X"), mask_x);
-    h->split_queues = !mask_f.empty() && !mask_x.empty();
-    { hipError_t e = h->split_queues ? hipExtStreamCreateWithCUMask(&h->own_stream, (uint32_t)mask_f.size(), mask_f.data()) : hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    h->split_queues = (!mask_f.empty() && !mask_x.empty()) || dev_env("FMD_SPLIT_QUEUES") != nullptr;     // FMD_SPLIT_QUEUES: the two-queue schedule on plain (unmasked) queues, with FMD_STREAM_PRIORITIES
+    { hipError_t e = !mask_f.empty() ? hipExtStreamCreateWithCUMask(&h->own_stream, (uint32_t)mask_f.size(), mask_f.data()) : hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
       if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e))); }
 
     h->pipelined = (cfg->flags & FMD_FLAG_NO_PIPELINE) == 0;
@@ -994,14 +1004,14 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     {
         // experiment hook: FMD_STREAM_PRIORITIES="f,b,x,r" — priorities of the front / PLL / extract / RDS streams (0 = default, negative = higher)
         int prio[6] = {0, 0, 0, 0, 0, 0};       // sF, sD, sA, sB, sX, sR
-        if (const char* e = dev_env("FMD_STREAM_PRIORITIES")) { int f = 0, b = 0, x = 0, r = 0; if (std::sscanf(e, "%d,%d,%d,%d", &f, &b, &x, &r) == 4) { prio[0] = f; prio[1] = f; prio[3] = b; prio[4] = x; prio[5] = r; } }
+        if (const char* e = dev_env("FMD_STREAM_PRIORITIES")) { int f = 0, b = 0, x = 0, r = 0; if (std::sscanf(e, "%d%*c%d%*c%d%*c%d", &f, &b, &x, &r) == 4) { prio[0] = f; prio[1] = f; prio[3] = b; prio[4] = x; prio[5] = r; } }
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         int i = 0;
         for (hipStream_t* st : {&h->sF, &h->sD, &h->sA, &h->sB, &h->sX, &h->sR}) {
             const int p = std::min(least, std::max(greatest, prio[i++]));
             hipError_t e;
-            if (h->split_queues && (st == &h->sF || st == &h->sX)) { const auto& mk = st == &h->sF ? mask_f : mask_x; e = hipExtStreamCreateWithCUMask(st, (uint32_t)mk.size(), mk.data()); }
+            if (!mask_f.empty() && !mask_x.empty() && (st == &h->sF || st == &h->sX)) { const auto& mk = st == &h->sF ? mask_f : mask_x; e = hipExtStreamCreateWithCUMask(st, (uint32_t)mk.size(), mk.data()); }
             else e = p ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, p) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
             if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e)));
         }
@@ -1627,6 +1637,7 @@ int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out) {
             HIP_TRY(h, hipEventElapsedTime(&ms, pm->t0[i], pm->t1[i]));
             int slot = -1;
             const char* nm = h->ctx.fast ? kStageNameFast[i] : kStageName[i];
+            if (h->ctx.fast && i == ST_EXTRACT && !h->ctx.extract_mix && h->ctx.d.n_audio % 256 == 0) nm = "k_extract_bp";      // (round 5: fmd_kernels_bp.inc)
             if (i == ST_FRONT && front_takes_capture(h->ctx)) nm = "k_front_pre_mfma";
             for (int j = 0; j < n; j++) if (std::strncmp(out[j].name, nm, sizeof(out[j].name)) == 0) { slot = j; break; }
             if (slot < 0) {

@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "fmdemod.h"
+#include "fmd_kernels.h"     // dev_env: development switches are read only in builds with -DFMD_DEV_HOOKS
 
 namespace {
 
@@ -134,6 +135,9 @@ constexpr int kMK = 16 * kMKW;              // 1232
 constexpr int kMRail = 5608;                // floats per rail: (kMG - 1) M + kMK <= 5608, and 5608 mod 32 == 8 (bank offset between the rails)
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+// Non-finite input: the banded operand multiplies EVERY staged sample of a group's 1232-sample window, its structural zeros included, so
+// one Inf / NaN input sample makes all 16 outputs of every group whose window holds it NaN (the VALU form only those with a real tap on
+// it).  A capture from a device is u8 / finite by construction; a host that may feed non-finite floats filters them at its boundary.
 __global__ __launch_bounds__(256, 3) void k_channelize16_mfma(ChanDims d, const float2* __restrict__ win, const float* __restrict__ atab /* [4][77][64] */,
                                                            const unsigned long long* __restrict__ phase_inc, float2* __restrict__ out, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -322,7 +326,7 @@ int fmd_chan_create(const fmd_chan_config* cfg, fmd_channelizer* out) {
     ok = ok && hipMemcpy(h->taps, h->h_taps.data(), sizeof(float) * h->h_taps.size(), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(h->inc, inc.data(), sizeof(unsigned long long) * h->C, hipMemcpyHostToDevice) == hipSuccess;
     // the matrix-core form: L == 16 and the operand / window sizes it is built for (10 MSa/s -> 256 kSa/s with 640 taps per phase)
-    if (ok && L == 16 && (15 * M) / 16 + T <= kMK && (kMG - 1) * M + kMK <= kMRail && !getenv("FMD_CHAN_VALU")) {
+    if (ok && L == 16 && (15 * M) / 16 + T <= kMK && (kMG - 1) * M + kMK <= kMRail && !fmd::dev_env("FMD_CHAN_VALU")) {
         std::vector<float> at((size_t)4 * kMKW * 64, 0.0f);
         for (int w = 0; w < 4; w++)
             for (int j = 0; j < kMKW; j++)

@@ -867,7 +867,8 @@ struct FrontPreGeom {
     static_assert(NCOLS % NSUB == 0 && NBS % 8 == 0 && SEG * (CS - 1) + 32 * KS <= NBS && GF::NWB >= NPH + 1, "geometry");
 };
 template <int M, typename InT, bool FUSED>
-__global__ __launch_bounds__(256, (FrontPreGeom<M, sizeof(InT) == 2>::MINWG)) void k_front_pre_mfma(Dims d, const InT* __restrict__ in, const float2* __restrict__ pre_tail_in, float2* __restrict__ pre_tail_out,
+// (launch bounds: the un-fused u8 form — small batches, start-up blocks — takes four workgroups per CU like the others: at five it spilled 24 bytes per lane)
+__global__ __launch_bounds__(256, (FUSED ? FrontPreGeom<M, sizeof(InT) == 2>::MINWG : 4)) void k_front_pre_mfma(Dims d, const InT* __restrict__ in, const float2* __restrict__ pre_tail_in, float2* __restrict__ pre_tail_out,
                                                            const float2* __restrict__ tail_in, float2* __restrict__ tail_out, float* __restrict__ fo_pl, float fm_gain,
                                                            const uint4* __restrict__ tab_pre, const uint4* __restrict__ tab, float4* __restrict__ pv_pl,
                                                            const PllSparseTab* __restrict__ sp, PllFusedArgs pf) {

@@ -129,6 +129,12 @@ const char* fmd_status_string(int status);
 int         fmd_device_count(void);
 
 void fmd_default_controls(fmd_controls* c);
+/* A configuration for `n_channels` stations of `fs_baseband` with 64 ms blocks (the reference's 65536 samples at 1.024 MSa/s,
+ * broadcast_fm_demod.cpp:62-77, scaled to the rate), on the current device, in the mode a many-station deployment wants:
+ * FMD_FLAG_FAST_MATH (the tolerance mode above).  `flags = 0`, the bit-exact mode, is what a parity harness asks for explicitly —
+ * it costs ~3x per block, and ~13x as soon as 1 % of the stations have no lockable pilot (a band scan: most channels are empty).
+ * Returns FMD_ERR_ARG for an unsupported rate. */
+int  fmd_default_config(fmd_config* cfg, int n_channels, int fs_baseband);
 
 /* Broadcast_FM_Demod::Broadcast_FM_Demod (broadcast_fm_demod.cpp:59-305) x n_channels */
 int fmd_create(const fmd_config* cfg, fmd_handle* out);

@@ -147,3 +147,14 @@ int main() {
     subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", f"-I{csrc}", str(src), "-o", str(exe)], check=True)
     n, bad = map(int, subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split())
     assert n > 12_000_000 and bad == 0
+
+
+def test_default_config_is_the_tolerance_mode_with_64_ms_blocks(pkg):
+    """fmd_default_config: the mode a band scan wants is what a caller gets without knowing the flags; flags = 0 stays the
+    bit-exact mode for parity harnesses (reference block: 65536 samples at 1.024 MSa/s, broadcast_fm_demod.cpp:62-77)."""
+    for fs, bs in ((256_000, 16384), (1_024_000, 65536), (2_048_000, 131072)):
+        cfg = pkg.default_config(40, fs)
+        assert (cfg.n_channels, cfg.block_size, cfg.fs_baseband, cfg.device) == (40, bs, fs, -1)
+        assert cfg.flags == pkg.FMD_FLAG_FAST_MATH
+    with pytest.raises(pkg.FmdError):
+        pkg.default_config(4, 48_000)

@@ -108,7 +108,8 @@ def soft_symbol_stats(sym_g, cnt_g, sym_o, cnt_o, lock_blocks):
     big = d > 1e-2
     return {"compared_from_block": int(first), "symbols": m, "median": float(np.median(d)), "p99": float(np.percentile(d, 99)),
             "rms": float(np.sqrt(np.mean(d ** 2))), "moved_over_1e-2": int(big.sum()),
-            "rms_of_the_rest": float(np.sqrt(np.mean(d[~big] ** 2))) if (~big).any() else 0.0}
+            "rms_of_the_rest": float(np.sqrt(np.mean(d[~big] ** 2))) if (~big).any() else 0.0,
+            "p99_of_the_rest": float(np.percentile(d[~big], 99)) if (~big).any() else 0.0}
 
 
 def record_parity_metrics(name, metrics):

@@ -189,7 +189,9 @@ def test_tolerance_mode_rds_stage_on_pipelined_wavefronts(pkg):
             "stations": n_st, "stations_compared": len(stats), "symbols_compared": total, "symbols_moved_over_1e-2": moved,
             "median_of_station_medians": float(np.median([s["median"] for s in stats])), "worst_station_median": max(s["median"] for s in stats),
             "worst_station_p99": max(s["p99"] for s in stats), "worst_station_rms": max(s["rms"] for s in stats),
-            "median_station_rms": float(np.median([s["rms"] for s in stats])), "worst_station_rms_of_the_rest": max(s["rms_of_the_rest"] for s in stats)}
+            "median_station_rms": float(np.median([s["rms"] for s in stats])), "worst_station_rms_of_the_rest": max(s["rms_of_the_rest"] for s in stats),
+            "worst_station_p99_of_the_rest": max(s["p99_of_the_rest"] for s in stats),
+            "median_station_p99_of_the_rest": float(np.median([s["p99_of_the_rest"] for s in stats]))}
         print("RDS soft symbols against the oracle, in lock:", summary[f"keep_taps_{int(keep)}"])
         assert len(stats) >= int(np.ceil(0.9 * n_st)), (keep, len(stats))                 # at least 90 % of the stations are compared
         assert max(s["median"] for s in stats) <= 1e-4, keep                                 # every station: the typical symbol within 1e-4
@@ -198,6 +200,12 @@ def test_tolerance_mode_rds_stage_on_pipelined_wavefronts(pkg):
         # ... and the symbols that did not move by 1e-2, on every station: inside what the reference's own two builds show for theirs (1.1e-3 on
         # their worst station, 5e-4 on their typical one: a moved decision's neighbours trail it)
         assert max(s["rms_of_the_rest"] for s in stats) <= 1.1e-3, keep
+        # a TAIL bound as well (the bar of rounds 1-3 was p99 <= 1.4e-3 over all symbols of a station; since round 4 a few symbols per
+        # station move with a tipped clock decision — as in the reference's own builds — and the p99 is taken over the ones that did not):
+        # the typical station keeps the old bar; the worst station — the one with the most tipped decisions, whose neighbouring symbols trail
+        # them — measured 3.0e-3 (round 5), bounded at 4e-3.  THE BAR CHANGED in round 4: it was p99 <= 1.4e-3 over ALL symbols of every station.
+        assert float(np.median([s["p99_of_the_rest"] for s in stats])) <= 1.4e-3, keep
+        assert max(s["p99_of_the_rest"] for s in stats) <= 4e-3, keep
     F.record_parity_metrics("rds_soft_symbols_24_stations_2_s", summary)
     same = sum(int(np.array_equal(out[False][0][c], out[True][0][c])) for c in range(n_st))
     assert same == n_st                                     # (the flag changes nothing the demodulator computes)

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Everything a round's profiles/ directory is made from, in one gpurun call (GPU box, repo root): counters and traces of the default line
 # (tools/collect_round.sh), the driver's command, the stages alone (development build of the library: tools/ab/dev.so, built by
-# `make -C fm-radio_amd/csrc dev`) and the measurement table.  ROUND=N (default 4).
-export ROUND=${ROUND:-4}
+# `make -C fm-radio_amd/csrc dev`) and the measurement table.  ROUND=N (default 5).
+export ROUND=${ROUND:-5}
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 O=gpurun_out/r${ROUND}_evidence; mkdir -p $O
 bash tools/collect_round.sh > $O/collect.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Per-round evidence (run on the GPU box through gpurun, from the repo root; ROUND=N names the output, default 4): the default bench line, kernel-trace statistics and a
+# Per-round evidence (run on the GPU box through gpurun, from the repo root; ROUND=N names the output, default 5): the default bench line, kernel-trace statistics and a
 # pipelined trace digest of the same command, and PMC passes of the un-pipelined run — counters only, one rocprofv3 run per
 # counter set, no tracing domains combined with --pmc.  BENCH_ARGS=--exact for the exact mode (SFX names another configuration's output).  Outputs: gpurun_out/r<ROUND>prof<sfx>/.
 set -u
@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 X="${BENCH_ARGS:-}"
 if [ -z "${SFX+x}" ]; then SFX=""; [ -n "$X" ] && SFX="_exact"; fi      # SFX=_1024k BENCH_ARGS="--fs 1024000": another configuration
-ROUND=${ROUND:-4}
+ROUND=${ROUND:-5}
 O=$R/gpurun_out/r${ROUND}prof$SFX
 rm -rf $O && mkdir -p $O
 cd $R

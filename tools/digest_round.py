@@ -64,12 +64,12 @@ def reduce(o: pathlib.Path, sfx: str) -> None:
         "trace_digest": json.loads((o / "trace_digest.json").read_text() or "{}")}, indent=1))
 
 
-def install(rnd: str = "4") -> None:
+def install(rnd: str = "5") -> None:
     dst = ROOT / "profiles" / f"round{rnd}"
     dst.mkdir(parents=True, exist_ok=True)
     traffic_tab = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text())
     valu_tab = json.loads((ROOT / "profiles" / "valu_instructions.json").read_text())
-    for sfx in ("", "_exact", "_1024k", "_1024k_u8", "_8192", "_1ch"):
+    for sfx in ("", "_exact", "_u8", "_1024k", "_1024k_u8", "_8192", "_1ch"):
         f = ROOT / "gpurun_out" / f"r{rnd}prof{sfx}" / "digest.json"
         if not f.exists():
             continue
@@ -119,6 +119,6 @@ def install(rnd: str = "4") -> None:
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--install":
-        install(sys.argv[2] if len(sys.argv) > 2 else "4")
+        install(sys.argv[2] if len(sys.argv) > 2 else "5")
     else:
         reduce(pathlib.Path(sys.argv[1]), sys.argv[2] if len(sys.argv) > 2 else "")
