@@ -24,3 +24,15 @@ def test_gather_bookkeeping(driver, args):
     r = subprocess.run([str(driver), *args], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     assert json.loads(r.stdout.strip().splitlines()[-1])["failed_checks"] == 0
+
+
+@pytest.mark.parametrize("san,args", [("thread", ["run", "4", "100"]), ("thread", ["abort"]), ("address,undefined", ["plan"]), ("address,undefined", ["run", "3", "60"])])
+def test_gather_bookkeeping_under_sanitizers(tmp_path, san, args):
+    """The host-side hand-shake is lock-free (atomics between the rank threads and the collecting thread): ThreadSanitizer on the
+    simulated runs, AddressSanitizer / UBSan on the plan logic (CPU builds only: GPU sanitizers are not available on this pool)."""
+    exe = tmp_path / "gather_plan_san"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", f"-fsanitize={san}", "-fno-sanitize-recover=all", f"-I{ROOT / 'fm-radio_amd' / 'csrc'}",
+                    str(ROOT / "tests" / "cpp" / "gather_plan_main.cpp"), "-lpthread", "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stderr[-3000:], r.stdout[-500:])
+    assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr
