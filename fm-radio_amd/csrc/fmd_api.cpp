@@ -204,28 +204,41 @@ void bandpass_taps(const float* h, const float* b_hil, int H, float* g_re, float
     }
     for (int u = 0; u < kBpTaps; u++) { g_re[u] = (float)re[u]; g_im[u] = (float)im[u]; }
 }
-// image of a complex FIR with rows (output o, rail): A[2 o + rail][t] = g_rail[t - shift - stride o], 8 outputs x 2 rails per 16-row tile
-void toeplitz_image_rails(const float* g_re, const float* g_im, int n_taps, int stride, int ksteps, uint16_t* img, int shift) {
-    for (int sK = 0; sK < ksteps; sK++)
-        for (int l = 0; l < 64; l++)
-            for (int i = 0; i < 8; i++) {
-                const int row = l % 16, t = 32 * sK + 8 * (l / 16) + i, idx = t - shift - stride * (row >> 1);
-                const float v = (idx >= 0 && idx < n_taps) ? ((row & 1) ? g_im[idx] : g_re[idx]) : 0.0f;
-                const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
-                img[(((size_t)sK * 2 + 0) * 64 + l) * 8 + i] = hi;
-                img[(((size_t)sK * 2 + 1) * 64 + l) * 8 + i] = lo;
-            }
+// Tap tables of k_extract_bp (fmd_kernels_bp.inc): kBpTabTL bf16 each, tap i at element kBpTabPadL + i (+ 4 for a "copy 4" table)
+constexpr int kBpTabPadL = 96, kBpTabTL = 448;
+constexpr size_t kBpTabSlotU16 = (size_t)12 * kBpTabTL, kBpRdsTabU16 = (size_t)6 * kBpTabTL;
+void bp_tap_table(const float* taps, int n_taps, int move, uint16_t* hi, uint16_t* lo) {
+    for (int i = 0; i < kBpTabTL; i++) { hi[i] = 0; if (lo) lo[i] = 0; }
+    for (int i = 0; i < n_taps; i++) {
+        const uint16_t h = bf16_rne(taps[i]);
+        hi[kBpTabPadL + move + i] = h;
+        if (lo) lo[kBpTabPadL + move + i] = bf16_rne(taps[i] - bf16_to_f32(h));
+    }
 }
-// k_extract_bp's operand images (fmd_kernels_bp.inc): every family on 8 K-steps of a column's window W[64 c .. 64 c + 255]
-constexpr size_t kBpFamU16 = (size_t)8 * 2 * 64 * 8, kBpSlotU16 = 3 * kBpFamU16, kBpRdsU16 = kBpFamU16 + kBpFamU16 / 2;
-// a cut-off slot: L+R (rows = 16 outputs, taps 32 samples into the window: the analytic signal's real rail is fm_out delayed by 32), L-R composite re, im
-void bp_slot_images(const float* taps, const float* b_hil, uint16_t* dst) {
-    toeplitz_image(taps, 128, 4, 8, dst, 32);
+// a stride-4 family's block: [hi, copy 0][hi, copy 4][lo, copy 0][lo, copy 4]
+void bp_family_block(const float* taps, int n_taps, uint16_t* dst) {
+    bp_tap_table(taps, n_taps, 0, dst, dst + 2 * kBpTabTL);
+    bp_tap_table(taps, n_taps, 4, dst + kBpTabTL, dst + 3 * kBpTabTL);
+}
+void bp_slot_tap_tables(const float* taps, const float* b_hil, uint16_t* dst) {
+    bp_family_block(taps, 128, dst);
     float gr[kBpTaps], gi[kBpTaps];
     bandpass_taps(taps, b_hil, 2, gr, gi);
-    toeplitz_image(gr, kBpTaps, 4, 8, dst + kBpFamU16, 0);
-    toeplitz_image(gi, kBpTaps, 4, 8, dst + 2 * kBpFamU16, 0);
+    bp_family_block(gr, kBpTaps, dst + 4 * kBpTabTL);
+    bp_family_block(gi, kBpTaps, dst + 8 * kBpTabTL);
 }
+// RDS (rows (o, rail), band offset 4 + 8 o: every table moved on by four): S0 [re hi][im hi][re lo][im lo], S1 [re hi][im hi]
+void bp_rds_tap_tables(const float* b_rds, const float* b_hil, uint16_t* dst) {
+    float gr[kBpTaps], gi[kBpTaps], h1[128];
+    bandpass_taps(b_rds, b_hil, 3, gr, gi);
+    bp_tap_table(gr, kBpTaps, 4, dst, dst + 2 * kBpTabTL);
+    bp_tap_table(gi, kBpTaps, 4, dst + kBpTabTL, dst + 3 * kBpTabTL);
+    for (int i = 0; i < 128; i++) h1[i] = (float)(((double)i - 63.5) * (double)b_rds[i]);
+    bandpass_taps(h1, b_hil, 3, gr, gi);
+    bp_tap_table(gr, kBpTaps, 4, dst + 4 * kBpTabTL, nullptr);
+    bp_tap_table(gi, kBpTaps, 4, dst + 5 * kBpTabTL, nullptr);
+}
+
 // The block's first 31 L-R outputs, the part of their sums that lies in the PREVIOUS block (mixed with its L-R offset, reference
 // broadcast_fm_demod.cpp:485-517): S_old[m] = sum_{tau < 124 - 4 m} h[tau] e^{-j 2 pi 38 tau / 128} a[4 m - 124 + tau] = sum_u K_m[u] W[u],
 // W[u] = fm_out[u - 188], K_m[u] = (composite of the TRUNCATED taps)[u - 4 m].  Layout [m][lane p of 8][24 columns][re, im], fp16.
@@ -259,18 +272,6 @@ void bp_edge_matrix(const float* taps, const float* b_hil, uint16_t* dst) {
             e[0] = f32_to_f16_rne(gr[idx]); e[1] = f32_to_f16_rne(gi[idx]);
         }
     }
-}
-
-// RDS: S0 (rows = 8 outputs x rail); then the first-order term's S1 (taps (tau - 63.5) h[tau]), hi halves only, [K-step][lane]
-void bp_rds_images(const float* b_rds, const float* b_hil, uint16_t* dst) {
-    float gr[kBpTaps], gi[kBpTaps], h1[128];
-    bandpass_taps(b_rds, b_hil, 3, gr, gi);
-    toeplitz_image_rails(gr, gi, kBpTaps, 8, 8, dst, 4);
-    for (int i = 0; i < 128; i++) h1[i] = (float)(((double)i - 63.5) * (double)b_rds[i]);
-    bandpass_taps(h1, b_hil, 3, gr, gi);
-    std::vector<uint16_t> full(kBpFamU16);
-    toeplitz_image_rails(gr, gi, kBpTaps, 8, 8, full.data(), 4);
-    for (int sK = 0; sK < 8; sK++) std::memcpy(dst + kBpFamU16 + (size_t)sK * 64 * 8, full.data() + (size_t)sK * 2 * 64 * 8, sizeof(uint16_t) * 64 * 8);
 }
 
 const std::vector<float>& lpf_taps(fmd_handle h, int hz) {
@@ -324,10 +325,10 @@ int upload_controls(fmd_handle h, hipStream_t s) {
                 int rc = dev_alloc(h, &q, cap * kAudImgU16 * 2 / sizeof(uint4));
                 if (rc) return rc;
                 b.aud_img = q;       // the old table stays on the handle's allocation list until fmd_destroy
-                uint4* q2 = nullptr;
-                rc = dev_alloc(h, &q2, cap * kBpSlotU16 * 2 / sizeof(uint4));
+                uint4* q4 = nullptr;
+                rc = dev_alloc(h, &q4, cap * kBpTabSlotU16 * 2 / sizeof(uint4));
                 if (rc) return rc;
-                b.bp_img = q2;
+                b.bp_tab = q4;
                 uint4* q3 = nullptr;
                 rc = dev_alloc(h, &q3, cap * kBpEdgeHalves * 2 / sizeof(uint4));
                 if (rc) return rc;
@@ -337,10 +338,10 @@ int upload_controls(fmd_handle h, hipStream_t s) {
             std::vector<uint16_t> imgs(n_slots * kAudImgU16);
             for (const auto& kv : h->img_slot) toeplitz_image(lpf_taps(h, kv.first).data(), 128, 4, 6, imgs.data() + (size_t)kv.second * kAudImgU16);
             HIP_TRY(h, hipMemcpyAsync(b.aud_img, imgs.data(), imgs.size() * 2, hipMemcpyHostToDevice, s));
-            // k_extract_bp: per cut-off the operand images of the L+R FIR and of the L-R composite (mixer + Hilbert FIR folded into the taps)
-            std::vector<uint16_t> bimgs(n_slots * kBpSlotU16);
-            for (const auto& kv : h->img_slot) bp_slot_images(lpf_taps(h, kv.first).data(), h->base.b_hilbert, bimgs.data() + (size_t)kv.second * kBpSlotU16);
-            HIP_TRY(h, hipMemcpyAsync(b.bp_img, bimgs.data(), bimgs.size() * 2, hipMemcpyHostToDevice, s));
+            // k_extract_bp: per cut-off the tap tables of the L+R FIR and of the L-R composite (mixer + Hilbert FIR folded into the taps)
+            std::vector<uint16_t> tabsv(n_slots * kBpTabSlotU16);
+            for (const auto& kv : h->img_slot) bp_slot_tap_tables(lpf_taps(h, kv.first).data(), h->base.b_hilbert, tabsv.data() + (size_t)kv.second * kBpTabSlotU16);
+            HIP_TRY(h, hipMemcpyAsync(b.bp_tab, tabsv.data(), tabsv.size() * 2, hipMemcpyHostToDevice, s));
             std::vector<uint16_t> edges(n_slots * kBpEdgeHalves);
             for (const auto& kv : h->img_slot) bp_edge_matrix(lpf_taps(h, kv.first).data(), h->base.b_hilbert, edges.data() + (size_t)kv.second * kBpEdgeHalves);
             HIP_TRY(h, hipMemcpyAsync(b.bp_edge, edges.data(), edges.size() * 2, hipMemcpyHostToDevice, s));
@@ -1118,11 +1119,11 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
                 if (hipMemcpyAsync(b.rds_img, rimg.data(), rimg.size() * 2, hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
                     hipStreamSynchronize(h->own_stream) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "operand table upload failed");
             }
-            if (!rc) rc = dev_alloc(h, &b.rds_bp_img, kBpRdsU16 * 2 / sizeof(uint4));
+            if (!rc) rc = dev_alloc(h, &b.rds_bp_tab, kBpRdsTabU16 * 2 / sizeof(uint4));
             if (!rc) {
-                std::vector<uint16_t> rtab(kBpRdsU16);
-                bp_rds_images(h->base.b_rds, h->base.b_hilbert, rtab.data());
-                if (hipMemcpyAsync(b.rds_bp_img, rtab.data(), rtab.size() * 2, hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
+                std::vector<uint16_t> rt(kBpRdsTabU16);
+                bp_rds_tap_tables(h->base.b_rds, h->base.b_hilbert, rt.data());
+                if (hipMemcpyAsync(b.rds_bp_tab, rt.data(), rt.size() * 2, hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
                     hipStreamSynchronize(h->own_stream) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "operand table upload failed");
             }
             if (!rc) rc = dev_alloc(h, &b.span_tab, 1);

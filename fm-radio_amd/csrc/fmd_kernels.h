@@ -200,8 +200,8 @@ struct Buffers {
     uint4*  aud_img;                 // ... of k_extract_mfma's audio FIRs, one per distinct cut-off: [slot][k-step][hi/lo][lane]
     int2*   aud_idx;                 // [C] slots of a station's L+R and L-R images
     uint4*  rds_img;                 // ... of the RDS FIR
-    uint4*  bp_img;                  // k_extract_bp: per distinct cut-off the operand images of the L+R FIR and of the L-R composite band-pass FIR's two rails (kBpSlotU4 uint4s a slot)
-    uint4*  rds_bp_img;              // ... of the RDS composite band-pass FIR and of its first-order term
+    uint4*  bp_tab;                  // k_extract_bp: per distinct cut-off the zero-padded tap tables of the L+R FIR and of the L-R composite band-pass FIR's two rails (12 tables a slot, fmd_kernels_bp.inc)
+    uint4*  rds_bp_tab;              // ... of the RDS composite band-pass FIR (4 tables) and of its first-order term (2)
     uint4*  bp_edge;                 // ... per cut-off slot [31 outputs][8 lanes][6] (fp16 pairs): the matrix of the block's first outputs' sums over the previous block's samples
     uint4*  front_mfma;              // FMD_FLAG_FAST_MATH only: Toeplitz operand images of k_front_mfma's two FIRs, [fir][k-step][hi/lo][lane]; m > 1: then k_predecim_mfma's
     unsigned int* pll_chain;         // [wavefronts of k_pilot_pll + 1] last block number each wavefront completed; [last] = watchdog flag

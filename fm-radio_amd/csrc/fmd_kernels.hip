@@ -3172,7 +3172,7 @@ static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
             if (const char* e = dev_env("FMD_BP_NT")) { const int v = atoi(e); if (v > 0 && tiles % v == 0) nt = v; }      // (development A/B)
             if (dev_env("FMD_BP_NOEDGE")) nt |= 0x100;                       // (development, timing only: the first tile's sums over the previous block skipped)
             FMD_LAUNCH(r, true, true, k_extract_bp, dim3((unsigned)(tiles / (nt & 0xff) * d.C)), dim3(TA), 0, s, d, nt, b.fo_pl[r.buf], b.pll_poly[r.buf],
-                       b.bp_img, b.aud_idx, b.rds_bp_img, b.bp_edge, b.mix,
+                       b.bp_tab, b.aud_idx, b.rds_bp_tab, b.bp_edge, b.mix,
                        b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est[r.par], b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps,
                        lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr, lmr_field(r.par), lmr_field(r.par ^ 1), b.rds_pow[r.buf]);
             return;
