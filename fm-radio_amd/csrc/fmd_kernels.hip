@@ -3164,14 +3164,13 @@ static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     if constexpr (FAST && TA == 256) {   // tolerance mode: the FIRs on the matrix cores
         if (!ctx.extract_mix) {          // round 5: the mixers behind the FIRs (fmd_kernels_bp.inc)
             const int tiles = d.n_audio / TA;
-            // tiles per workgroup (its operand images are loaded once): the whole block when that still leaves two rounds of workgroups for
-            // the chip (3 per CU: measured 4096 stations x 8 tiles: 0.119 ms with 8 tiles per workgroup, 0.137 with 4, 0.15 with 1), else the
-            // largest divisor that does
+            // a workgroup = station x 4 nt tiles, nt per wavefront (the station's tap tables are staged once per workgroup): the largest nt that
+            // still leaves 1536 workgroups for the chip (4 per CU: a round and a half)
             int nt = 1;
-            for (int v = tiles; v >= 1; v--) if (tiles % v == 0 && (long)(tiles / v) * d.C >= 1536) { nt = v; break; }
-            if (const char* e = dev_env("FMD_BP_NT")) { const int v = atoi(e); if (v > 0 && tiles % v == 0) nt = v; }      // (development A/B)
+            for (int v = (tiles + 3) / 4; v >= 1; v--) if ((long)((tiles + 4 * v - 1) / (4 * v)) * d.C >= 1536) { nt = v; break; }
+            if (const char* e = dev_env("FMD_BP_NT")) { const int v = atoi(e); if (v > 0 && v <= 255) nt = v; }      // (development A/B)
             if (dev_env("FMD_BP_NOEDGE")) nt |= 0x100;                       // (development, timing only: the first tile's sums over the previous block skipped)
-            FMD_LAUNCH(r, true, true, k_extract_bp, dim3((unsigned)(tiles / (nt & 0xff) * d.C)), dim3(TA), 0, s, d, nt, b.fo_pl[r.buf], b.pll_poly[r.buf],
+            FMD_LAUNCH(r, true, true, k_extract_bp, dim3((unsigned)((tiles + 4 * (nt & 0xff) - 1) / (4 * (nt & 0xff)) * d.C)), dim3(TA), 0, s, d, nt, b.fo_pl[r.buf], b.pll_poly[r.buf],
                        b.bp_tab, b.aud_idx, b.rds_bp_tab, b.bp_edge, b.mix,
                        b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est[r.par], b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps,
                        lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr, lmr_field(r.par), lmr_field(r.par ^ 1), b.rds_pow[r.buf]);
