@@ -89,7 +89,7 @@ def chain_traffic(C: int, fs: int, block: int, u8: bool, fast: bool):
 
 def dominant_kernel(avg_ms: dict, ms_per_step: float, fast: bool):
     """The kernel `roofline` is quoted on: the longest average launch.  Tolerance mode: its two throughput kernels (k_front_mfma,
-    k_extract_mfma) take turns on one queue while the serial stages (k_rds_sync: 64 workgroups; the pilot stage rides in the front end's launch) run
+    k_extract_bp) take turns on one queue while the serial stages (k_rds_sync: 64 workgroups; the pilot stage rides in the front end's launch) run
     beside them on queues of their own with launches that overlap consecutive blocks'; such a side-queue kernel is the dominant one only
     when its launch is what the step waits for (>= 90 % of the step while the throughput kernels' queue has slack: small batches) —
     otherwise the longest throughput kernel is, and `whole_step_frac` (algorithmic bytes over the whole step) is the figure that says how

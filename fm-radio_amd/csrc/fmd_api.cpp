@@ -30,7 +30,7 @@ using namespace fmd;
 enum Stage { ST_FRONT = 0, ST_DEEMPH, ST_POWER, ST_PLL, ST_EXTRACT, ST_RDS, ST_PREDECIM, ST_COUNT };
 static const char* const kStageName[ST_COUNT] = {"k_front", "k_deemphasis+k_hilbert", "k_pilot_power", "k_pilot_pll", "k_extract", "k_rds_sync", "k_predecim"};
 // ... and of the tolerance mode's kernels, as they appear in rocprofv3 kernel traces
-static const char* const kStageNameFast[ST_COUNT] = {"k_front_mfma", "k_deemphasis", "k_pilot_power", "k_pll_sparse", "k_extract_mfma", "k_rds_sync", "k_predecim_mfma"};
+static const char* const kStageNameFast[ST_COUNT] = {"k_front_mfma", "k_deemphasis", "k_pilot_power", "k_pll_sparse", "k_extract_bp", "k_rds_sync", "k_predecim_mfma"};
 
 struct ProfiledBlock { hipEvent_t t0[ST_COUNT], t1[ST_COUNT]; bool used[ST_COUNT]; };
 
@@ -60,7 +60,7 @@ struct fmd_handle_s {
     bool last_block_deemph = false;          // the previous block went through the de-emphasis stage (stream sD)
     bool poisoned = false;                   // a block failed part-way: state is not the state after a whole number of blocks
     bool pipelined = true;
-    // Tolerance mode, fmd_submit_*: k_extract_mfma shares k_front_mfma's stream and a block's extract + RDS stages are queued when the
+    // Tolerance mode, fmd_submit_*: k_extract_bp shares k_front_mfma's stream and a block's extract + RDS stages are queued when the
     // NEXT block is submitted (behind that block's front end) or when somebody asks for the outputs — see process_dev
     bool lazy_extract = false, lazy_capable = false;
     bool no_fused_pll = false;               // development A/B: the deferred pilot stage as a launch of its own
@@ -90,7 +90,7 @@ struct fmd_handle_s {
     int bytes_cap = 0;
     std::string err;
     std::map<int, std::vector<float>> lpf_cache;  // cut-off Hz -> 128 taps
-    std::map<int, int> img_slot;                  // FMD_FLAG_FAST_MATH: cut-off Hz -> slot of its operand image in aud_img (k_extract_mfma)
+    std::map<int, int> img_slot;                  // FMD_FLAG_FAST_MATH: cut-off Hz -> slot of its operand image in aud_img (k_extract_bp)
     size_t img_capacity = 0;                      // slots allocated in aud_img
     unsigned debug_skip = 0;                 // development knob FMD_DEBUG_SKIP_STAGES: bit (1 << Stage) = do not launch that stage (timing experiments only: outputs are garbage)
     int profiling = 0;                       // 0 off, 1 every kernel of every block, 2 k_pilot_pll every block + the rest every 4th
@@ -180,7 +180,6 @@ void toeplitz_image(const float* taps, int n_taps, int stride, int ksteps, uint1
                 img[(((size_t)sK * 2 + 1) * 64 + l) * 8 + i] = lo;
             }
 }
-constexpr size_t kAudImgU16 = (size_t)6 * 2 * 64 * 8, kRdsImgU16 = (size_t)8 * 2 * 64 * 8;
 
 // k_extract_bp (fmd_kernels_bp.inc): the harmonic mixer folded into the decimating FIR.  The reference's L-R / RDS rails are
 //   sum_tau h[tau] a[t0 + tau] e^{j 2 pi H dt[t0 + tau]},  a[t] = x[t - 32] + j sum_n b_hil[n] x[t - 64 + n]   (broadcast_fm_demod.cpp:463-536)
@@ -307,7 +306,7 @@ int upload_controls(fmd_handle h, hipStream_t s) {
     }
     Buffers& b = h->ctx.b;
     if (h->ctx.fast) {
-        // k_extract_mfma: one operand image per distinct audio cut-off, and which two each station uses
+        // k_extract_bp: one set of tap tables per distinct audio cut-off, and which two each station uses
         std::vector<int> idx((size_t)C * 2);
         bool grew = false;
         for (int c = 0; c < C; c++)
@@ -321,24 +320,17 @@ int upload_controls(fmd_handle h, hipStream_t s) {
             const size_t n_slots = h->img_slot.size();
             if (n_slots > h->img_capacity) {   // (everything is idle here: upload_controls runs behind sync_all)
                 const size_t cap = std::max<size_t>(2 * n_slots, 8);
-                uint4* q = nullptr;
-                int rc = dev_alloc(h, &q, cap * kAudImgU16 * 2 / sizeof(uint4));
-                if (rc) return rc;
-                b.aud_img = q;       // the old table stays on the handle's allocation list until fmd_destroy
                 uint4* q4 = nullptr;
-                rc = dev_alloc(h, &q4, cap * kBpTabSlotU16 * 2 / sizeof(uint4));
+                int rc = dev_alloc(h, &q4, cap * kBpTabSlotU16 * 2 / sizeof(uint4));
                 if (rc) return rc;
-                b.bp_tab = q4;
+                b.bp_tab = q4;       // the old table stays on the handle's allocation list until fmd_destroy
                 uint4* q3 = nullptr;
                 rc = dev_alloc(h, &q3, cap * kBpEdgeHalves * 2 / sizeof(uint4));
                 if (rc) return rc;
                 b.bp_edge = q3;
                 h->img_capacity = cap;
             }
-            std::vector<uint16_t> imgs(n_slots * kAudImgU16);
-            for (const auto& kv : h->img_slot) toeplitz_image(lpf_taps(h, kv.first).data(), 128, 4, 6, imgs.data() + (size_t)kv.second * kAudImgU16);
-            HIP_TRY(h, hipMemcpyAsync(b.aud_img, imgs.data(), imgs.size() * 2, hipMemcpyHostToDevice, s));
-            // k_extract_bp: per cut-off the tap tables of the L+R FIR and of the L-R composite (mixer + Hilbert FIR folded into the taps)
+            // per cut-off the tap tables of the L+R FIR and of the L-R composite (mixer + Hilbert FIR folded into the taps)
             std::vector<uint16_t> tabsv(n_slots * kBpTabSlotU16);
             for (const auto& kv : h->img_slot) bp_slot_tap_tables(lpf_taps(h, kv.first).data(), h->base.b_hilbert, tabsv.data() + (size_t)kv.second * kBpTabSlotU16);
             HIP_TRY(h, hipMemcpyAsync(b.bp_tab, tabsv.data(), tabsv.size() * 2, hipMemcpyHostToDevice, s));
@@ -601,7 +593,7 @@ int zero_history(fmd_handle h, hipStream_t s) {
 }
 
 // The extract + RDS stages of the block whose launch fmd_submit_* put off (tolerance mode).
-// behind_front (the next block has just been submitted): k_extract_mfma goes on the FRONT END's stream.  The two throughput kernels
+// behind_front (the next block has just been submitted): k_extract_bp goes on the FRONT END's stream.  The two throughput kernels
 // gain nothing from running side by side — together they took longer than one after the other (tools/r3_timeline.sh: 0.37 ms a block for
 // the pair against 0.14 + 0.17 ms alone; they share a CU's LDS and wave slots, and every hop between queues costs ~50 us) — so they take
 // turns on one queue, in the order front(k + 1), extract(k), front(k + 2), ...; by the time extract(k) is reached, the pilot loop of
@@ -767,7 +759,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     hipStream_t sP = (pipe && h->ctx.d.m > 1 && !chained) ? h->own_stream : sF;
     // Deferred schedule at 1.024 / 2.048 MSa/s: the front end (with the previous block's pilot stage riding it) follows the first
     // decimator on that queue, and the extract stages have the front end's queue to themselves: two queues that each run ahead,
-    // instead of one on which k_extract_mfma and the front end take turns while the decimator works beside both.
+    // instead of one on which k_extract_bp and the front end take turns while the decimator works beside both.
     hipStream_t sFq = (lazy && h->ctx.d.m > 1 && sP != sF && h->ctx.fast && h->front_with_predecim) ? sP : sF;
     hipStream_t s_first = predecim ? sP : sFq;     // the stream of the stage that reads the caller's input
     if (pipe) {
@@ -1052,7 +1044,6 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     h->no_fused_pll = dev_env("FMD_NO_FUSED_PLL") != nullptr;
     h->pll_eager = dev_env("FMD_PLL_EAGER") != nullptr;
     if (dev_env("FMD_FRONT_OWN_QUEUE")) h->front_with_predecim = false;
-    h->ctx.extract_mix = dev_env("FMD_EXTRACT_MIX") != nullptr;    // development A/B: round 4's k_extract_mfma (mixers at 128 kHz) instead of k_extract_bp
 
     fmd_controls def;
     fmd_default_controls(&def);
@@ -1112,13 +1103,6 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
             if (!rc && (hipMemcpyAsync(b.front_mfma, img.data(), img.size() * 2, hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
                         hipStreamSynchronize(h->own_stream) != hipSuccess)) rc = fail(h, FMD_ERR_DEVICE, "operand table upload failed");
             if (!rc) rc = dev_alloc(h, &b.aud_idx, C);
-            if (!rc) rc = dev_alloc(h, &b.rds_img, kRdsImgU16 * 2 / sizeof(uint4));
-            if (!rc) {
-                std::vector<uint16_t> rimg(kRdsImgU16);
-                toeplitz_image(h->base.b_rds, 128, 8, 8, rimg.data());
-                if (hipMemcpyAsync(b.rds_img, rimg.data(), rimg.size() * 2, hipMemcpyHostToDevice, h->own_stream) != hipSuccess ||
-                    hipStreamSynchronize(h->own_stream) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "operand table upload failed");
-            }
             if (!rc) rc = dev_alloc(h, &b.rds_bp_tab, kBpRdsTabU16 * 2 / sizeof(uint4));
             if (!rc) {
                 std::vector<uint16_t> rt(kBpRdsTabU16);
@@ -1638,7 +1622,7 @@ int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out) {
             HIP_TRY(h, hipEventElapsedTime(&ms, pm->t0[i], pm->t1[i]));
             int slot = -1;
             const char* nm = h->ctx.fast ? kStageNameFast[i] : kStageName[i];
-            if (h->ctx.fast && i == ST_EXTRACT && !h->ctx.extract_mix && h->ctx.d.n_audio % 256 == 0) nm = "k_extract_bp";      // (round 5: fmd_kernels_bp.inc)
+            if (h->ctx.fast && i == ST_EXTRACT && h->ctx.d.n_audio % 256 == 0) nm = "k_extract_bp";      // (round 5: fmd_kernels_bp.inc)
             if (i == ST_FRONT && front_takes_capture(h->ctx)) nm = "k_front_pre_mfma";
             for (int j = 0; j < n; j++) if (std::strncmp(out[j].name, nm, sizeof(out[j].name)) == 0) { slot = j; break; }
             if (slot < 0) {

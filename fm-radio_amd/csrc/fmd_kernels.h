@@ -131,7 +131,7 @@ struct PllSparseTab {
 // rows of the fast-mode planes carry the previous block's last samples in front (written by k_pll_span of that block), so the
 // consumers address history and block uniformly
 static constexpr int kFrontImgU4 = 2 * 3 * 2 * 64;   // uint4s of k_front_mfma's two operand images in Buffers::front_mfma; k_predecim_mfma's image follows them
-static constexpr int kFoPad = 192;   // fm_out: k_extract_mfma reaches back 124 + 64 samples (its Hilbert FIR), k_pll_span 33 (65 while a station warms up)
+static constexpr int kFoPad = 192;   // fm_out: k_extract_bp reaches back 124 + 64 samples (its Hilbert FIR), k_pll_span 33 (65 while a station warms up)
 
 struct Dims {
     int C;          // channels
@@ -191,15 +191,13 @@ struct Buffers {
     // FMD_FLAG_FAST_MATH (round 3): planar analytic signal and the PLL's span polynomials
     float*  fo_pl[kSlots];           // [C][kFoPad + n_fm_out]  fm_out (the analytic signal's real rail is this delayed by 32)
     float4* pll_poly[kSlots];        // [C][1 + n_fm_out / kSpan]  NCO phase of a span: c0 + c1 u + c2 u^2 + c3 u^3 - frac(19 (u + 1) / 128), u = sample in span
-    float*  rds_pow[kSlots];         // [C][2 n_audio / 256]  partial sums of |rds|^2 (k_extract_mfma -> k_rds_sync's AGC)
+    float*  rds_pow[kSlots];         // [C][2 n_audio / 256]  partial sums of |rds|^2 (k_extract_bp -> k_rds_sync's AGC)
     PllSpanTab* span_tab;
     PllSparseTab* sparse_tab;
     float4* pv_pl[kSlots];           // [C][n_fm_out / 16] per 16-sample column of fm_out: (new.re, new.im, old.re, old.im), the two half sums of the pilot points' inputs
     float4* pv_hist[2];              // [C][4] the previous block's last four columns, by block parity (k_pll_sparse reads [par], writes [par ^ 1])
     PilotFastTab* pilot_tab;         // FMD_FLAG_FAST_MATH only
-    uint4*  aud_img;                 // ... of k_extract_mfma's audio FIRs, one per distinct cut-off: [slot][k-step][hi/lo][lane]
     int2*   aud_idx;                 // [C] slots of a station's L+R and L-R images
-    uint4*  rds_img;                 // ... of the RDS FIR
     uint4*  bp_tab;                  // k_extract_bp: per distinct cut-off the zero-padded tap tables of the L+R FIR and of the L-R composite band-pass FIR's two rails (12 tables a slot, fmd_kernels_bp.inc)
     uint4*  rds_bp_tab;              // ... of the RDS composite band-pass FIR (4 tables) and of its first-order term (2)
     uint4*  bp_edge;                 // ... per cut-off slot [31 outputs][8 lanes][6] (fp16 pairs): the matrix of the block's first outputs' sums over the previous block's samples
@@ -222,7 +220,6 @@ struct LaunchCtx {
     int fast;                             // FMD_FLAG_FAST_MATH: the tolerance-mode kernels
     int any_deemph;
     int deemph_in_tile;     // FMD_FLAG_FAST_MATH: the de-emphasis IIR runs inside k_front's tile (every filtering channel's pole <= 0.905, i.e. up to ~79 us)
-    int extract_mix;        // development A/B (FMD_EXTRACT_MIX): k_extract_mfma, the extract stage with the mixers at 128 kHz (round 4), instead of k_extract_bp
     int split_front;        // fmd_debug_split_front: 1.024 / 2.048 MSa/s tolerance mode with k_predecim_mfma and k_front_mfma as two kernels (the parity check of k_front_pre_mfma)
     int bytes_cap;
     int pll_time_parallel_max_channels;   // batches up to this size use the time-parallel PLL kernel, larger ones the low-work one

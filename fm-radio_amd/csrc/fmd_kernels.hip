@@ -22,7 +22,7 @@
 //   k_pll_sparse   [serial]    a6 peak filter as a decimated one-pole, a7 AGC state, a8 the loop at eight points per 128-sample span
 //                              (fmd_kernels_sparse.inc; the first workgroups of the next block's front-end launch on the deferred
 //                              schedule; k_pll_span of fmd_kernels_fast.inc for a station's first 8192 samples)  -> one cubic per span
-//   k_extract_mfma [parallel]  a5 Hilbert FIR, a9 mixers, a10 / a12 decimating FIRs (matrix cores), a11, a15, the RDS AGC's
+//   k_extract_bp   [parallel]  a5 Hilbert FIR and a9 mixers folded into the a10 / a12 decimating FIRs (matrix cores), a11, a15, the RDS AGC's
 //                              block power as per-tile partial sums                            -> audio, rds, lmr_est, rds_pow
 //   k_rds_sync3    [serial]    a13, a14, Manchester decode: the loop pipelined over five wavefronts (fmd_kernels_fast.inc)
 //
@@ -99,7 +99,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static constexpr f32x4 kZero4 = {0.f, 0.f, 0.f, 0.f};
 template <int TT, int WU>
 struct FrontGeomM {
-    static constexpr int T = TT, NF = T + WU, NW = 2 * NF + 63, TAIL = 63 + 2 * WU;   // (no Hilbert history: k_extract_mfma takes that FIR)
+    static constexpr int T = TT, NF = T + WU, NW = 2 * NF + 63, TAIL = 63 + 2 * WU;   // (no Hilbert history: k_extract_bp takes that FIR)
     static constexpr int NWB = (NW + 8 + 7) & ~7;        // bf16 elements per half (hi / lo) of the discriminator output, zero padded
     static constexpr int OFF_THETA = 0;                  // [NW] floats; then, in place: dem_hi [NWB] bf16, dem_lo [NWB] bf16
     static constexpr int OFF_FO = NWB;                   // WU > 0: fm_out fp32 [NF], and the segment end states of the de-emphasis IIR
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ i
 // =============================================================================================
 // k_front_mfma — FMD_FLAG_FAST_MATH form of k_front up to fm_out: the minimax arctangent (in turns), the decimating FIR as a
 // bf16 x 3 matrix product (FrontGeomM above); WU > 0: with the de-emphasis IIR inside the tile (see k_front).  The Hilbert FIR is
-// k_extract_mfma's: the analytic signal never goes through HBM, only fm_out does (4 bytes per sample instead of 8).
+// k_extract_bp's: the analytic signal never goes through HBM, only fm_out does (4 bytes per sample instead of 8).
 // =============================================================================================
 // The operands a front-end workgroup loads once: the Toeplitz images of the decimating FIR, and this lane's element of the operand that
 // makes the pilot stage's four column sums from a tile of outputs (below): rows 0-3 = new.re, new.im, old.re, old.im weights (PllSparseTab)
@@ -374,7 +374,7 @@ __device__ __forceinline__ void front_from_phases(const Dims& d, float* smem, co
     F_STAMP(4);
     // a3: decimate-by-2 FIR: wavefront w takes the 16-column tiles w, w + 4, ... (a column = 16 consecutive outputs).
     // fm_out goes to its plane undelayed (the rows start with the previous block's tail, k_pll_sparse); the consumers delay it by 32
-    // for the real rail and k_extract_mfma makes the Hilbert rail from it.
+    // for the real rail and k_extract_bp's composite FIRs contain the Hilbert rail.
     float* fo_row = fo_pl + (size_t)c * (kFoPad + d.n_fm_out) + kFoPad + o0;
     for (int ct = wv; ct * 16 < G::NCOL; ct += 4) {
         const int col = ct * 16 + lrow, colr = col < G::NCOL ? col : G::NCOL - 1;
@@ -1842,7 +1842,7 @@ __device__ __forceinline__ float lmr_phase_finish(float sum, int n_est, float cu
 }
 // sum over the 64 lanes of a wavefront, the same value in every lane
 // (the xor butterfly 32, 16, 8, 4, 2, 1 of six __shfl_xor steps — same partner in every step, so the same sum bit for bit — without their
-//  six LDS round trips (ds_bpermute: ~130 cycles each on a lone dependent chain, tools/dbg/x_probe.py): lane-swap and DPP moves)
+//  six LDS round trips (ds_bpermute: ~130 cycles each on a lone dependent chain): lane-swap and DPP moves)
 __device__ __forceinline__ float wave_sum_f32(float v) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);       // halves of the wavefront change places
     v = __uint_as_float(r[0]) + __uint_as_float(r[1]);                                                      // v[i] + v[i ^ 32]
@@ -2038,341 +2038,15 @@ __global__ __launch_bounds__(TA) void k_extract(Dims d, const float2* __restrict
     }
 }
 
-// =============================================================================================
-// k_extract_mfma — FMD_FLAG_FAST_MATH form of k_extract<256>: the same tile, mixing and epilogue; the three decimating FIRs as
-// bf16 x 3 banded-Toeplitz products (see FrontGeomM):
-//   L+R, L-R (decimate by 4, 128 taps, taps per station):  Y[m][c] = y[16 c + m] = sum_t A[m][t] x[64 c + t],   A[m][t] = h[t - 4 m]   (t < 188: 6 K-steps)
-//   RDS (decimate by 8, 128 taps), both rails in one 16-column tile:   sum_t A[m][t] x[128 c + t],             A[m][t] = h[t - 8 m]   (t < 248: 8 K-steps)
-// The operand images of A are made on the host, one per distinct cut-off (aud_img, 12 KB each; aud_idx says which two a station
-// uses) and one for the RDS taps.  Signals are staged as bf16 hi / lo halves in natural order, 8 elements of padding after every
-// 32 (a lane's 16-byte operand read never crosses a group; column strides of 80 / 160 elements spread the lanes over the banks).
-// Wavefront 0: L+R, 1: L-R, 2: RDS, 3: the real rail of every 10th L-R output for the phase estimate (VALU, as before).
-// =============================================================================================
-struct ExtractGeomM {
-    static constexpr int TA = 256, XS = 4 * TA + 124, XSP = 1152;         // staged analytic samples, padded with zeros to the operands' reach
-    static constexpr int NB = XSP + 8 * (XSP >> 5);                       // bf16 elements per half-array with the padding
-    static constexpr int NEST = TA / 10 + 2;
-    // fm_out window W[i] = fm_out[s_lo - 64 + i]: the Hilbert FIR's reach in front of the first staged sample, zero padded to the
-    // reach of the dummy columns of its fifth tile (16 * 79 + 64 + 24 + 8)
-    static constexpr int WN = XS + 64, WNP = 1376, NBWW = (WNP + 8 * (WNP >> 5)) / 2;   // words per bf16 half-array of W
-    __device__ static __forceinline__ int pad(int i) { return i + 8 * (i >> 5); }
-    static_assert(WNP % 32 == 0 && WNP >= 16 * 79 + 64 + 24 + 8, "reach of the Hilbert operand");
-};
-
 #ifdef FMD_X_PROBE
-// development probe (tools/dbg/x_probe.py): cycles between the barriers of k_extract_mfma, summed over sampled workgroups (wavefronts 0 and 3), and their count
+// development probe (tools/dbg/bp_probe.py): cycles of k_extract_bp's phases, summed over sampled workgroups (wavefronts 0 and 3), and their count
 __device__ unsigned long long g_x_probe[16];
 __device__ unsigned long long g_x_probe2[16];
-#define X_STAMP2(i_) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (xp_on && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 3)) \
-    atomicAdd(&g_x_probe2[(i_) + ((threadIdx.x >> 6) ? 8 : 0)], t_ - xp_t2); xp_t2 = t_; } while (0)
 #define X_STAMP(i_) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (xp_on && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 3)) \
     atomicAdd(&g_x_probe[(i_) + ((threadIdx.x >> 6) ? 8 : 0)], t_ - xp_t); xp_t = t_; } while (0)
 #else
 #define X_STAMP(i_)
 #endif
-__global__ __launch_bounds__(256) void k_extract_mfma(Dims d, const float* __restrict__ fo_pl, const uint4* __restrict__ hil_img,
-                                                      const float4* __restrict__ pll_poly,
-                                                      const uint4* __restrict__ aud_img, const int2* __restrict__ aud_idx, const uint4* __restrict__ rds_img,
-                                                      const float* __restrict__ b_lmr, const float* __restrict__ mixctl, float* __restrict__ state,
-                                                      float* __restrict__ audio, float2* __restrict__ rds, float* __restrict__ lmr_est,
-                                                      float* __restrict__ lpr_out, float* __restrict__ lmr_out, int keep_taps,
-                                                      const float* __restrict__ lmr_est_prev, int field_cur, int field_prev, float* __restrict__ rds_pow) {
-    using G = ExtractGeomM;
-    constexpr int TA = G::TA, XS = G::XS, XSP = G::XSP, NBW = G::NB / 2;
-    // 31.9 KB: five workgroups per CU (at four the kernel alone takes 13 % longer: tools/r3_ab_alone.sh)
-    __shared__ __attribute__((aligned(16))) uint32_t fow_h[G::NBWW], fow_l[G::NBWW];                   // fm_out window: Hilbert operand, and (32 on) the L+R FIR's
-    __shared__ __attribute__((aligned(16))) float im_f[XSP];                                           // Hilbert rail; the mixers leave the x2-mixed signal's real rail in its place
-    __shared__ __attribute__((aligned(16))) uint32_t lmr_h[NBW], lmr_l[NBW];                           // imaginary rail of the x2-mixed signal
-    __shared__ __attribute__((aligned(16))) uint32_t rre_h[NBW], rre_l[NBW], rim_h[NBW], rim_l[NBW];   // x3-mixed signal
-    __shared__ __attribute__((aligned(16))) float res_lpr[TA];
-    __shared__ __attribute__((aligned(16))) float res_lmr[TA];
-    __shared__ __attribute__((aligned(16))) float res_rds[TA];        // [TA/2][2]
-    __shared__ float res_est_re[G::NEST];
-    __shared__ float off_s;
-    float* lmr_re = im_f;                        // (phase estimate's FIR input)
-
-    const int tiles = d.n_audio / TA;
-    const int c = blockIdx.x / tiles, tile = blockIdx.x % tiles;
-    const int i0 = tile * TA, tid = threadIdx.x;
-    __builtin_assume(tid >= 0 && tid < 256);     // (the bounds of the unrolled staging loops are tested against it)
-    const int lane = tid & (kWave - 1), wv = tid >> 6, lrow = lane & 15, lq = lane >> 4;
-    const int s_lo = 4 * i0 - 124;               // first analytic sample staged (block relative), even
-    const int n = d.n_fm_out;
-#ifdef FMD_X_PROBE
-    const bool xp_on = (blockIdx.x % 61) == 0;
-    unsigned long long xp_t = __builtin_readcyclecounter(), xp_t2 = xp_t;
-    const unsigned long long xp_c0 = xp_t, xp_w0 = wall_clock64();
-    if (xp_on && threadIdx.x == 0) atomicAdd(&g_x_probe[7], 1ull);
-#endif
-    // the plane's rows carry the previous block's tail in front (k_pll_span): history and block are addressed alike.
-    // Analytic signal: re[s] = fm_out[s - 32], im[s] = sum_k b[k] fm_out[s - 64 + k] (reference hilbert FIR, broadcast_fm_demod.cpp:261-275
-    // as k_front makes it in exact mode); NCO phase: the span's cubic (PllSpanTab)
-    const float* fo_c = fo_pl + (size_t)c * (kFoPad + n) + kFoPad;
-    const float4* po_c = pll_poly + (size_t)c * (1 + n / kSpan) + 1;
-    const float off_prev = st(state, field_prev, d.C, c);
-    float off_cur = lmr_est_prev ? 0.0f : st(state, field_cur, d.C, c);
-
-    constexpr int NPAIR = (XSP + 4) / 2 + 0;           // pairs e = 0, 2, ... up to the zero padding of the RDS arrays (e - 4 < XSP)
-    constexpr int PERP = (NPAIR + 255) / 256;
-    float4 pv[PERP];
-    float ev[kLmrInlineMax / kWave];
-    // all loads first: the fm_out window, the spans' cubics, last block's phase estimates.  A thread loads the window pairs 32 samples
-    // behind its analytic pairs — the real-rail samples it mixes later stay in its registers in fp32 — and 16 threads the window's first 32.
-    // LDS word indices of the thread's pairs e = 2 (tid + 256 r): pad(e) / 2 = w4b + 320 r (512 samples = 16 padded groups of 40 elements),
-    // the RDS arrays' pad(e - 4) / 2 = w8b + 320 r (floor shifts: also right where 2 tid - 4 < 0 and r > 0)
-    const int w4b = G::pad(2 * tid) >> 1, w8b = ((2 * tid - 4) + 8 * ((2 * tid - 4) >> 5)) >> 1;
-    float2 wv2[PERP], wh2;
-    bf16x8 ahh[3], ahl[3];      // the Hilbert FIR's operand image: asked for with the other early loads (behind the first barrier its trip to L2 took
-                                // 1000 of the 1700 cycles a tile of that FIR cost, tools/dbg/x_probe.py)
-    {
-        // last block's phase estimates FIRST: loads return in order, and these (from HBM: nothing has touched them for a block) were what the
-        // wavefront that integrates them still waited for 3500 cycles later when they were the last ones issued
-        if (lmr_est_prev && wv == 3) {
-#pragma unroll
-            for (int k = 0; k < kLmrInlineMax / kWave; k++)
-                ev[k] = (lane + kWave * k < d.n_est) ? lmr_est_prev[(size_t)c * d.n_est + lane + kWave * k] : 0.0f;
-        }
-#pragma unroll
-        for (int r = 0; r < PERP; r++) {
-            const int e = 2 * (tid + 256 * r);
-            if (e + 32 < G::WN) wv2[r] = *reinterpret_cast<const float2*>(fo_c + (s_lo - 32 + e));
-        }
-#pragma unroll
-        for (int sK = 0; sK < 3; sK++) {
-            ahh[sK] = __builtin_bit_cast(bf16x8, hil_img[(sK * 2 + 0) * kWave + lane]);
-            ahl[sK] = __builtin_bit_cast(bf16x8, hil_img[(sK * 2 + 1) * kWave + lane]);
-        }
-        // (the odd jobs of the staging and of the next phase are spread over the wavefronts: with all of them on wavefront 0 the other
-        //  three waited ~1000 cycles at each of the first two barriers, tools/dbg/x_probe.py)
-        if (wv == 1 && lane < 16) wh2 = *reinterpret_cast<const float2*>(fo_c + (s_lo - 64 + 2 * lane));
-#pragma unroll
-        for (int r = 0; r < PERP; r++) {
-            const int e = 2 * (tid + 256 * r);
-            if (e < XS) pv[r] = po_c[(s_lo + e) >> 7];          // (span -1: the previous block's last)
-        }
-        uint32_t h0, l0, h1, l1;
-#pragma unroll
-        for (int r = 0; r < PERP; r++) {
-            const int e = 2 * (tid + 256 * r);
-            if (e + 32 < G::WN) {
-                split_bf16(wv2[r].x, h0, l0); split_bf16(wv2[r].y, h1, l1);
-                const int w = w4b + 20 + 320 * r;           // pad(e + 32) / 2
-                fow_h[w] = pack_hi16(h0, h1); fow_l[w] = pack_hi16(l0, l1);
-            }
-        }
-        if (wv == 1 && lane < 16) { split_bf16(wh2.x, h0, l0); split_bf16(wh2.y, h1, l1); fow_h[lane] = pack_hi16(h0, h1); fow_l[lane] = pack_hi16(l0, l1); }
-        // zeros behind the window, up to the reach of the Toeplitz operands
-        static_assert((G::WNP - G::WN) / 2 <= 128, "two wavefronts fill the zeros");
-        if (wv >= 2 && tid - 128 < (G::WNP - G::WN) / 2) { const int w = G::pad(G::WN + 2 * (tid - 128)) >> 1; fow_h[w] = 0u; fow_l[w] = 0u; }
-    }
-    X_STAMP(0);
-    __syncthreads();
-    X_STAMP(1);
-#ifdef FMD_X_PROBE
-    xp_t2 = __builtin_readcyclecounter();
-#endif
-    // the Hilbert FIR (FrontGeomM's form: Y[m][col] = im[16 col + m] = sum_t A[m][t] W[16 col + t], t < 80): 72 columns, five 16-column tiles
-    {
-        for (int it = 0; it < (wv == 2 ? 2 : 1); it++) {           // wavefront 2 takes the fifth (half) tile: 1 and 3 have jobs of their own around this phase
-            const int ct = wv + 2 * it, col = ct * 16 + lrow;
-            f32x4 acc, acc1, acc2;
-#pragma unroll
-            for (int sK = 0; sK < 3; sK++) {
-                const int e = 16 * col + 32 * sK + 8 * lq, w = G::pad(e) >> 1;
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fow_h + w));
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fow_l + w));
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahh[sK], bh, sK ? acc : kZero4, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahl[sK], bh, sK ? acc1 : kZero4, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahh[sK], bl, sK ? acc2 : kZero4, 0, 0, 0);
-            }
-            acc = acc + (acc1 + acc2);
-            if (col < XSP / 16) *reinterpret_cast<float4*>(im_f + 16 * col + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        }
-    }
-#ifdef FMD_X_PROBE
-    X_STAMP2(0);
-#endif
-    // NCO phases of the pairs: c0 + c1 u + c2 u^2 + c3 u^3 - frac(19 (u + 1) / 128), u = sample within its span (both samples of a pair share one)
-    float2 dv[PERP];
-#pragma unroll
-    for (int r = 0; r < PERP; r++) {
-        const int u0 = (s_lo + 2 * (tid + 256 * r)) & (kSpan - 1);
-        const float ua = (float)u0, ub = (float)(u0 + 1);
-        const float fa_ = __builtin_amdgcn_fractf(ub * (19.0f / 128.0f)), fb_ = __builtin_amdgcn_fractf((ub + 1.0f) * (19.0f / 128.0f));   // exact: multiples of 1/128 below 20
-        dv[r] = make_float2(fmaf(fmaf(fmaf(pv[r].w, ua, pv[r].z), ua, pv[r].y), ua, pv[r].x) - fa_,
-                            fmaf(fmaf(fmaf(pv[r].w, ub, pv[r].z), ub, pv[r].y), ub, pv[r].x) - fb_);
-    }
-#ifdef FMD_X_PROBE
-    X_STAMP2(1);
-#endif
-    if (lmr_est_prev && wv == 3) {
-        float part = 0.0f;
-#pragma unroll
-        for (int k = 0; k < kLmrInlineMax / kWave; k++) part += ev[k];
-        float nxt = fmaf(wave_sum_f32(part) * __builtin_amdgcn_rcpf((float)d.n_est), 0.1f, off_prev);
-        const float two_pi = bits_f32(kTwoPiBits);
-        nxt = (nxt >= two_pi) ? nxt - two_pi : ((nxt <= -two_pi) ? nxt + two_pi : nxt);
-        if (lane == 0) { off_s = nxt; if (tile == 0) st(state, field_cur, d.C, c) = nxt; }
-    }
-#ifdef FMD_X_PROBE
-    X_STAMP2(2);
-#endif
-    X_STAMP(2);
-    __syncthreads();
-    X_STAMP(3);
-    if (lmr_est_prev) off_cur = off_s;
-    // the zero padding behind the staged samples, up to the reach of the Toeplitz operands
-    if (tid < (XSP + 4 - XS) / 2) {
-        const int e = XS + 2 * tid;
-        if (e < XSP) { const int w4 = G::pad(e) >> 1; lmr_h[w4] = 0u; lmr_l[w4] = 0u; *reinterpret_cast<float2*>(lmr_re + e) = make_float2(0.f, 0.f); }
-        const int w8 = G::pad(e - 4) >> 1; rre_h[w8] = 0u; rre_l[w8] = 0u; rim_h[w8] = 0u; rim_l[w8] = 0u;
-    }
-    // mix, two consecutive samples per thread and step
-    {
-        const float co_cur = fast_cos_turns(off_cur), so_cur = fast_sin_turns(off_cur);
-        const float co_prev = fast_cos_turns(off_prev), so_prev = fast_sin_turns(off_prev);
-#pragma unroll
-        for (int r = 0; r < PERP; r++) {
-            const int e = 2 * (tid + 256 * r);
-            if (e < XS) {
-                const bool hist = s_lo + e < 0;                      // history samples were mixed with last block's offset
-                const float co = hist ? co_prev : co_cur, so = hist ? so_prev : so_cur;
-                const float2 re2 = wv2[r], im2 = *reinterpret_cast<const float2*>(im_f + e);
-                float m2r[2], m2i[2], m3r[2], m3i[2];
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const float xr = u ? re2.y : re2.x, xi = u ? im2.y : im2.x, t = u ? dv[r].y : dv[r].x;
-                    const float c1 = fast_cos_turns(t), s1 = fast_sin_turns(t);
-                    // x e^{j 2 t} once; the 38 kHz rail turns it by the L-R offset, the 57 kHz rail by e^{j t} once more (16 operations a
-                    // sample instead of the 20 of forming e^{j(2 t + off)} and e^{j 3 t} first)
-                    const float c2 = fmaf(c1, c1, -(s1 * s1)), s2 = (c1 + c1) * s1;
-                    const float yr = fmaf(c2, xr, -(xi * s2)), yi = fmaf(c2, xi, xr * s2);
-                    m2r[u] = fmaf(co, yr, -(yi * so)); m2i[u] = fmaf(co, yi, yr * so);
-                    m3r[u] = fmaf(c1, yr, -(yi * s1)); m3i[u] = fmaf(c1, yi, yr * s1);
-                }
-                uint32_t h0, l0, h1, l1;
-                if (e < XSP) {
-                    const int w4 = w4b + 320 * r;
-                    split_bf16(m2i[0], h0, l0); split_bf16(m2i[1], h1, l1); lmr_h[w4] = pack_hi16(h0, h1); lmr_l[w4] = pack_hi16(l0, l1);
-                    *reinterpret_cast<float2*>(lmr_re + e) = make_float2(m2r[0], m2r[1]);
-                }
-                if (e >= 4) {
-                    const int w8 = w8b + 320 * r;
-                    split_bf16(m3r[0], h0, l0); split_bf16(m3r[1], h1, l1); rre_h[w8] = pack_hi16(h0, h1); rre_l[w8] = pack_hi16(l0, l1);
-                    split_bf16(m3i[0], h0, l0); split_bf16(m3i[1], h1, l1); rim_h[w8] = pack_hi16(h0, h1); rim_l[w8] = pack_hi16(l0, l1);
-                }
-            }
-        }
-    }
-    X_STAMP(4);
-    __syncthreads();
-    X_STAMP(5);
-#ifdef FMD_X_PROBE
-    xp_t2 = __builtin_readcyclecounter();
-#endif
-
-    const float* taps_lmr = b_lmr + (size_t)c * 128;
-    const int est_first = (10 - (i0 % 10)) % 10;   // first output of this tile whose block index is a multiple of 10
-    if (wv < 2) {
-        // L+R / L-R: one 16 x 16 tile = the 256 outputs of the workgroup
-        const int2 slot = aud_idx[c];
-        const uint4* img = aud_img + (size_t)(wv ? slot.y : slot.x) * (6 * 2 * kWave);
-#ifdef FMD_X_PROBE
-        asm volatile("" :: "s"(slot.x), "s"(slot.y));
-        X_STAMP2(3);
-#endif
-        // (L+R is the real rail itself: the fm_out window 32 samples on, i.e. one padded group of 40 elements)
-        const uint32_t* sh = wv ? lmr_h : fow_h + 20;
-        const uint32_t* sl = wv ? lmr_l : fow_l + 20;
-        f32x4 acc, acc1, acc2;   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
-#pragma unroll
-        for (int sK = 0; sK < 6; sK++) {
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, img[(sK * 2 + 0) * kWave + lane]);
-            const bf16x8 al = __builtin_bit_cast(bf16x8, img[(sK * 2 + 1) * kWave + lane]);
-            const int e = 64 * lrow + 32 * sK + 8 * lq, w4 = (e + 8 * (2 * lrow + sK)) >> 1;
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sh + w4));
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sl + w4));
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, sK ? acc : kZero4, 0, 0, 0);      // (the first step starts from the constant 0: no registers to clear)
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, sK ? acc1 : kZero4, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, sK ? acc2 : kZero4, 0, 0, 0);
-#ifdef FMD_X_PROBE
-            if (sK == 0) { asm volatile("" :: "v"(acc[0])); X_STAMP2(4); }
-#endif
-        }
-        acc = acc + (acc1 + acc2);
-        *reinterpret_cast<float4*>((wv ? res_lmr : res_lpr) + 16 * lrow + 4 * lq) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-#ifdef FMD_X_PROBE
-        X_STAMP2(5);
-#endif
-    } else if (wv == 2) {
-        // RDS: columns 0-7 the real rail's 128 outputs, 8-15 the imaginary rail's
-        const int rail = lrow >> 3, colr = lrow & 7;
-        const uint32_t* sh = rail ? rim_h : rre_h;
-        const uint32_t* sl = rail ? rim_l : rre_l;
-        f32x4 acc, acc1, acc2;   // three chains (hi hi, lo hi, hi lo) instead of one three times as long
-#pragma unroll
-        for (int sK = 0; sK < 8; sK++) {
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, rds_img[(sK * 2 + 0) * kWave + lane]);
-            const bf16x8 al = __builtin_bit_cast(bf16x8, rds_img[(sK * 2 + 1) * kWave + lane]);
-            const int e = 128 * colr + 32 * sK + 8 * lq, w8 = (e + 8 * (4 * colr + sK)) >> 1;
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sh + w8));
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sl + w8));
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, sK ? acc : kZero4, 0, 0, 0);      // (the first step starts from the constant 0: no registers to clear)
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, sK ? acc1 : kZero4, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, sK ? acc2 : kZero4, 0, 0, 0);
-        }
-        acc = acc + (acc1 + acc2);
-#pragma unroll
-        for (int i = 0; i < 4; i++) res_rds[2 * (16 * colr + 4 * lq + i) + rail] = acc[i];
-    } else {
-        // real rail of the L-R outputs that feed the phase estimate (one output per thread)
-        const int u = lane, ii = est_first + 10 * u;
-        if (ii < TA) {
-            float a[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-            for (int jj = 0; jj < 32; jj++) {
-                const float4 x4 = *reinterpret_cast<const float4*>(lmr_re + 4 * (ii + jj));
-                a[0] = fmaf(x4.x, taps_lmr[4 * jj + 0], a[0]); a[1] = fmaf(x4.y, taps_lmr[4 * jj + 1], a[1]);
-                a[2] = fmaf(x4.z, taps_lmr[4 * jj + 2], a[2]); a[3] = fmaf(x4.w, taps_lmr[4 * jj + 3], a[3]);
-            }
-            res_est_re[u] = (a[0] + a[2]) + (a[1] + a[3]);
-        }
-    }
-    X_STAMP(6);
-    __syncthreads();
-
-    {
-        const int i = i0 + tid;
-        const float lpr = res_lpr[tid], lmr = res_lmr[tid];
-        const int mode = (int)mixctl[2 * c];
-        const float kmix = mixctl[2 * c + 1];
-        float l, r;
-        if (mode == FMD_AUDIO_STEREO) { l = fmaf(lmr, kmix, lpr); r = fmaf(-lmr, kmix, lpr); }
-        else if (mode == FMD_AUDIO_LMR) { l = lmr; r = lmr; }
-        else { l = lpr; r = lpr; }
-        reinterpret_cast<float2*>(audio)[(size_t)c * d.n_audio + i] = make_float2(l + l, r + r);
-        if (keep_taps) { lpr_out[(size_t)c * d.n_audio + i] = lpr; lmr_out[(size_t)c * d.n_audio + i] = lmr; }
-        if (tid < TA / 2) {
-            const float rr = res_rds[2 * tid], ri = res_rds[2 * tid + 1];
-            rds[(size_t)c * d.n_rds + i0 / 2 + tid] = make_float2(rr, ri);
-            // a13: the RDS AGC's block power (reference AGC_Filter::calculate_average_power, agc.h:21-30), summed here per half tile
-            // instead of in a pass of its own over the block in k_rds_sync (the lone wavefront's latency there sets small batches' step)
-            const float pw = wave_sum_f32(fmaf(rr, rr, ri * ri));
-            if (lane == 0) rds_pow[((size_t)c * tiles + tile) * 2 + wv] = pw;
-        }
-        // reference :500-510: estimate against the +-pi/2 constellation, every 10th output of the block
-        const int ii = est_first + 10 * tid;
-        if (ii < TA) {
-            const float ph = fast_atan2f(res_lmr[ii], res_est_re[tid]);
-            const float half_pi = bits_f32(kHalfPiBits);
-            lmr_est[(size_t)c * d.n_est + (i0 + ii) / 10] = (ph > 0.0f) ? (half_pi - ph) : (-half_pi - ph);
-        }
-    }
-#ifdef FMD_X_PROBE
-    xp_t2 = xp_t; X_STAMP2(6);
-    if (xp_on && threadIdx.x == 0) { atomicAdd(&g_x_probe2[7], __builtin_readcyclecounter() - xp_c0); atomicAdd(&g_x_probe2[15], wall_clock64() - xp_w0); }   // shader cycles / 100 MHz ticks: the clock under this load
-#endif
-}
 
 #include "fmd_kernels_bp.inc"
 
@@ -2457,7 +2131,7 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
                                                         int bytes_cap, int keep_taps, const float* __restrict__ rds_pow, int n_pow) {
     // Tolerance mode: two ring slots instead of four (the loader keeps two chunks in registers beyond the one it stores: 7 us of
     // look-ahead are enough): 43 KB of LDS instead of 78 on the 64 CUs this kernel's workgroups sit on for most of a block's time —
-    // k_extract_mfma gets three workgroups beside it there instead of two
+    // the extract stage gets three workgroups beside it there instead of two
     constexpr int kRingSlots = FAST ? 2 : 4;
     constexpr int kSignWords = 33;                                       // 1024 symbols per lane between two runs of the decoder (+1: odd stride, no bank conflicts)
     __shared__ __attribute__((aligned(16))) float2 ring[kRingSlots][kWave * kRowC];
@@ -2466,7 +2140,7 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
     const int lane = threadIdx.x & (kWave - 1), c0 = blockIdx.x * kWave, c = c0 + lane;
     const bool live = c < d.C;
     const int cs = live ? c : d.C - 1;
-    // rds_pow (tolerance mode with k_extract_mfma): the block's power arrives as n_pow partial sums per station and the block is
+    // rds_pow (tolerance mode with k_extract_bp): the block's power arrives as n_pow partial sums per station and the block is
     // walked once; otherwise twice (power pass, then the synchroniser pass)
     const bool one_pass = FAST && rds_pow != nullptr;
     const int n = d.n_rds, chunks = n / kChunk, steps = one_pass ? chunks : 2 * chunks;      // step i handles chunk i mod chunks
@@ -3162,22 +2836,16 @@ static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
         if (ctx.fast) return launch_extract_ta<TA, true>(ctx, r, s);
     }
     if constexpr (FAST && TA == 256) {   // tolerance mode: the FIRs on the matrix cores
-        if (!ctx.extract_mix) {          // round 5: the mixers behind the FIRs (fmd_kernels_bp.inc)
-            const int tiles = d.n_audio / TA;
-            // a workgroup = station x 4 nt tiles, nt per wavefront (the station's tap tables are staged once per workgroup): the largest nt that
-            // still leaves 1536 workgroups for the chip (4 per CU: a round and a half)
-            int nt = 1;
-            for (int v = (tiles + 3) / 4; v >= 1; v--) if ((long)((tiles + 4 * v - 1) / (4 * v)) * d.C >= 1536) { nt = v; break; }
-            if (const char* e = dev_env("FMD_BP_NT")) { const int v = atoi(e); if (v > 0 && v <= 255) nt = v; }      // (development A/B)
-            if (dev_env("FMD_BP_NOEDGE")) nt |= 0x100;                       // (development, timing only: the first tile's sums over the previous block skipped)
-            FMD_LAUNCH(r, true, true, k_extract_bp, dim3((unsigned)((tiles + 4 * (nt & 0xff) - 1) / (4 * (nt & 0xff)) * d.C)), dim3(TA), 0, s, d, nt, b.fo_pl[r.buf], b.pll_poly[r.buf],
-                       b.bp_tab, b.aud_idx, b.rds_bp_tab, b.bp_edge, b.mix,
-                       b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est[r.par], b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps,
-                       lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr, lmr_field(r.par), lmr_field(r.par ^ 1), b.rds_pow[r.buf]);
-            return;
-        }
-        FMD_LAUNCH(r, true, true, k_extract_mfma, dim3((unsigned)(d.n_audio / TA * d.C)), dim3(TA), 0, s, d, b.fo_pl[r.buf], b.front_mfma + 6 * kWave, b.pll_poly[r.buf],
-                   b.aud_img, b.aud_idx, b.rds_img, b.b_lmr, b.mix,
+        // round 5: the mixers behind the FIRs, a wavefront per tile (fmd_kernels_bp.inc)
+        const int tiles = d.n_audio / TA;
+        // a workgroup = station x 4 nt tiles, nt per wavefront (the station's tap tables are staged once per workgroup): the largest nt that
+        // still leaves 1536 workgroups for the chip (4 per CU: a round and a half)
+        int nt = 1;
+        for (int v = (tiles + 3) / 4; v >= 1; v--) if ((long)((tiles + 4 * v - 1) / (4 * v)) * d.C >= 1536) { nt = v; break; }
+        if (const char* e = dev_env("FMD_BP_NT")) { const int v = atoi(e); if (v > 0 && v <= 255) nt = v; }      // (development A/B)
+        if (dev_env("FMD_BP_NOEDGE")) nt |= 0x100;                       // (development, timing only: the first tile's sums over the previous block skipped)
+        FMD_LAUNCH(r, true, true, k_extract_bp, dim3((unsigned)((tiles + 4 * (nt & 0xff) - 1) / (4 * (nt & 0xff)) * d.C)), dim3(TA), 0, s, d, nt, b.fo_pl[r.buf], b.pll_poly[r.buf],
+                   b.bp_tab, b.aud_idx, b.rds_bp_tab, b.bp_edge, b.mix,
                    b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est[r.par], b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps,
                    lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr, lmr_field(r.par), lmr_field(r.par ^ 1), b.rds_pow[r.buf]);
         return;
@@ -3239,7 +2907,7 @@ hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
     if (ctx.fast) {
-        const bool partials = d.n_audio % 256 == 0;       // k_extract_mfma ran and left the block's power as 2 partial sums per tile
+        const bool partials = d.n_audio % 256 == 0;       // k_extract_bp ran and left the block's power as 2 partial sums per tile
         static const bool two_waves = dev_env("FMD_RDS_TWO_WAVES") != nullptr;      // (A/B hook: the two-wavefront form)
         if (partials && !two_waves) {      // the loop split over mixer, clock and dump wavefronts (fmd_kernels_fast.inc)
             FMD_LAUNCH(r, true, true, k_rds_sync3, dim3(serial_waves(d)), dim3(5 * kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],

@@ -1,5 +1,5 @@
 """Development (GPU box, library built with -DFMD_X_PROBE: tools/build_variant.sh xprobe "-DFMD_X_PROBE"): cycles k_extract_bp's wavefronts 0 and 3
-spend between its barriers, per tile, averaged over every 61st workgroup of the bench's 4096-station blocks."""
+spend in the phases of a tile (a wavefront owns a tile: no barriers between them), averaged over every 61st workgroup of the bench's 4096-station blocks."""
 import sys, ctypes as C, numpy as np, pathlib
 ROOT = pathlib.Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests")); sys.path.insert(0, str(ROOT / "oracle"))
@@ -17,11 +17,11 @@ dm.synchronize()
 out = (C.c_ulonglong * 16)()
 assert dm.L.fmd_debug_read_x_probe(out) == 0
 v = list(out); cnt = max(v[7], 1)
-names = ["(prefetched window ->) staging", "wait barrier 1", "edge sums (first tile) + FIRs", "wait barrier 2", "epilogue (rotations, stores)"]
+names = ["window split into bf16 halves, span cubics asked for", "the workgroup's prologue (tables, estimates, S_old, barriers), per tile", "FIRs (88 ds_read_b128, 104 v_mfma)", "outputs from the accumulators, stores", "-"]
 for w, off in (("wavefront 0", 0), ("wavefront 3", 8)):
     print(w, "per tile", round(sum(v[off:off + 5]) / cnt))
-    for i, nme in enumerate(names):
-        print(f"   {nme:34s} {v[off + i] / cnt:8.0f} cycles")
+    for i, nme in enumerate(names[:4]):
+        print(f"   {nme:72s} {v[off + i] / cnt:8.0f} cycles")
 print("sampled tiles:", cnt)
 out2 = (C.c_ulonglong * 16)()
 if dm.L.fmd_debug_read_x_probe2(out2) == 0:
