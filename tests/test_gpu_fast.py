@@ -351,8 +351,8 @@ def test_fast_mode_de_emphasis_switched_on_and_off_between_blocks(pkg, fs, bs):
 
 def test_fast_mode_odd_block_length_and_per_station_cut_offs(pkg):
     """A block length whose tiles are the small ones (9216 samples at 256 kSa/s: 512-sample front tiles, 128-sample extract tiles
-    on the VALU), and eleven stations with eleven different L+R / L-R cut-offs: k_extract_mfma takes its Toeplitz operand images
-    per distinct cut-off (the table grows past its first allocation here) through a per-station index."""
+    on the VALU), and eleven stations with eleven different L+R / L-R cut-offs: k_extract_bp takes its tap tables (and the matrix of
+    the block-edge sums) per distinct cut-off (the table grows past its first allocation here) through a per-station index."""
     from fm_radio_amd.capi import default_controls
     from gpu_parity import oracle_controls
     for bs, n_ch in ((9216, 3), (16384, 11)):
@@ -373,6 +373,21 @@ def test_fast_mode_odd_block_length_and_per_station_cut_offs(pkg):
             ex, _, _, _ = lmr_audio_excess(g, o, c, caps.shape[1] // bs)
             assert ex <= 1.0, (bs, c, ex)
             assert same_bits_once_in_lock(g["rds_bytes"][c], o["rds_bytes"], skip_bits=5 * 76), (bs, c)
+
+
+@pytest.mark.parametrize("bs", [2048, 4096, 6144, 12288])
+def test_fast_mode_short_blocks_whose_tiles_do_not_fill_a_workgroup(pkg, bs):
+    """k_extract_bp gives each of a workgroup's four wavefronts tiles of 256 audio samples (tile_first + w, + 4, ...): blocks of 1, 2, 3 and
+    6 tiles leave wavefronts without a tile or with fewer than the others; the block edge (the first 31 outputs' sums over the previous
+    block) then comes round every 1-6 tiles.  L+R, L-R and audio against the oracle from the first block."""
+    nb = 8 * 16384 // bs
+    caps = _caps(2, nb * bs, 256_000.0, seed=9500 + bs)
+    g = run_gpu(pkg, caps, bs, 256_000, fast_math=True)
+    for c in range(2):
+        o = O.run_chain(caps[c], bs, 256_000, u8=False, coeffs=lib_coeffs_to_oracle(g["coeffs"][c]), streams=["lpr", "lmr", "audio", "lmr_phase"])
+        assert rms(g["lpr"][c].astype(np.float64) - o["lpr"]) <= TOL_RMS, (bs, c)
+        assert lmr_audio_excess(g, o, c, nb)[0] <= 1.0, (bs, c)
+        assert np.all(np.isfinite(g["audio"][c]))
 
 
 def test_fast_mode_golden_chain_fixture(pkg, golden):
