@@ -30,7 +30,7 @@ def weight(op: str, line: str) -> float:
 
 
 def main() -> None:
-    pats = sys.argv[1:] or ["k_front_mfmaI15HIP_vector_typeIfLj2EELi1024ELi0", "k_extract_mfma", "k_pll_sparse"]
+    pats = sys.argv[1:] or ["k_front_mfmaI15HIP_vector_typeIfLj2EELi1024ELi0", "k_extract_bp", "k_pll_sparse"]
     with tempfile.TemporaryDirectory() as d:
         s = pathlib.Path(d) / "k.s"
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form", f"-I{ROOT / 'include'}", "-S", "--cuda-device-only",

@@ -22,7 +22,7 @@ for line in err.splitlines():
         cur[k] = v
 out = ["# Kernel resources (hipcc -O3 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage of fm-radio_amd/csrc/fmd_kernels.hip, tools/kernel_resources.py)", "",
        "Occupancy column: wavefronts per SIMD the register allocation allows (512 VGPRs + AGPRs per lane and SIMD); LDS (160 KB per CU) and the",
-       "launch (four wavefronts per workgroup for k_pll_sparse and k_rds_sync3) bound it further: k_extract_mfma 5 workgroups per CU, k_front_mfma 7-8.", "",
+       "launch (four wavefronts per workgroup for k_pll_sparse and k_rds_sync3) bound it further: k_extract_bp 4 workgroups per CU (40.7 KB of LDS each), k_front_mfma 6-8.", "",
        "| kernel | VGPRs | AGPRs | SGPRs | static LDS bytes / workgroup | scratch B/lane | waves/SIMD by registers |", "|---|---|---|---|---|---|---|"]
 for name in sorted(rows):
     r = rows[name]
