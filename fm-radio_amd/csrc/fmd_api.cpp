@@ -1001,10 +1001,16 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         int i = 0;
+        const int reserve_cus = dev_env("FMD_CU_RESERVE") ? atoi(dev_env("FMD_CU_RESERVE")) : 0;
         for (hipStream_t* st : {&h->sF, &h->sD, &h->sA, &h->sB, &h->sX, &h->sR}) {
             const int p = std::min(least, std::max(greatest, prio[i++]));
             hipError_t e;
             if (!mask_f.empty() && !mask_x.empty() && (st == &h->sF || st == &h->sX)) { const auto& mk = st == &h->sF ? mask_f : mask_x; e = hipExtStreamCreateWithCUMask(st, (uint32_t)mk.size(), mk.data()); }
+            else if (reserve_cus > 0) {      // (development: the RDS stage's queue on CUs 0 .. reserve - 1 of every XCD, every other queue on the rest)
+                uint32_t mk[8];
+                for (int w = 0; w < 8; w++) { const int lo = 32 * w; uint32_t v = 0; for (int b = 0; b < 32; b++) if (((lo + b) / 8 < reserve_cus) == (st == &h->sR)) v |= 1u << b; mk[w] = v; }
+                e = hipExtStreamCreateWithCUMask(st, 8, mk);
+            }
             else e = p ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, p) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
             if (e != hipSuccess) return bail(fail(h, FMD_ERR_DEVICE, "stream: %s", hipGetErrorString(e)));
         }
