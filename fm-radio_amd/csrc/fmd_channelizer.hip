@@ -47,11 +47,25 @@ struct ChanDims {
     long long n_out;        // outputs per station this call
     long long out_stride;   // row stride of the caller's output buffer (its capacity per station)
     unsigned long long o0;  // absolute index of the first output of this call
-    unsigned long long n_base;  // absolute input index of win[0]
+    unsigned long long n_base;  // absolute input index of the window's first sample: [T - 1 history samples][this call's block]
+    long long n_in;             // samples of this call's block
 };
 
+// The window of a call is [T - 1 history samples][the caller's block]: two buffers, read in place (round 5: staging the block behind the
+// history and copying the new history out were two device copies around every launch — 5 us each plus the queue's gaps, a quarter of a
+// 10 MSa/s block's 100 us on the channeliser's queue).  The launch's first workgroup hands the last T - 1 samples over to the OTHER
+// history buffer, which no workgroup of this launch reads.
+struct ChanWin { const float2* hist; const float2* blk; float2* next_hist; };
+__device__ __forceinline__ float2 win_at(const ChanDims& d, const ChanWin& w, long long j) {
+    const float2* p = j < d.T - 1 ? w.hist + j : w.blk + (j - (d.T - 1));      // (the POINTER is selected: one load, no branch)
+    return *p;
+}
+__device__ __forceinline__ void hand_over_history(const ChanDims& d, const ChanWin& w) {
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < d.T - 1; i += 256) w.next_hist[i] = win_at(d, w, d.n_in + i);
+}
 // window staging shared by both kernels: xs[i] = win[n_lo + i] * exp(-j 2 pi f n / fs)
-__device__ __forceinline__ void stage_mixed(const ChanDims& d, const float2* __restrict__ win, unsigned long long n_lo, int n_win,
+__device__ __forceinline__ void stage_mixed(const ChanDims& d, const ChanWin& win, unsigned long long n_lo, int n_win,
                                             unsigned long long inc, float2* xs) {
     // phase in turns = frac(n_abs * f_k / fs_in), exact in 64-bit modular arithmetic, then one rounding to float
     const unsigned long long n_first = n_lo + (unsigned long long)threadIdx.x;
@@ -62,7 +76,7 @@ __device__ __forceinline__ void stage_mixed(const ChanDims& d, const float2* __r
     float ss, cs;
     sincospif((float)phs * 4.656612873077393e-10f, &ss, &cs);
     for (int i = threadIdx.x; i < n_win; i += 256) {
-        const float2 x = win[(n_lo + (unsigned long long)i) - d.n_base];
+        const float2 x = win_at(d, win, (long long)((n_lo + (unsigned long long)i) - d.n_base));
         xs[i] = make_float2(fmaf(x.x, c, x.y * s), fmaf(x.y, c, -(x.x * s)));   // x * (cos - j sin)
         const float cn = fmaf(c, cs, -(s * ss)), sn = fmaf(s, cs, c * ss);
         c = cn; s = sn;
@@ -70,7 +84,7 @@ __device__ __forceinline__ void stage_mixed(const ChanDims& d, const float2* __r
 }
 
 // L == 16: see the header comment
-__global__ __launch_bounds__(256) void k_channelize16(ChanDims d, const float2* __restrict__ win, const float* __restrict__ taps /* [T][16] */,
+__global__ __launch_bounds__(256) void k_channelize16(ChanDims d, ChanWin win, const float* __restrict__ taps /* [T][16] */,
                                                       const unsigned long long* __restrict__ phase_inc, float2* __restrict__ out) {
     constexpr int L = 16, PER = kTile / L;                    // 8 outputs of a branch per tile
     constexpr int kMaxSlice = 64;                             // taps per slice held in registers (T <= 1024)
@@ -83,6 +97,7 @@ __global__ __launch_bounds__(256) void k_channelize16(ChanDims d, const float2* 
     const unsigned long long n_hi = (o_last * (unsigned long long)d.M) / (unsigned long long)L;
     const unsigned long long n_lo = (o_first * (unsigned long long)d.M) / (unsigned long long)L - (unsigned long long)(d.T - 1);
     stage_mixed(d, win, n_lo, (int)(n_hi - n_lo + 1), phase_inc[k], xs);
+    hand_over_history(d, win);
     // this thread's branch and slice: outputs oo = j0 + 16 q (q < 8) where j0 is the tile-relative output with branch p
     const int p = threadIdx.x & (L - 1), sl = threadIdx.x >> 4;
     const int tps = d.T / kSlices, t0 = sl * tps;             // T is a multiple of 64
@@ -138,7 +153,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // Non-finite input: the banded operand multiplies EVERY staged sample of a group's 1232-sample window, its structural zeros included, so
 // one Inf / NaN input sample makes all 16 outputs of every group whose window holds it NaN (the VALU form only those with a real tap on
 // it).  A capture from a device is u8 / finite by construction; a host that may feed non-finite floats filters them at its boundary.
-__global__ __launch_bounds__(256, 3) void k_channelize16_mfma(ChanDims d, const float2* __restrict__ win, const float* __restrict__ atab /* [4][77][64] */,
+__global__ __launch_bounds__(256, 3) void k_channelize16_mfma(ChanDims d, ChanWin win, const float* __restrict__ atab /* [4][77][64] */,
                                                            const unsigned long long* __restrict__ phase_inc, float2* __restrict__ out, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xr = smem;                       // mixed window, real rail: xr[i] = Re x_k[n_lo + i]
@@ -153,6 +168,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize16_mfma(ChanDims d, const 
     float ss, cs;
     sincospif((float)(unsigned int)((256ull * inc) >> 32) * 4.656612873077393e-10f, &ss, &cs);
     const float* xb = ((col >> 3) ? xi : xr) + d.M * (col & 7) + kq + 4 * kMKW * wv;
+    hand_over_history(d, win);
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long tile0 = (long long)tile * kTile;
         const int n_tile = (int)((d.n_out - tile0) < kTile ? (d.n_out - tile0) : kTile);
@@ -162,17 +178,34 @@ __global__ __launch_bounds__(256, 3) void k_channelize16_mfma(ChanDims d, const 
         {
             float s, c;
             sincospif((float)(unsigned int)(((n_lo + (unsigned long long)tid) * inc) >> 32) * 4.656612873077393e-10f, &s, &c);
-            const float2* src = win + (n_lo - d.n_base);
+            const long long j0 = (long long)(n_lo - d.n_base);
             constexpr int PER = (kMRail + 255) / 256;
             float2 x[PER];
+            // the caller's block through ONE base and immediate offsets (per-sample pointers for all 22 spilled registers); the history's
+            // samples — in front of a call's first windows only — are patched in behind, a sample at a time
+            const long long jb = j0 - (d.T - 1);          // where the window starts in the block: negative in front of a call's first windows
+            const float2* src = win.blk + jb;
+            const int i_lo = jb < 0 ? (int)(-jb) : 0;     // (one unsigned compare per sample: i_lo <= i < n_valid)
 #pragma unroll
-            for (int r = 0; r < PER; r++) { const int i = tid + 256 * r; x[r] = (i < n_valid) ? src[i] : make_float2(0.f, 0.f); }
+            for (int r = 0; r < PER; r++) { const int i = tid + 256 * r; x[r] = ((unsigned)(i - i_lo) < (unsigned)(n_valid - i_lo)) ? src[i] : make_float2(0.f, 0.f); }
 #pragma unroll
             for (int r = 0; r < PER; r++) {
                 const int i = tid + 256 * r;
                 if (i < kMRail) { xr[i] = fmaf(x[r].x, c, x[r].y * s); xi[i] = fmaf(x[r].y, c, -(x[r].x * s)); }   // x * (cos - j sin)
                 const float cn = fmaf(c, cs, -(s * ss)), sn = fmaf(s, cs, c * ss);
                 c = cn; s = sn;
+            }
+            if (jb < 0) {
+                const int nh = (int)(-jb) < n_valid ? (int)(-jb) : n_valid;
+#pragma unroll 1
+                for (int i = tid; i < nh; i += 256) {
+                    const float2 v = win.hist[j0 + i];
+                    // the phase of sample i exactly as the recurrence above reaches it: i = tid + 256 r steps of (cs, ss) from the thread's first
+                    float s2, c2;
+                    sincospif((float)(unsigned int)(((n_lo + (unsigned long long)tid) * inc) >> 32) * 4.656612873077393e-10f, &s2, &c2);
+                    for (int q = 0; q < i / 256; q++) { const float cn = fmaf(c2, cs, -(s2 * ss)), sn = fmaf(s2, cs, c2 * ss); c2 = cn; s2 = sn; }
+                    xr[i] = fmaf(v.x, c2, v.y * s2); xi[i] = fmaf(v.y, c2, -(v.x * s2));
+                }
             }
         }
         __syncthreads();
@@ -196,7 +229,7 @@ __global__ __launch_bounds__(256, 3) void k_channelize16_mfma(ChanDims d, const 
 }
 
 // any L <= 64: one output per thread (the first 128 threads), taps read from global memory
-__global__ __launch_bounds__(256) void k_channelize(ChanDims d, const float2* __restrict__ win, const float* __restrict__ taps /* [T][L] */,
+__global__ __launch_bounds__(256) void k_channelize(ChanDims d, ChanWin win, const float* __restrict__ taps /* [T][L] */,
                                                     const unsigned long long* __restrict__ phase_inc /* [C], turns * 2^64 per input sample */,
                                                     float2* __restrict__ out /* [C][out_stride] */) {
     __shared__ float2 xs[kMaxWindow];
@@ -208,6 +241,7 @@ __global__ __launch_bounds__(256) void k_channelize(ChanDims d, const float2* __
     const unsigned long long n_hi = (o_last * (unsigned long long)d.M) / (unsigned long long)d.L;
     const unsigned long long n_lo = (o_first * (unsigned long long)d.M) / (unsigned long long)d.L - (unsigned long long)(d.T - 1);
     stage_mixed(d, win, n_lo, (int)(n_hi - n_lo + 1), phase_inc[k], xs);
+    hand_over_history(d, win);
     __syncthreads();
     for (int oo = threadIdx.x; oo < n_tile; oo += 256) {
         const unsigned long long o = o_first + (unsigned long long)oo;
@@ -245,7 +279,7 @@ struct fmd_channelizer_s {
     size_t max_in = 0;
     unsigned long long n_abs = 0;     // absolute index of the next input sample
     unsigned long long o_abs = 0;     // absolute index of the next output sample
-    float2* win[2] = {nullptr, nullptr};   // [T-1 + max_in] each, ping-pong: the history hand-over copies between DIFFERENT buffers
+    float2* win[2] = {nullptr, nullptr};   // [T - 1] history samples each, ping-pong: a launch reads one and writes the next call's into the other
     int cur = 0;                      // window the next call stages into (its first T-1 samples hold the history)
     hipEvent_t done = nullptr;        // end of the previous call's work, for callers that change streams between calls
     bool have_done = false;
@@ -318,11 +352,11 @@ int fmd_chan_create(const fmd_chan_config* cfg, fmd_channelizer* out) {
         inc[k] = (unsigned long long)std::llround(std::ldexp(fr, 63)) << 1;   // fr * 2^64, even
     }
     bool ok = hipSetDevice(dev) == hipSuccess;
-    for (int i = 0; i < 2; i++) ok = ok && hipMalloc(&h->win[i], sizeof(float2) * (h->max_in + (size_t)T)) == hipSuccess;
+    for (int i = 0; i < 2; i++) ok = ok && hipMalloc(&h->win[i], sizeof(float2) * (size_t)T) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->done, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(&h->taps, sizeof(float) * h->h_taps.size()) == hipSuccess;
     ok = ok && hipMalloc(&h->inc, sizeof(unsigned long long) * h->C) == hipSuccess;
-    for (int i = 0; i < 2; i++) ok = ok && hipMemset(h->win[i], 0, sizeof(float2) * (h->max_in + (size_t)T)) == hipSuccess;
+    for (int i = 0; i < 2; i++) ok = ok && hipMemset(h->win[i], 0, sizeof(float2) * (size_t)T) == hipSuccess;
     ok = ok && hipMemcpy(h->taps, h->h_taps.data(), sizeof(float) * h->h_taps.size(), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(h->inc, inc.data(), sizeof(unsigned long long) * h->C, hipMemcpyHostToDevice) == hipSuccess;
     // the matrix-core form: L == 16 and the operand / window sizes it is built for (10 MSa/s -> 256 kSa/s with 640 taps per phase)
@@ -375,7 +409,7 @@ int fmd_chan_reset(fmd_channelizer h) {
     if (!h) return FMD_ERR_ARG;
     if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "synchronise failed");
     for (int i = 0; i < 2; i++)
-        if (hipMemset(h->win[i], 0, sizeof(float2) * (h->max_in + (size_t)h->T)) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "memset failed");
+        if (hipMemset(h->win[i], 0, sizeof(float2) * (size_t)h->T) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "memset failed");
     h->n_abs = 0; h->o_abs = 0; h->cur = 0; h->have_done = false;
     return FMD_OK;
 }
@@ -391,11 +425,9 @@ int fmd_chan_process_cf32_dev(fmd_channelizer h, const float* d_wide, size_t n_i
     const int T = h->T;
     // the windows carry state from call to call: a caller that switches streams is ordered behind the previous call's work
     if (h->have_done && hipStreamWaitEvent(s, h->done, 0) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "stream wait failed");
-    // window = [T-1 history samples][this block]; win[0] has absolute input index n_abs - (T-1)
-    float2* win = h->win[h->cur];
-    float2* next = h->win[h->cur ^ 1];
-    if (hipMemcpyAsync(win + (T - 1), d_wide, sizeof(float2) * n_in, hipMemcpyDeviceToDevice, s) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "staging copy failed");
-    ChanDims d{h->L, h->M, T, h->C, (long long)no, (long long)out_capacity_per_station, h->o_abs, h->n_abs - (unsigned long long)(T - 1)};
+    // window = [T-1 history samples][this block], read in place; its first sample has absolute input index n_abs - (T-1)
+    const ChanWin win{h->win[h->cur], reinterpret_cast<const float2*>(d_wide), h->win[h->cur ^ 1]};
+    ChanDims d{h->L, h->M, T, h->C, (long long)no, (long long)out_capacity_per_station, h->o_abs, h->n_abs - (unsigned long long)(T - 1), (long long)n_in};
     // outputs o0 .. o0+no-1 need inputs up to floor((o0+no-1) M / L) <= n_abs + n_in - 1 by construction
     if (h->atab) {
         // every workgroup keeps its operand registers over several tiles: about three workgroups per CU in all
@@ -411,9 +443,8 @@ int fmd_chan_process_cf32_dev(fmd_channelizer h, const float* d_wide, size_t n_i
         hipLaunchKernelGGL(k_channelize, dim3((unsigned)((no + kTile - 1) / kTile), (unsigned)h->C), dim3(256), 0, s, d, win, h->taps, h->inc,
                            reinterpret_cast<float2*>(d_out));
     if (hipGetLastError() != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "k_channelize launch failed");
-    // the last T-1 samples of [history ++ block] are the next call's history: copied into the OTHER window, so source and
-    // destination never overlap however short the block is (n_in = 625 < T - 1 = 639 is a legal call)
-    if (hipMemcpyAsync(next, win + n_in, sizeof(float2) * (size_t)(T - 1), hipMemcpyDeviceToDevice, s) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "history copy failed");
+    // (the last T-1 samples of [history ++ block] are the next call's history: the launch's first workgroup has written them into the
+    //  OTHER history buffer, however short the block is — n_in = 625 < T - 1 = 639 is a legal call)
     if (hipEventRecord(h->done, s) != hipSuccess) return chan_fail(h, FMD_ERR_DEVICE, "event record failed");
     h->have_done = true;
     h->cur ^= 1;

@@ -293,7 +293,8 @@ int fmd_chan_get_taps(fmd_channelizer h, float* taps, size_t cap_floats);
 /* d_wide: [n_in][2] cf32 on the device; n_in * L must be a multiple of M (625 input samples per 16 outputs at 10 M -> 256 k).
  * d_out: [n_stations][out_capacity_per_station][2] cf32 on the device — station k's *n_out samples start at row k (row
  * stride = out_capacity_per_station; pass the exact n_out to get the dense [C][n_out] layout fmd_process_cf32_dev takes).
- * Asynchronous on `stream`; consecutive calls may use different streams (the library orders them). */
+ * Asynchronous on `stream`; consecutive calls may use different streams (the library orders them).  d_wide is read IN PLACE by the call's
+ * kernel (no staging copy): like d_out it belongs to the call until its work on `stream` has completed. */
 int fmd_chan_process_cf32_dev(fmd_channelizer h, const float* d_wide, size_t n_in, float* d_out, size_t out_capacity_per_station,
                               size_t* n_out, void* stream);
 const char* fmd_chan_last_error(fmd_channelizer h);
