@@ -430,9 +430,14 @@ int fmd_chan_process_cf32_dev(fmd_channelizer h, const float* d_wide, size_t n_i
     ChanDims d{h->L, h->M, T, h->C, (long long)no, (long long)out_capacity_per_station, h->o_abs, h->n_abs - (unsigned long long)(T - 1), (long long)n_in};
     // outputs o0 .. o0+no-1 need inputs up to floor((o0+no-1) M / L) <= n_abs + n_in - 1 by construction
     if (h->atab) {
-        // every workgroup keeps its operand registers over several tiles: about three workgroups per CU in all
+        // every workgroup keeps its operand registers over several tiles
         const int n_tiles = (int)((no + kTile - 1) / kTile);
-        int gx = (3 * 256) / h->C;
+        // two workgroups per CU: three (what its 164 registers and 49 KB of LDS allow) leave no wavefront slot and no LDS for the
+        // demodulator's kernels that run beside it, which then wait for a 60 us persistent workgroup to finish — the configs[4] line x537
+        // with three, x571-581 with two (profiles/round5/rds_stage_ab.txt)
+        int per_cu = 2;
+        if (const char* e = fmd::dev_env("FMD_CHAN_WG_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 3) per_cu = v; }      // (development A/B)
+        int gx = (per_cu * 256) / h->C;
         gx = gx < 1 ? 1 : (gx > n_tiles ? n_tiles : gx);
         hipLaunchKernelGGL(k_channelize16_mfma, dim3((unsigned)gx, (unsigned)h->C), dim3(256), sizeof(float) * (2 * kMRail + 4 * 256), s, d, win, h->atab, h->inc,
                            reinterpret_cast<float2*>(d_out), n_tiles);
