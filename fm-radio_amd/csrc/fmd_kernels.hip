@@ -2634,6 +2634,16 @@ __global__ void k_reset(Dims d, float* __restrict__ state) {
 // ---------------------------------------------------------------------------------------------
 // host-side stage launchers
 // ---------------------------------------------------------------------------------------------
+// Batches of 1024 .. 1792 stations at 256 kSa/s (the smallest on the deferred schedule — fmd_api.cpp — up to where the front end's own length takes over): the serial RDS stage's launch is the step (0.092 ms alone, 0.12 beside the throughput kernels)
+// and the front end has slack.  With 44 KB of extra dynamic LDS its workgroups come two to a CU instead of six and leave the serial stages'
+// wavefronts the issue slots: 1024 stations 0.125 -> 0.114 ms (RDS launch 0.121 -> 0.102, the front end itself 0.060 -> 0.053), 1536 stations
+// 0.135 -> 0.126, 1792: 0.144 -> 0.136, 1024 x u8 0.117 -> 0.110; 512 stations and the 40 of configs[4]: no difference; 640: slower (0.111 ->
+// 0.120: no deferred schedule there), 2048: slower (0.148 -> 0.154) (profiles/round5/rds_stage_ab.txt).  FMD_FRONT_LDS_PAD (development builds) overrides the amount.
+static size_t front_lds_pad(const Dims& d) {
+    static const long forced = dev_env("FMD_FRONT_LDS_PAD") ? atol(dev_env("FMD_FRONT_LDS_PAD")) : -1;
+    if (forced >= 0) return (size_t)(forced <= 49152 ? forced : 49152);
+    return (d.m == 1 && d.C >= 1024 && d.C <= 1792) ? 45056 : 0;
+}
 template <typename InT, int TT = 512, bool FAST = false>
 static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq, hipStream_t s, const SlotRef* pll = nullptr) {
     using G = FrontGeom<TT>;
@@ -2659,15 +2669,15 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
         const unsigned grid = (unsigned)(tiles * d.C + pf.n_wg);
         if (ctx.deemph_in_tile) {
             using GM = FrontGeomM<TT, kDeemphWarmup>;
-            if (pll) FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, kDeemphWarmup, true>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
+            if (pll) FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, kDeemphWarmup, true>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS + front_lds_pad(d), s, d, d_iq,
                                 ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, ctx.b.pv_pl[r.buf], ctx.b.sparse_tab, pf);
-            else FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, kDeemphWarmup, false>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
+            else FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, kDeemphWarmup, false>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS + front_lds_pad(d), s, d, d_iq,
                             ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, ctx.b.pv_pl[r.buf], ctx.b.sparse_tab, pf);
         } else {
             using GM = FrontGeomM<TT, 0>;
-            if (pll) FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, 0, true>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
+            if (pll) FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, 0, true>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS + front_lds_pad(d), s, d, d_iq,
                                 ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, ctx.b.pv_pl[r.buf], ctx.b.sparse_tab, pf);
-            else FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, 0, false>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS, s, d, d_iq,
+            else FMD_LAUNCH(r, true, true, (k_front_mfma<InT, TT, 0, false>), dim3(grid), dim3(256), sizeof(float) * GM::LDS_FLOATS + front_lds_pad(d), s, d, d_iq,
                             ctx.b.base_tail[r.par], ctx.b.base_tail[r.par ^ 1], ctx.b.fo_pl[r.buf], ctx.front.fm_gain, ctx.b.deemph, ctx.b.front_mfma, ctx.b.pv_pl[r.buf], ctx.b.sparse_tab, pf);
         }
         return hipGetLastError();
@@ -2931,16 +2941,16 @@ static hipError_t prepare_front() {
                                        (int)(sizeof(float) * FrontGeom<TT>::LDS_FLOATS));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(float) * FrontGeomM<TT, 0>::LDS_FLOATS));
+                            (int)(sizeof(float) * FrontGeomM<TT, 0>::LDS_FLOATS) + 49152);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, kDeemphWarmup, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(float) * FrontGeomM<TT, kDeemphWarmup>::LDS_FLOATS));
+                            (int)(sizeof(float) * FrontGeomM<TT, kDeemphWarmup>::LDS_FLOATS) + 49152);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(float) * FrontGeomM<TT, 0>::LDS_FLOATS));
+                            (int)(sizeof(float) * FrontGeomM<TT, 0>::LDS_FLOATS) + 49152);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_mfma<InT, TT, kDeemphWarmup, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(float) * FrontGeomM<TT, kDeemphWarmup>::LDS_FLOATS));
+                            (int)(sizeof(float) * FrontGeomM<TT, kDeemphWarmup>::LDS_FLOATS) + 49152);
     if (e != hipSuccess) return e;
     return e;
 }
