@@ -84,6 +84,7 @@ struct fmd_handle_s {
     int sub_slot = 0;                        // slot of the newest submitted block
     bool have_out = false;                   // some block's output stages have been queued since create / reset
     long out_block = -1;                     // ... and which block's (0 = the first since create / reset) the output views are
+    long epoch = 0;                          // how often the block numbering restarted (fmd_reset, fmd_set_config ...): fmd_outputs_epoch
     bool lag_outputs = false;                // fmd_set_output_lag
     hipEvent_t ev_consumed = nullptr;        // fires when the newest block's input buffer has been read (fmd_wait_input)
     int device = 0;
@@ -586,6 +587,7 @@ int zero_history(fmd_handle h, hipStream_t s) {
     for (hipEvent_t& e : h->x_done) e = nullptr;
     h->ev_consumed = nullptr;
     h->out_slot = 0; h->sub_slot = 0; h->have_out = false; h->out_block = -1;
+    h->epoch++;
     for (bool& u : h->slot_used) u = false;
     for (bool& u : h->consumer_pending) u = false;
     h->poisoned = false;
@@ -1262,6 +1264,12 @@ int fmd_outputs_block(fmd_handle h, long* block) {
     int rc = outputs_wanted(h);
     if (rc) return rc;
     *block = h->have_out ? h->out_block : -1;
+    return FMD_OK;
+}
+
+int fmd_outputs_epoch(fmd_handle h, long* epoch) {
+    if (!h || !epoch) return FMD_ERR_ARG;
+    *epoch = h->epoch;
     return FMD_OK;
 }
 

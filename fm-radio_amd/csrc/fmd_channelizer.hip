@@ -57,8 +57,10 @@ struct ChanDims {
 // history buffer, which no workgroup of this launch reads.
 struct ChanWin { const float2* hist; const float2* blk; float2* next_hist; };
 __device__ __forceinline__ float2 win_at(const ChanDims& d, const ChanWin& w, long long j) {
-    const float2* p = j < d.T - 1 ? w.hist + j : w.blk + (j - (d.T - 1));      // (the POINTER is selected: one load, no branch)
-    return *p;
+    // (base and index are selected, then ONE load, no branch; the address is never formed from `blk` with a negative offset — ADVICE r5)
+    const long long jb = j - (d.T - 1);
+    const float2* base = jb < 0 ? w.hist : w.blk;
+    return base[jb < 0 ? j : jb];
 }
 __device__ __forceinline__ void hand_over_history(const ChanDims& d, const ChanWin& w) {
     if (blockIdx.x == 0 && blockIdx.y == 0)
@@ -184,7 +186,9 @@ __global__ __launch_bounds__(256, 3) void k_channelize16_mfma(ChanDims d, ChanWi
             // the caller's block through ONE base and immediate offsets (per-sample pointers for all 22 spilled registers); the history's
             // samples — in front of a call's first windows only — are patched in behind, a sample at a time
             const long long jb = j0 - (d.T - 1);          // where the window starts in the block: negative in front of a call's first windows
-            const float2* src = win.blk + jb;
+            // (the base of the immediate offsets, made by INTEGER arithmetic: with jb < 0 it lies in front of the block and `win.blk + jb` would be
+            //  pointer arithmetic out of the array — ADVICE r5; only elements i >= -jb are ever read through it)
+            const float2* src = reinterpret_cast<const float2*>(reinterpret_cast<uintptr_t>(win.blk) + (uintptr_t)(jb * (long long)sizeof(float2)));
             const int i_lo = jb < 0 ? (int)(-jb) : 0;     // (one unsigned compare per sample: i_lo <= i < n_valid)
 #pragma unroll
             for (int r = 0; r < PER; r++) { const int i = tid + 256 * r; x[r] = ((unsigned)(i - i_lo) < (unsigned)(n_valid - i_lo)) ? src[i] : make_float2(0.f, 0.f); }

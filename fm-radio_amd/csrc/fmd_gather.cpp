@@ -108,14 +108,14 @@ int fmd_gather_create(const fmd_gather_config* cfg, const fmd_handle* handles, f
     const int root_dev = P.devices[(size_t)cfg->root];
     // equal shards, one geometry
     fmd_rates r0{};
-    std::vector<long> blk0((size_t)cfg->n_ranks, -1);
+    std::vector<long> blk0((size_t)cfg->n_ranks, -1), epoch0((size_t)cfg->n_ranks, 0);
     for (int i = 0; i < cfg->n_ranks; i++) {
         if (!handles[i]) return bail(gfail(g, FMD_ERR_ARG, "rank %d: null handle", i));
         fmd_rates ri{};
         const uint8_t* b = nullptr; const int* c = nullptr; int cap = 0;
         if (fmd_get_rates(handles[i], &ri) != FMD_OK || fmd_rds_bytes_dev(handles[i], &b, &c, &cap) != FMD_OK) return bail(gfail(g, FMD_ERR_ARG, "rank %d: handle refused", i));
         fmd_config ci{};
-        if (fmd_get_config(handles[i], &ci) != FMD_OK || fmd_outputs_block(handles[i], &blk0[(size_t)i]) != FMD_OK) return bail(gfail(g, FMD_ERR_ARG, "rank %d: handle refused", i));
+        if (fmd_get_config(handles[i], &ci) != FMD_OK || fmd_outputs_block(handles[i], &blk0[(size_t)i]) != FMD_OK || fmd_outputs_epoch(handles[i], &epoch0[(size_t)i]) != FMD_OK) return bail(gfail(g, FMD_ERR_ARG, "rank %d: handle refused", i));
         if (ci.device != cfg->devices[i]) return bail(gfail(g, FMD_ERR_ARG, "rank %d: handle lives on device %d, not %d", i, ci.device, cfg->devices[i]));
         const int C = ci.n_channels;
         if (i == 0) { r0 = ri; g->C_local = C; g->n_audio = ri.n_audio; g->cap = cap; }
@@ -131,7 +131,7 @@ int fmd_gather_create(const fmd_gather_config* cfg, const fmd_handle* handles, f
         rc->h = handles[i];
         rc->local = rc->dev == root_dev;
         rc->comm_index = P.comm_index[(size_t)i];
-        rc->blocks.start(blk0[(size_t)i]);           // (a handle that has run blocks before the gather exists: its numbering is ahead by that much)
+        rc->blocks.start(blk0[(size_t)i], epoch0[(size_t)i]);           // (a handle that has run blocks before the gather exists: its numbering is ahead by that much)
         g->r.push_back(std::move(rc));
     }
     g->comms.assign(g->plan.uniq.size(), nullptr);
@@ -170,7 +170,13 @@ int fmd_gather_destroy(fmd_gather g) {
     // the stream it is queued on: the communicators are aborted FIRST (every rank thread has left the library by now: the caller joins
     // them before it destroys — multi_gpu_host.hpp does), which completes what is queued on them; only then are the streams drained.
     const bool aborted = g->sync && g->sync->is_aborted();
-    if (aborted) for (ncclComm_t& c : g->comms) if (c) { (void)ncclCommAbort(c); c = nullptr; }
+    // (each communicator's lock is taken around its abort: a caller that destroys while a rank thread is still inside ncclSend / ncclRecv —
+    //  against the contract of fmdemod_gather.h — then waits for that call instead of freeing the communicator under it)
+    if (aborted) for (size_t i = 0; i < g->comms.size(); i++) if (g->comms[i]) {
+        std::unique_lock<std::mutex> lk;
+        if (i < g->comm_mu.size() && g->comm_mu[i]) lk = std::unique_lock<std::mutex>(*g->comm_mu[i]);
+        (void)ncclCommAbort(g->comms[i]); g->comms[i] = nullptr;
+    }
     for (auto& rc : g->r) {
         (void)hipSetDevice(rc->dev);
         if (rc->s) { (void)hipStreamSynchronize(rc->s); (void)hipStreamDestroy(rc->s); }
@@ -202,10 +208,11 @@ int fmd_gather_submit(fmd_gather g, int rank) {
     if (!g->sync->begin_submit(k)) return gfail(g, FMD_ERR_STATE, "gather aborted");
     G_HIP(g, hipSetDevice(rc.dev));
     {   // the handle's device views must be THIS block's (a handle under fmd_set_output_lag shows the block before: not supported here)
-        long blk = -1;
+        long blk = -1, epoch = 0;
         G_FMD(g, rc.h, fmd_outputs_block(rc.h, &blk));
-        const long rel = rc.blocks.relative(blk, k);
-        if (rel != k) return gfail(g, FMD_ERR_ARG, "rank %d: the handle's outputs are its block %ld (%ld since fmd_gather_create), the gather expects block %ld (submit one block per fmd_gather_submit; handles under fmd_set_output_lag are not supported)", rank, blk, rel, k);
+        G_FMD(g, rc.h, fmd_outputs_epoch(rc.h, &epoch));
+        const long rel = rc.blocks.relative(blk, epoch, k);
+        if (rel != k) return gfail(g, FMD_ERR_ARG, "rank %d: the handle's outputs are its block %ld (%ld since fmd_gather_create), the gather expects block %ld: one new block per fmd_gather_submit — a repeated submit, a skipped block, or a handle under fmd_set_output_lag (whose views are the block before: not supported here)", rank, blk, rel, k);
     }
     // the block's outputs, behind its last stage, on the rank's gather stream
     const void* src_audio = nullptr;

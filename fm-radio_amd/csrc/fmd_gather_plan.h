@@ -110,13 +110,16 @@ struct Sync {
 };
 
 // A handle's block numbering against the gather's: fmd_outputs_block counts since fmd_create / fmd_reset, the gather since
-// fmd_gather_create.  base = the handle's block count when the gather was created; a handle whose numbering goes BACK was reset, and
-// its first block after the reset re-bases.  Returns the gather-relative block of handle block `blk`.
+// fmd_gather_create.  base = the handle's block count when the gather was created.  The numbering restarts ONLY when the handle says so
+// (fmd_outputs_epoch changes: fmd_reset), and then the first block after the restart — the handle's block 0 — is the gather's next one.
+// Returns the gather-relative block of handle block `blk`; anything but expect_k is the caller's error to report: a second submit without a
+// new block (blk == last), a skipped block, a handle under fmd_set_output_lag (its views are the block before: -1, then k - 1).
+// (Round 5 inferred a restart from blk <= last, which also "re-based" exactly those repeated and lagged submits — ADVICE r5.)
 struct BlockBase {
-    long base = 0, last = -1;
-    void start(long outputs_block_at_create) { base = outputs_block_at_create + 1; last = outputs_block_at_create; }
-    long relative(long blk, long expect_k) {
-        if (blk <= last) base = blk - expect_k;      // fmd_reset since the last submit: the numbering restarted (it only ever grows otherwise)
+    long base = 0, last = -1, epoch = 0;
+    void start(long outputs_block_at_create, long epoch_at_create = 0) { base = outputs_block_at_create + 1; last = outputs_block_at_create; epoch = epoch_at_create; }
+    long relative(long blk, long epoch_now, long expect_k) {
+        if (epoch_now != epoch) { epoch = epoch_now; base = -expect_k; }      // restarted: the handle's block 0 is the gather's block expect_k
         last = blk;
         return blk - base;
     }

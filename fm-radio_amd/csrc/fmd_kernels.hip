@@ -136,6 +136,39 @@ __device__ __forceinline__ float4 load_iq2(const uchar2* p, size_t i) {
     return make_float4((float)v.x - 127.0f, (float)v.y - 127.0f, (float)v.z - 127.0f, (float)v.w - 127.0f);
 }
 
+// Stream-once traffic (the capture's samples, the audio frames): non-temporal accesses, so that the lines do not displace the planes the
+// kernels hand each other through L2 / the Infinity Cache (fo_pl, pv_pl).  A/B switches of the development builds: -DFMD_NT_IN=0 / -DFMD_NT_OUT=0.
+#ifndef FMD_NT_IN
+#define FMD_NT_IN 1
+#endif
+#ifndef FMD_NT_OUT
+#define FMD_NT_OUT 1
+#endif
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef float nt_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+#if FMD_NT_IN
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p)); return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ uint4 ld_stream(const uint4* p) {
+#if FMD_NT_IN
+    const nt_u4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u4*>(p)); return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream(float4* p, const float4& v) {
+#if FMD_NT_OUT
+    __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f4*>(p));
+#else
+    *p = v;
+#endif
+}
+
 template <typename InT, int TT = 512>
 __global__ __launch_bounds__(256) void k_front(Dims d, const InT* __restrict__ in, const float2* __restrict__ tail_in,
                                                float2* __restrict__ tail_out, float2* __restrict__ fm_out_iq,
@@ -501,7 +534,7 @@ __global__ __launch_bounds__(256, FUSED ? 6 : 5) void k_front_mfma(Dims d, const
             const float4* src = reinterpret_cast<const float4*>(in_c + (g_lo - 1));
             float4 qb[PERQ]; float2 rb[PERR];
 #pragma unroll
-            for (int r = 0; r < PERQ; r++) qb[r] = src[tid + 256 * r];
+            for (int r = 0; r < PERQ; r++) qb[r] = ld_stream(src + tid + 256 * r);
 #pragma unroll
             for (int r = 0; r < PERR; r++) { const int i = REST0 + tid + 256 * r; if (i < NW) rb[r] = load_iq(in_c, (unsigned)(g_lo + i)); }
 #pragma unroll
@@ -525,7 +558,7 @@ __global__ __launch_bounds__(256, FUSED ? 6 : 5) void k_front_mfma(Dims d, const
             const uint4* src = reinterpret_cast<const uint4*>(in_c + (g_lo - 1));
             uint4 ob[PERO]; float2 rb[PERR];
 #pragma unroll
-            for (int r = 0; r < PERO; r++) ob[r] = src[tid + 256 * r];
+            for (int r = 0; r < PERO; r++) ob[r] = ld_stream(src + tid + 256 * r);
 #pragma unroll
             for (int r = 0; r < PERR; r++) { const int i = REST0 + tid + 256 * r; if (i < NW) rb[r] = load_iq(in_c, (unsigned)(g_lo + i)); }
 #pragma unroll
@@ -915,8 +948,8 @@ __global__ __launch_bounds__(256, (FUSED ? FrontPreGeom<M, sizeof(InT) == 2>::MI
         if (j < ITEMS) {
             int g = gs + IS * j;
             g = g < -G::HIST ? -G::HIST : (g < d.N - IS ? g : d.N - IS);
-            if constexpr (!U8) buf[r] = (g < 0) ? *reinterpret_cast<const uint4*>(ptail_c + (G::HIST + g)) : *reinterpret_cast<const uint4*>(in_c + g);
-            else if (g >= 0) buf[r] = *reinterpret_cast<const uint4*>(in_c + g);
+            if constexpr (!U8) buf[r] = (g < 0) ? *reinterpret_cast<const uint4*>(ptail_c + (G::HIST + g)) : ld_stream(reinterpret_cast<const uint4*>(in_c + g));
+            else if (g >= 0) buf[r] = ld_stream(reinterpret_cast<const uint4*>(in_c + g));
         }
     };
     auto convert1 = [&](int gs, int r) {
@@ -2851,10 +2884,14 @@ static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
         // a workgroup = station x 4 nt tiles, nt per wavefront (the station's tap tables are staged once per workgroup): the largest nt that
         // still leaves 1536 workgroups for the chip (4 per CU: a round and a half)
         int nt = 1;
-        for (int v = (tiles + 3) / 4; v >= 1; v--) if ((long)((tiles + 4 * v - 1) / (4 * v)) * d.C >= 1536) { nt = v; break; }
-        if (const char* e = dev_env("FMD_BP_NT")) { const int v = atoi(e); if (v > 0 && v <= 255) nt = v; }      // (development A/B)
-        if (dev_env("FMD_BP_NOEDGE")) nt |= 0x100;                       // (development, timing only: the first tile's sums over the previous block skipped)
-        FMD_LAUNCH(r, true, true, k_extract_bp, dim3((unsigned)((tiles + 4 * (nt & 0xff) - 1) / (4 * (nt & 0xff)) * d.C)), dim3(TA), 0, s, d, nt, b.fo_pl[r.buf], b.pll_poly[r.buf],
+        // (nt travels in the low 16 bits of one kernel argument, the development switch in bit 16: block_size has no cap, so the search is
+        //  clamped — ADVICE r5: at 8 bits a block of a million samples could wrap nt to 0)
+        constexpr int kNtMax = 0x7fff;
+        for (int v = (tiles + 3) / 4 < kNtMax ? (tiles + 3) / 4 : kNtMax; v >= 1; v--) if ((long)((tiles + 4 * v - 1) / (4 * v)) * d.C >= 1536) { nt = v; break; }
+        if (const char* e = dev_env("FMD_BP_NT")) { const int v = atoi(e); if (v > 0 && v <= kNtMax) nt = v; }      // (development A/B)
+        const int grid_x = (tiles + 4 * nt - 1) / (4 * nt) * d.C;
+        if (dev_env("FMD_BP_NOEDGE")) nt |= 0x10000;                     // (development, timing only: the first tile's sums over the previous block skipped)
+        FMD_LAUNCH(r, true, true, k_extract_bp, dim3((unsigned)grid_x), dim3(TA), 0, s, d, nt, b.fo_pl[r.buf], b.pll_poly[r.buf],
                    b.bp_tab, b.aud_idx, b.rds_bp_tab, b.bp_edge, b.mix,
                    b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est[r.par], b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps,
                    lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr, lmr_field(r.par), lmr_field(r.par ^ 1), b.rds_pow[r.buf]);

@@ -215,6 +215,9 @@ int fmd_set_output_lag(fmd_handle h, int on);
  * (Under fmd_set_output_lag(h, 1) a consumer needs it to tell k from k - 1: batches below the size named above, and the exact mode,
  * queue every block's stages at submission.) */
 int fmd_outputs_block(fmd_handle h, long* block);
+/* how often the handle's block numbering has restarted (fmd_create counts as the first start; every fmd_reset restarts it): a consumer
+ * that follows fmd_outputs_block across resets — the multi-GPU gather does — tells a restart from a repeated or skipped block by it */
+int fmd_outputs_epoch(fmd_handle h, long* epoch);
 /* The consumer's side of the lifetime rule: everything queued on `stream` so far (the kernels / copies that read the newest
  * block's output views) must finish before the library overwrites those views, however many blocks are submitted meanwhile.
  * Records an event on `stream`; the library's writers of that buffer slot wait for it on the device.  Never blocks the host. */

@@ -47,6 +47,7 @@ typedef struct {
 /* handles: [n_ranks] demodulators with the SAME n_channels, block_size and fs_baseband (equal shards: pad the last one with idle
  * stations), handles[r] living on devices[r].  Collective over nothing: called once, by any thread, before the rank threads start. */
 int fmd_gather_create(const fmd_gather_config* cfg, const fmd_handle* handles, fmd_gather* out);
+/* after every rank thread has left the library (see fmd_gather_abort) */
 int fmd_gather_destroy(fmd_gather g);
 
 /* Rank `rank`'s thread, after it has submitted a block to handles[rank] (fmd_submit_*_dev / fmd_process_*_dev): queue the rank's part
@@ -64,9 +65,11 @@ int fmd_gather_wait(fmd_gather g, const void** d_audio, const uint8_t** d_rds_by
 
 /* which rank collects block `block` (0 = the first since fmd_gather_create) and on which device fmd_gather_wait's views of it live */
 int fmd_gather_collector(fmd_gather g, long block, int* rank, int* device);
-/* Give up: every fmd_gather_submit / fmd_gather_wait that is waiting on the host (for a rank that will never submit, for views that will
- * never be given back) returns FMD_ERR_STATE, now and from here on, and the communicators are aborted so that a receive whose sender is
- * gone completes.  For a host whose rank thread failed (fm-radio_amd/host/multi_gpu_host.hpp).  Any thread. */
+/* Give up, HOST SIDE ONLY: every fmd_gather_submit / fmd_gather_wait that is waiting on the host (for a rank that will never submit, for
+ * views that will never be given back) returns FMD_ERR_STATE, now and from here on.  It does not touch the communicators: a rank thread
+ * may be inside ncclSend / ncclRecv right now, and ncclCommAbort frees what that call uses.  The communicators are aborted by
+ * fmd_gather_destroy — so that a receive whose sender is gone completes and its stream can be drained — which therefore must run AFTER
+ * every rank thread has left the library (join them first; fm-radio_amd/host/multi_gpu_host.hpp does).  Any thread. */
 int fmd_gather_abort(fmd_gather g);
 
 /* bytes one block moves into the collector from the other GPUs (for sizing against the 7 x ~153 GB/s of xGMI ingress) */

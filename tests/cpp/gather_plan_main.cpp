@@ -71,14 +71,29 @@ static int test_plan() {
         Plan t; CHECK(!t.init(1, one, 1, 0).empty() && !t.init(0, one, 0, 0).empty() && !t.init(1, one, 0, 64).empty());
         Plan u; CHECK(u.init(1, one, 0, kRotate).empty() && !u.rotate);                           // one rank: nothing to rotate
     }
-    {   // a handle's block numbering against the gather's
-        BlockBase b; b.start(-1);                     // fresh handle
-        CHECK(b.relative(0, 0) == 0 && b.relative(1, 1) == 1);
-        BlockBase c; c.start(4);                      // five blocks of pre-roll before the gather existed
-        CHECK(c.relative(5, 0) == 0 && c.relative(6, 1) == 1);
-        CHECK(c.relative(0, 2) == 2 && c.relative(1, 3) == 3);            // fmd_reset in between: the numbering restarted, the first block re-bases
-        BlockBase e; e.start(-1);
-        CHECK(e.relative(0, 0) == 0 && e.relative(2, 1) == 2);            // a skipped block is NOT the gather's block 1: reported to the caller
+    {   // a handle's block numbering against the gather's (epoch = fmd_outputs_epoch: changes only with fmd_reset)
+        BlockBase b; b.start(-1, 1);                  // fresh handle
+        CHECK(b.relative(0, 1, 0) == 0 && b.relative(1, 1, 1) == 1);
+        BlockBase c; c.start(4, 1);                   // five blocks of pre-roll before the gather existed
+        CHECK(c.relative(5, 1, 0) == 0 && c.relative(6, 1, 1) == 1);
+        CHECK(c.relative(0, 2, 2) == 2 && c.relative(1, 2, 3) == 3);      // fmd_reset in between: the numbering restarted, the first block re-bases
+        BlockBase e; e.start(-1, 1);
+        CHECK(e.relative(0, 1, 0) == 0 && e.relative(2, 1, 1) == 2);      // a skipped block is NOT the gather's block 1: reported to the caller
+        // a second submit without a new block must NOT pass as a restart (it did while blk <= last meant "reset")
+        BlockBase f; f.start(-1, 1);
+        CHECK(f.relative(0, 1, 0) == 0);
+        CHECK(f.relative(0, 1, 1) != 1);              // the same block again: refused
+        CHECK(f.relative(1, 1, 1) == 1);              // ... and the gather carries on with the right one
+        // a handle under fmd_set_output_lag shows no block, then the block before: neither is the gather's block
+        BlockBase l; l.start(-1, 1);
+        CHECK(l.relative(-1, 1, 0) != 0);
+        CHECK(l.relative(0, 1, 1) != 1);
+        // a reset followed by TWO blocks before the next submit: a skipped block, not a restart at the second one
+        BlockBase r; r.start(-1, 1);
+        CHECK(r.relative(0, 1, 0) == 0 && r.relative(1, 2, 1) != 1);
+        // a reset before the gather's first submit
+        BlockBase q; q.start(7, 3);
+        CHECK(q.relative(0, 4, 0) == 0 && q.relative(1, 4, 1) == 1);
     }
     return fails;
 }

@@ -126,6 +126,17 @@ def test_the_other_kernel_forms_match_the_float64_definition(pkg, fs_out, tpp, f
         assert y.shape[1] == ref.size
         err = np.abs(y[k] - ref).max() / np.abs(ref).max()
         assert err < 2e-5, (form, k, err)
+    # streamed (only the matrix-core form had its history hand-over checked across calls): the same capture in several
+    # calls — uneven ones, and then the SHORTEST legal calls (one M-sample step of the rate pair, shorter than the T - 1 samples of
+    # history, so a call's window lies in the history buffer and the block at once) — must give the one-shot result
+    unit = M * (16 // int(np.gcd(16, L)))                # samples per whole number of outputs (and of 16-output groups where L = 16)
+    for cuts in ([0, 3 * unit, 4 * unit, n_in], list(range(0, n_in + 1, unit))):
+        ch.reset()
+        outs = [ch.process(xt[a:b].contiguous()).clone() for a, b in zip(cuts[:-1], cuts[1:])]
+        ys = torch.cat(outs, dim=1).cpu().numpy()
+        ys = ys[..., 0] + 1j * ys[..., 1]
+        assert ys.shape == y.shape
+        assert np.abs(ys - y).max() <= 5e-6 * np.abs(y).max(), (form, len(cuts))
     ch.close()
 
 
