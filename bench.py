@@ -58,6 +58,47 @@ def algorithmic_bytes_per_sample(fs: int, u8: bool) -> float:
 
 
 SIDE_QUEUE_KERNELS = ("k_rds_sync", "k_pll_sparse", "k_pll_span", "k_lmr_phase")
+HBM_RIDGE_FLOP_PER_BYTE = 157.3e12 / 8.0e12     # fp32 vector peak over the HBM peak: above it a chain's algorithmic work is compute-bound
+
+
+def kernel_source_stamp() -> str:
+    """sha256 (first 16 hex digits) over the library's kernel and host sources: what ties a row of the committed PMC tables
+    (profiles/hbm_traffic.json `_meta.kernel_source_stamp`, written by tools/digest_round.py --install) to the build it was measured on.
+    (A git hash would do in the build container; the GPU box's snapshot has no .git.)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = ROOT / "fm-radio_amd" / "csrc"
+    for f in sorted(list(d.glob("*.hip")) + list(d.glob("*.inc")) + list(d.glob("*.h")) + list(d.glob("*.cpp"))):
+        h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def traffic_meta() -> dict:
+    try:
+        return json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text()).get("_meta", {})
+    except Exception:
+        return {}
+
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 on the matrix cores (the headline figure with 2:1 sparsity is not priced against)
+
+
+def roof_sides(fs: int, u8: bool, samples: float, seconds: float) -> dict:
+    """Both roofs on ALGORITHMIC work done in `seconds`: HBM bytes against 8 TB/s, and the chain's flops.
+    The flops are almost all FIR taps; the tolerance mode runs every FIR on the matrix cores as three bf16 products per fp32 product, so the
+    compute roof that applies to them is the bf16 MFMA peak / 3 (833 TFLOP/s of fp32-equivalent work, ridge 104 flop/B), not the fp32
+    VECTOR peak (157.3 TFLOP/s, ridge 19.7 flop/B) — which configs[2]'s 42.6 flop/B exceeds and which the measured step
+    therefore exceeds too on algorithmic flops (`fp32_vector.frac` > 1 at 1.024 MSa/s).  `bound` names the side the intensity puts the
+    configuration under on the pipe its flops run on; all three fractions are printed."""
+    bps, fps = algorithmic_bytes_per_sample(fs, u8), algorithmic_flops_per_sample(fs)
+    hbm = {"achieved": bps * samples / seconds / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    vec = {"achieved": fps * samples / seconds / 1e12, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s"}
+    mfma = {"achieved": fps * samples / seconds / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s (fp32 work as 3 bf16 products)"}
+    for o in (hbm, vec, mfma):
+        o["frac"] = o["achieved"] / o["peak"]
+    ridge_mfma = MFMA_BF16_PEAK_TFLOPS / 3.0 * 1e12 / (HBM_PEAK_GBS * 1e9)
+    return {"flop_per_byte": fps / bps, "ridge_fp32_vector": HBM_RIDGE_FLOP_PER_BYTE, "ridge_mfma_bf16x3": ridge_mfma,
+            "bound": "mfma" if fps / bps > ridge_mfma else "hbm", "hbm": hbm, "fp32_vector": vec, "mfma_bf16x3": mfma}
 
 
 def lookup_traffic(kernel: str, C: int, fs: int, block: int, u8: bool, fast: bool):
@@ -363,8 +404,11 @@ def measure_config(torch, pkg, device, label: str, C: int, fs: int, u8: bool, fa
     return {"config": label, "channels": C, "fs_baseband": fs, "block_size": block, "ingest": "u8" if u8 else "cf32",
             "mode": MODE_TEXT[fast], "steps": steps, "ms_per_step": el / steps * 1e3, "value": value, "unit": "MSa/s",
             "channels_at_realtime": value * 1e6 / fs, "algorithmic_bytes_per_sample": bps,
-            "roofline": {"kernel": dom[0], "avg_launch_ms": dom[1], "frac": (bps * C * block / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom[1] else None,
+            "roofline": {"bound": roof_sides(fs, u8, 1.0, 1.0)["bound"], "flop_per_byte": roof_sides(fs, u8, 1.0, 1.0)["flop_per_byte"],
+                         "kernel": dom[0], "avg_launch_ms": dom[1], "frac": (bps * C * block / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom[1] else None,
+                         "frac_fp32_vector": (algorithmic_flops_per_sample(fs) * C * block / (dom[1] * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS) if dom[1] else None,
                          "whole_step_frac": bps * value * 1e6 / 1e9 / HBM_PEAK_GBS,
+                         "whole_step_frac_fp32_vector": algorithmic_flops_per_sample(fs) * value * 1e6 / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
                          "traffic": chain_traffic(C, fs, block, u8, fast)[0],       # the chain's HBM bytes per step (committed PMC table), None if not profiled
                          "traffic_ratio": (lambda t: None if t is None else t / (bps * C * block))(chain_traffic(C, fs, block, u8, fast)[0]),
                          "kernels_ms_per_step": kt}}
@@ -642,16 +686,31 @@ def main() -> None:
                             "cycles_per_instruction_assumed": 4.0, "frac_at_probe_rate_2p75": vt / (1024 * clk / 2.75 * el / K)}
             except Exception:
                 valu = None
-        roofline = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS,
+        # Which roof: roof_sides() — configs[2] asks 385 flop for 9.04 B per sample = 42.6 flop/B: above the fp32 VECTOR
+        # ridge (19.7), below the ridge of the matrix cores its FIRs run on (104): `bound` names the side, `achieved / peak / unit / frac` are that
+        # side's for the dominant kernel's launch, every side is printed beside it (and for the whole step in `whole_step`).
+        sides = roof_sides(fs, args.u8, C * block, avg_ms * 1e-3)
+        step_sides = roof_sides(fs, args.u8, C * block * K, el) if world == 1 else None
+        side = sides[sides["bound"]]
+        meta = traffic_meta()
+        stamp = kernel_source_stamp()
+        roofline = {"bound": sides["bound"], "kernel": dom[0], "achieved": side["achieved"], "peak": side["peak"], "unit": side["unit"],
+                    "frac": side["frac"],
+                    # the longest launch of the step whatever its queue (the serial RDS stage runs beside the throughput kernels on a queue of its own)
+                    "kernel_longest": None if longest is None else {"kernel": longest, "avg_launch_ms": all_avg[longest],
+                                                                    "frac_hbm": algo_bytes / (all_avg[longest] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                    "flop_per_byte": sides["flop_per_byte"], "ridge_fp32_vector": sides["ridge_fp32_vector"], "ridge_mfma_bf16x3": sides["ridge_mfma_bf16x3"],
+                    "hbm": sides["hbm"], "fp32_vector": sides["fp32_vector"], "mfma_bf16x3": sides["mfma_bf16x3"],
+                    "whole_step": None if step_sides is None else {"hbm_frac": step_sides["hbm"]["frac"], "fp32_vector_frac": step_sides["fp32_vector"]["frac"],
+                                                                   "mfma_bf16x3_frac": step_sides["mfma_bf16x3"]["frac"]},
                     # HBM bytes one step really moves: the CHAIN's (every kernel of a steady block), beside the algorithmic bytes `achieved` is made of
                     "traffic": traffic, "traffic_ratio": None if traffic is None else traffic / algo_bytes,
                     "traffic_per_kernel": traffic_per_kernel, "traffic_dominant_kernel": traffic_dom,
                     "traffic_source": None if traffic is None else "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                       "configuration (tools/collect_round.sh), committed; not re-measured by this run",
-                    # the longest launch of the step whatever its queue (the serial RDS stage runs beside the two throughput kernels on a queue of its own)
-                    "kernel_longest": None if longest is None else {"kernel": longest, "avg_launch_ms": all_avg[longest],
-                                                                    "frac": algo_bytes / (all_avg[longest] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                    # the table's rows were measured on the library whose sources hash to `traffic_measured_on`; this run's library: `kernel_source_stamp`
+                    "traffic_measured_on": meta.get("kernel_source_stamp"), "kernel_source_stamp": stamp,
+                    "traffic_stale": None if traffic is None else (meta.get("kernel_source_stamp") != stamp),
                     "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_launch": algo_bytes,
                     "whole_step_frac": (bps * C * block * K / el / 1e9) / HBM_PEAK_GBS if world == 1 else None,
@@ -743,10 +802,19 @@ def main() -> None:
         torch.cuda.empty_cache()
         if not args.no_host_fed:
             out["host_fed_u8"] = host_fed_line(C, block, fs, args.fast_math)
-        out["cpu_baseline"] = cpu_baseline(fs, block)
+        # cpu_baseline: the REAL reference (oracle/_ref/fm_demod_benchmark, prebuilt from the reference's own sources) on the box's host
+        # cores, on its native workload — 1.024 MSa/s u8 captures, one single-threaded demodulator per physical core;
+        # cpu_port: the oracle's scalar restatement at THIS run's rate and format (`kind: port`), which is what cpu_baseline was through
+        # round 5 and still is where the reference binary did not travel
+        port = cpu_baseline(fs, block)
         ref = cpu_reference()
         if ref is not None:
-            out["cpu_reference_1024k"] = ref
+            ref["workload_note"] = ("the reference has one rate and one capture format (Fs_baseband = 1 024 000, u8: src/app.cpp:56-65, "
+                                    "broadcast_fm_demod.cpp:68); its MSa/s are baseband samples of THAT workload, four per 256 kSa/s sample of configs[2]")
+            out["cpu_baseline"] = ref
+            out["cpu_port"] = port
+        else:
+            out["cpu_baseline"] = port
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

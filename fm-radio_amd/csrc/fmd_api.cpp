@@ -1086,6 +1086,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
         if (!rc) rc = dev_alloc(h, &b.audio[p], C * d.n_audio * 2);
         if (!rc) rc = dev_alloc(h, &b.rds_sym[p], C * d.n_rds);
         if (!rc) rc = dev_alloc(h, &b.rds_raw_sym[p], h->ctx.keep_taps ? C * d.n_rds : 4);
+        if (!rc && !fast && h->ctx.keep_taps) rc = dev_alloc(h, &b.taps[p], tap_floats(d));
         if (!rc) rc = dev_alloc(h, &b.rds_count[p], C);
         if (!rc) rc = dev_alloc(h, &b.lpr[p], h->ctx.keep_taps ? C * d.n_audio : 4);
         if (!rc) rc = dev_alloc(h, &b.lmr[p], h->ctx.keep_taps ? C * d.n_audio : 4);
@@ -1142,7 +1143,8 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     // per-wavefront hand-over between consecutive k_pilot_pll launches: the time-parallel kernel only, pipelined mode only
     // (the low-work kernel k_pilot_pll_pairs has no chain argument: its launches must stay ordered by the stream)
     const bool time_parallel = d.C <= h->ctx.pll_time_parallel_max_channels;
-    h->pll_chained = h->pipelined && !h->ctx.fast && time_parallel && effective_channels(d) <= 3328 && !(cfg->flags & (FMD_FLAG_PLL_STREAM_ORDER | FMD_FLAG_PLL_LOW_WORK));
+    // (FMD_FLAG_KEEP_TAPS: k_pll_taps reads the loop's start state ahead of the PLL kernel — consecutive blocks' launches stay in stream order)
+    h->pll_chained = h->pipelined && !h->ctx.fast && !h->ctx.keep_taps && time_parallel && effective_channels(d) <= 3328 && !(cfg->flags & (FMD_FLAG_PLL_STREAM_ORDER | FMD_FLAG_PLL_LOW_WORK));
     h->pll_waves = (effective_channels(d) <= h->ctx.pll_k16_max_channels) ? (d.C + 3) / 4 : (d.C + 7) / 8;
     if (!rc) rc = dev_alloc(h, &b.pll_chain, (size_t)h->pll_waves + 1);
     if (rc) return bail(rc);
@@ -1392,6 +1394,27 @@ int fmd_get_stream(fmd_handle h, const char* name, float* out, size_t cap_floats
     else if (s == "lpr" && keep) { p = b.lpr[o]; n = C * d.n_audio; }
     else if (s == "lmr" && keep) { p = b.lmr[o]; n = C * d.n_audio; }
     else if (s == "rds_raw_sym" && keep) { p = b.rds_raw_sym[o]; n = 2 * C * d.n_rds; }
+    else if (s == "pilot" || s == "pll" || s == "pll_raw_err" || s == "pll_pi_err" || s.rfind("bpsk_", 0) == 0) {
+        // reference GetPilotOutput / GetPLLOutput / Get_PLL_Raw_Phase_Error_Output / Get_PLL_LPF_Phase_Error_Output (broadcast_fm_demod.h:245-248),
+        // BPSK_Synchroniser::Get* (bpsk_synchroniser.h:78-85): per-sample traces of the two loops, kept by the exact mode's kernels on request
+        const TapPtrs t = tap_ptrs(h->ctx, o);
+        if (!t.pilot) return fail(h, FMD_ERR_NAME, "stream '%s' needs FMD_FLAG_KEEP_TAPS in the exact mode (the tolerance mode's loops run at eight points per span / on "
+                                                   "groups of four samples: they have no per-sample trace)", name);
+        const size_t nf = C * d.n_fm_out, nr = C * d.n_rds;
+        if (s == "pilot") { p = t.pilot; n = 2 * nf; }
+        else if (s == "pll") { p = t.pll; n = 2 * nf; }
+        else if (s == "pll_raw_err") { p = t.pll_raw; n = nf; }
+        else if (s == "pll_pi_err") { p = t.pll_pi; n = nf; }
+        else if (s == "bpsk_pll_sym") { p = t.b_pll_sym; n = 2 * nr; }
+        else if (s == "bpsk_intdump") { p = t.b_intdump; n = 2 * nr; }
+        else if (s == "bpsk_ted_raw") { p = t.b_ted_raw; n = nr; }
+        else if (s == "bpsk_ted_pi") { p = t.b_ted_pi; n = nr; }
+        else if (s == "bpsk_pll_raw") { p = t.b_pll_raw; n = nr; }
+        else if (s == "bpsk_pll_pi") { p = t.b_pll_pi; n = nr; }
+        else if (s == "bpsk_zcd") { p = t.b_zcd; n = nr; }
+        else if (s == "bpsk_trig") { p = t.b_trig; n = nr; }
+        else return fail(h, FMD_ERR_NAME, "unknown stream '%s'", name);
+    }
     else if (s == "lmr_phase") { lmr_peek = true; p = b.lmr_peek; n = C; }
     else if (s == "agc_pilot_gain") { from_state = true; field = S_AGC_PILOT_GAIN; }
     else if (s == "agc_rds_gain") { from_state = true; field = S_AGC_RDS_GAIN; }

@@ -156,6 +156,12 @@ static_assert(kSlots <= 8, "one S_PILOT_POWER state field per slot");
 // 0: plain stream order
 // warm: tolerance mode, a block inside some station's first kPllWarmSamples after a reset / a restored start-up state: k_pll_span runs
 // beside k_pll_sparse and each station takes the result of the one in charge of it
+// FMD_FLAG_KEEP_TAPS in the exact mode: the traces behind the reference's GetPilotOutput / GetPLLOutput / Get_PLL_Raw_Phase_Error_Output /
+// Get_PLL_LPF_Phase_Error_Output (broadcast_fm_demod.h:245-248) and BPSK_Synchroniser's Get* views (bpsk_synchroniser.h:78-85); all null otherwise
+struct TapPtrs {
+    float2* pilot; float2* pll; float* pll_raw; float* pll_pi;                                     // [C][n_fm_out]
+    float2* b_pll_sym; float2* b_intdump; float* b_ted_raw; float* b_ted_pi; float* b_pll_raw; float* b_pll_pi; float* b_zcd; float* b_trig;   // [C][n_rds]
+};
 struct SlotRef { int buf; int par; hipEvent_t t0 = nullptr; hipEvent_t t1 = nullptr; hipEvent_t done = nullptr; unsigned seq = 0; int warm = 0; };
 struct Buffers {
     // history tails: stage of block b reads [par], writes [par^1] (producer and consumer are the same stage, same stream)
@@ -177,6 +183,7 @@ struct Buffers {
     float*  audio[kSlots];       // [C][n_audio][2]
     float*  rds_sym[kSlots];     // [C][n_rds]
     float2* rds_raw_sym[kSlots]; // [C][n_rds]      (KEEP_TAPS)
+    float*  taps[kSlots];        // exact mode + KEEP_TAPS: the loops' per-sample traces, one allocation per slot (tap_ptrs() for the layout)
     int*    rds_count[kSlots];   // [C]
     float*  lpr[kSlots];         // [C][n_audio]    (KEEP_TAPS)
     float*  lmr[kSlots];         // [C][n_audio]    (KEEP_TAPS)
@@ -226,6 +233,28 @@ struct LaunchCtx {
     int pll_k16_max_channels;             // (channels x m) up to this: 16 lanes per channel, above: 8
 };
 
+// where a slot's traces lie inside Buffers::taps[buf] (null pointers when the handle keeps none)
+inline TapPtrs tap_ptrs(const LaunchCtx& ctx, int buf) {
+    TapPtrs t{};
+    float* p = ctx.b.taps[buf];
+    if (!p) return t;
+    const size_t nf = (size_t)ctx.d.C * ctx.d.n_fm_out, nr = (size_t)ctx.d.C * ctx.d.n_rds;
+    t.pilot = reinterpret_cast<float2*>(p); p += 2 * nf;
+    t.pll = reinterpret_cast<float2*>(p); p += 2 * nf;
+    t.pll_raw = p; p += nf;
+    t.pll_pi = p; p += nf;
+    t.b_pll_sym = reinterpret_cast<float2*>(p); p += 2 * nr;
+    t.b_intdump = reinterpret_cast<float2*>(p); p += 2 * nr;
+    t.b_ted_raw = p; p += nr;
+    t.b_ted_pi = p; p += nr;
+    t.b_pll_raw = p; p += nr;
+    t.b_pll_pi = p; p += nr;
+    t.b_zcd = p; p += nr;
+    t.b_trig = p;
+    return t;
+}
+inline size_t tap_floats(const Dims& d) { return (size_t)d.C * (6 * (size_t)d.n_fm_out + 10 * (size_t)d.n_rds); }
+
 // One launcher per pipeline stage of one block.  The host (fmd_api.cpp) places the stages on
 // streams and orders them with events.
 hipError_t launch_stage_predecim(const LaunchCtx& ctx, SlotRef r, const void* d_iq, bool u8, hipStream_t s);   // k_predecim (m > 1)
@@ -236,6 +265,8 @@ hipError_t launch_stage_deemph(const LaunchCtx& ctx, SlotRef r, hipStream_t s); 
 hipError_t launch_stage_power(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                             // k_pilot_power
 hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                               // k_pilot_pll
 hipError_t launch_stage_extract(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                           // k_extract
+bool chain_possible(const LaunchCtx& ctx);                                                                 // tolerance mode, 256 kSa/s cf32: front end + pilot + extract as one launch
+hipError_t launch_stage_chain(const LaunchCtx& ctx, SlotRef r, const void* d_iq, hipStream_t s);              // k_chain (fmd_kernels_chain.inc)
 hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s);                               // k_rds_sync
 hipError_t launch_lmr_phase_peek(const LaunchCtx& ctx, int par, float* out_row, hipStream_t s);            // k_lmr_phase into a scratch row
 hipError_t launch_reset_state(const LaunchCtx& ctx, hipStream_t stream);

@@ -1198,6 +1198,48 @@ __device__ __forceinline__ float pll_step(PllState& s, float p, float q, const L
     return s.tph;
 }
 
+// FMD_FLAG_KEEP_TAPS, exact mode: the loop's per-sample traces behind the reference's GetPilotOutput (the pilot after its AGC),
+// GetPLLOutput (the NCO's (cos, sin)), Get_PLL_Raw_Phase_Error_Output and Get_PLL_LPF_Phase_Error_Output (broadcast_fm_demod.h:245-248;
+// what the oracle keeps at fm_oracle.c lock_onto_pilot).  The time-parallel kernels below commit only the NCO phase; this is the plain
+// reference iteration once more, lane per station, ahead of them on the same stream from the same start state (it writes no state).
+// A getter's kernel: uncoalesced by design, launched only for handles that asked for the traces.
+__global__ __launch_bounds__(kWave) void k_pll_taps(Dims d, const float2* __restrict__ pilot, const float* __restrict__ state, LoopCoeffs k, int power_field, TapPtrs t) {
+    const int c = blockIdx.x * kWave + threadIdx.x;
+    if (c >= d.C) return;
+    const int n = d.n_fm_out;
+    float gain = state[(size_t)S_AGC_PILOT_GAIN * d.C + c];
+    {   // AGC_Filter::process (agc.h:12-19) as k_pilot_pll computes it
+        const float sum = state[(size_t)power_field * d.C + c];
+        const float target_gain = sqrtf((1.0f / sum) * (float)n);
+        gain = fmaf(target_gain - gain, 0.2f, gain);
+    }
+    PllState S{state[(size_t)S_PLL_X1 * d.C + c], state[(size_t)S_PLL_Y1 * d.C + c], state[(size_t)S_PLL_INT * d.C + c], state[(size_t)S_PLL_ERR * d.C + c],
+               state[(size_t)S_PLL_T * d.C + c]};
+    const float Ts = 1.0f / 128000.0f, KTsI = 0.1f * Ts;
+    for (int i = 0; i < n; i++) {
+        const float2 x = pilot[(size_t)c * n + i];
+        const float p = gain * x.x, q = gain * x.y;
+        // (pll_step, with what it computes on the way kept)
+        const float t0 = fmaf(S.lx1, k.pll_b0, S.ly1 * k.pll_a0);
+        const float t1 = fmaf(S.err, k.pll_b1, 0.0f);
+        const float lpf = (0.0f + t0) + t1;
+        S.lx1 = S.err; S.ly1 = lpf;
+        const float P = lpf * 0.01f;
+        S.integ = clampf(fmaf(S.err, KTsI, S.integ), -1.0f, 1.0f);
+        const float PI_error = S.integ + P;
+        const float control = clampf(PI_error * 1.0f, -1.0f, 1.0f);
+        const float freq = fmaf(control, -100.0f, -19000.0f);
+        const float yy = fmaf(freq, Ts, S.tph);
+        S.tph = yy - round_half_away(yy);
+        float dt_cos = S.tph + 0.25f;
+        dt_cos = dt_cos - round_half_away(dt_cos);
+        const float ps = cheb_sine_scalar(S.tph), pc = cheb_sine_scalar(dt_cos);
+        S.err = fmd_atan2f(fmaf(ps, p, q * pc), fmaf(p, pc, -(q * ps)));
+        const size_t o = (size_t)c * n + i;
+        t.pilot[o] = make_float2(p, q); t.pll[o] = make_float2(pc, ps); t.pll_raw[o] = S.err; t.pll_pi[o] = PI_error;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // k_pilot_pll — frequency-speculative, time-parallel evaluation of the pilot PLL.
 //
@@ -2082,6 +2124,7 @@ __device__ unsigned long long g_x_probe2[16];
 #endif
 
 #include "fmd_kernels_bp.inc"
+#include "fmd_kernels_chain.inc"
 
 // Tolerance mode, FMD_FLAG_KEEP_TAPS (the "fm_out_iq" getter) and block lengths whose audio blocks are not multiples of 256 (those run
 // k_extract<128, true> on the interleaved stream, with the history tails it keeps for itself): the analytic signal from the fm_out plane,
@@ -2161,7 +2204,7 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
                                                         float* __restrict__ state, LoopCoeffs k, float* __restrict__ rds_sym,
                                                         float2* __restrict__ rds_raw_sym, int* __restrict__ rds_count,
                                                         uint8_t* __restrict__ rds_bytes, int* __restrict__ rds_bytes_count,
-                                                        int bytes_cap, int keep_taps, const float* __restrict__ rds_pow, int n_pow) {
+                                                        int bytes_cap, int keep_taps, const float* __restrict__ rds_pow, int n_pow, TapPtrs taps) {
     // Tolerance mode: two ring slots instead of four (the loader keeps two chunks in registers beyond the one it stores: 7 us of
     // look-ahead are enough): 43 KB of LDS instead of 78 on the 64 CUs this kernel's workgroups sit on for most of a block's time —
     // the extract stage gets three workgroups beside it there instead of two
@@ -2440,7 +2483,8 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
                 const float dd = cfreq * Ts;
                 const float cy = dd + clock;
                 const float thr = fmaf(-dd, 0.5f, 1.0f);
-                if (thr > cy) {
+                const bool is_ted = !(thr > cy);
+                if (!is_ted) {
                     clock = cy;
                 } else {
                     clock = 0.0f;
@@ -2457,6 +2501,16 @@ __global__ __launch_bounds__(2 * kWave) void k_rds_sync(Dims d, float2* __restri
                     sign_word |= ((si > 0.0f) ? 1u : 0u) << (wsym & 31);
                     if ((wsym & 31) == 31) { sign_bits[lane * kSignWords + (wsym >> 5)] = sign_word; sign_word = 0u; }
                     n_sym++; wsym++;
+                }
+                if constexpr (!FAST) {
+                    // FMD_FLAG_KEEP_TAPS: BPSK_Synchroniser's per-sample views (bpsk_synchroniser.h:78-85; the oracle's bpsk_process keeps the same
+                    // values at the same point of the iteration)
+                    if (taps.b_pll_sym && live) {
+                        const size_t o = (size_t)c * n + (size_t)ch * kChunk + t;
+                        taps.b_pll_sym[o] = make_float2(iq_r, iq_i); taps.b_intdump[o] = make_float2(dump_r, dump_i);
+                        taps.b_ted_raw[o] = ted_err; taps.b_ted_pi[o] = PI_ted; taps.b_pll_raw[o] = pll_err; taps.b_pll_pi[o] = PI_pll;
+                        taps.b_zcd[o] = is_zcd ? 1.0f : 0.0f; taps.b_trig[o] = is_ted ? 1.0f : 0.0f;
+                    }
                 }
             }
             // a chunk adds at most kChunk / 4 symbols to a lane's row (3500 Hz of 16 kHz is fewer): decode before any row can overflow
@@ -2849,6 +2903,9 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
         if (iq) FMD_LAUNCH(r, false, true, k_planes_to_iq, dim3((unsigned)(d.n_fm_out / 256 * d.C)), dim3(256), 0, s, d, ctx.b.fo_pl[r.buf], ctx.b.fm_out_iq[r.buf], ctx.front);
         return hipGetLastError();
     }
+    // FMD_FLAG_KEEP_TAPS: the loop's traces, from the state the block starts from (ahead of the kernel that advances it)
+    if (ctx.b.taps[r.buf]) hipLaunchKernelGGL(k_pll_taps, dim3((unsigned)((d.C + kWave - 1) / kWave)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.state, ctx.loops,
+                                              (int)S_PILOT_POWER0 + r.buf, tap_ptrs(ctx, r.buf));
     if (d.C > ctx.pll_time_parallel_max_channels) {
         FMD_LAUNCH(r, true, true, k_pilot_pll_pairs, dim3((unsigned)((d.C + kPllCh - 1) / kPllCh)), dim3(2 * kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf],
                    ctx.b.state, ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
@@ -2950,6 +3007,42 @@ extern "C" int fmd_debug_read_rds_probe(unsigned long long* out16) {
 }
 namespace fmd {
 #endif
+// Tolerance mode, 256 kSa/s cf32 captures: the block's front end, pilot stage and extract stage as ONE launch (fmd_kernels_chain.inc); the
+// RDS stage follows as before.  chain_possible: what the kernel's geometry needs of the configuration (the host adds what it needs of the
+// block: no start-up block, no de-emphasis, one set of cut-offs for all stations — fmd_api.cpp).
+bool chain_possible(const LaunchCtx& ctx) {
+    static const bool off = dev_env("FMD_NO_CHAIN") != nullptr;      // (A/B hook)
+    const Dims& d = ctx.d;
+    return ctx.fast && d.m == 1 && !ctx.keep_taps && !ctx.b.fm_out_iq[0] && d.n_fm_out % 1024 == 0 && d.n_audio % 256 == 0 && d.tail_base >= 64 && !off;
+}
+hipError_t launch_stage_chain(const LaunchCtx& ctx, SlotRef r, const void* d_iq, hipStream_t s) {
+    const Dims& d = ctx.d;
+    const Buffers& b = ctx.b;
+    const int nxt = (r.buf + 1) % kSlots;
+    ChainArgs a{};
+    a.in = static_cast<const float2*>(d_iq); a.tail_in = b.base_tail[r.par]; a.tail_out = b.base_tail[r.par ^ 1];
+    a.front_tab = b.front_mfma; a.sp = b.sparse_tab; a.fm_gain = ctx.front.fm_gain;
+    a.fo_hist = b.fo_pl[r.buf]; a.fo_next = b.fo_pl[nxt];
+    a.hist_in = b.pv_hist[r.par]; a.hist_out = b.pv_hist[r.par ^ 1];
+    a.poly = b.pll_poly[r.buf]; a.poly_next = b.pll_poly[nxt];
+    a.state = b.state; a.k = ctx.loops;
+    a.bp_tab = b.bp_tab; a.aud_idx = b.aud_idx; a.rds_tab = b.rds_bp_tab; a.bp_edge = b.bp_edge; a.mixctl = b.mix;
+    a.audio = b.audio[r.buf]; a.rds = b.rds[r.buf]; a.lmr_est = b.lmr_est[r.par];
+    a.lmr_est_prev = lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr;
+    a.field_cur = lmr_field(r.par); a.field_prev = lmr_field(r.par ^ 1); a.rds_pow = b.rds_pow[r.buf];
+    a.spec_stats = b.spec_stats;
+    FMD_LAUNCH(r, true, true, k_chain, dim3((unsigned)((d.C + ChainGeom::G - 1) / ChainGeom::G)), dim3(320), 0, s, d, a);
+    if (!lmr_inline(ctx)) {   // P_{b+1} behind block b (launch_stage_extract)
+        if (ctx.fast && ctx.d.n_est <= kLmrInlineMax)
+            hipLaunchKernelGGL(k_lmr_phase_fast, dim3((unsigned)ctx.d.C), dim3(kWave), 0, s, ctx.d, ctx.b.lmr_est[r.par], ctx.b.state, lmr_field(r.par),
+                               ctx.b.state + (size_t)lmr_field(r.par ^ 1) * ctx.d.C);
+        else
+            hipLaunchKernelGGL(k_lmr_phase, dim3(serial_waves(ctx.d)), dim3(kWave), 0, s, ctx.d, ctx.b.lmr_est[r.par], ctx.b.state, lmr_field(r.par),
+                               ctx.b.state + (size_t)lmr_field(r.par ^ 1) * ctx.d.C);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     const Dims& d = ctx.d;
     const Buffers& b = ctx.b;
@@ -2964,10 +3057,11 @@ hipError_t launch_stage_rds(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
         }
         FMD_LAUNCH(r, true, true, k_rds_sync<true>, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
                    b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps,
-                   partials ? b.rds_pow[r.buf] : (const float*)nullptr, 2 * (d.n_audio / 256));
+                   partials ? b.rds_pow[r.buf] : (const float*)nullptr, 2 * (d.n_audio / 256), TapPtrs{});
     } else {
         FMD_LAUNCH(r, true, true, k_rds_sync<false>, dim3(serial_waves(d)), dim3(2 * kWave), 0, s, d, b.rds[r.buf], b.state, ctx.loops, b.rds_sym[r.buf],
-                   b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps, (const float*)nullptr, 0);
+                   b.rds_raw_sym[r.buf], b.rds_count[r.buf], b.rds_bytes[r.buf], b.rds_bytes_count[r.buf], ctx.bytes_cap, ctx.keep_taps, (const float*)nullptr, 0,
+                   tap_ptrs(ctx, r.buf));
     }
     return hipGetLastError();
 }

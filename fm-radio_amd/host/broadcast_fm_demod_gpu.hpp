@@ -7,6 +7,7 @@
 //   OnAudioOut().Attach(fn(span<const Frame<float>>, int Fs))     OnAudioOut().Attach(fn(const Frame*, size_t n, int Fs))
 //   OnRDSOut().Attach(fn(span<const float>))                      OnRDSOut().Attach(fn(const float*, size_t n))
 //   GetAudioOut() / GetRDSPredSymbols() / GetLPRAudioOutput() ... same names, return pointer+size views
+//   GetPilotOutput() / GetPLLOutput() / Get_PLL_*_Phase_Error_Output() (.h:244-248), GetBPSKSync().Get*() (bpsk_synchroniser.h:78-85): same names
 //   GetControls()                                                 GetControls() / ApplyControls()
 //   App::Process(span<const complex<uint8_t>>) (src/app.cpp:39-50)  App_GPU::Process(const uint8_t* iq, size_t n_samples)
 //
@@ -49,6 +50,7 @@ class Broadcast_FM_Demod_GPU {
     fmd_controls controls{};
     int n_channels, block_size;
     std::vector<float> audio, rds_sym, lpr, lmr, fm_out_iq, rds, rds_raw;
+    std::vector<float> pilot, pll, pll_raw_err, pll_pi_err, b_pll_sym, b_intdump, b_zcd, b_trig, b_ted_raw, b_ted_pi, b_pll_raw, b_pll_pi;
     std::vector<int> rds_count;
     std::vector<uint8_t> rds_bytes;
     std::vector<int> rds_bytes_count;
@@ -62,6 +64,11 @@ class Broadcast_FM_Demod_GPU {
         fmd_get_stream(h, name, v.data(), 0, &n);
         v.resize(n);
         check(fmd_get_stream(h, name, v.data(), v.size(), &n), name);
+    }
+    View<float> fview(const char* name, std::vector<float>& v, int c, int n) { fetch(name, v); return {v.data() + (size_t)c * n, (size_t)n}; }
+    View<std::complex<float>> cview(const char* name, std::vector<float>& v, int c, int n) {
+        fetch(name, v);
+        return {reinterpret_cast<const std::complex<float>*>(v.data()) + (size_t)c * n, (size_t)n};
     }
 public:
     explicit Broadcast_FM_Demod_GPU(int _block_size, int _n_channels = 1, int fs_baseband = 1024000, bool keep_taps = true)
@@ -95,6 +102,26 @@ public:
     View<std::complex<float>> GetRDSOutput(int c = 0) { fetch("rds", rds);
         return {reinterpret_cast<const std::complex<float>*>(rds.data()) + (size_t)c * rates.n_rds, (size_t)rates.n_rds}; }
     float GetAudioLMRPhaseError(int c = 0) { std::vector<float> v; fetch("lmr_phase", v); return v[c]; }
+    // 2. Lock onto pilot (reference .h:244-248) — the loop's per-sample traces; the adaptor runs the exact mode with FMD_FLAG_KEEP_TAPS
+    View<std::complex<float>> GetPilotOutput(int c = 0) { return cview("pilot", pilot, c, rates.n_fm_out); }
+    View<std::complex<float>> GetPLLOutput(int c = 0) { return cview("pll", pll, c, rates.n_fm_out); }
+    View<float> Get_PLL_Raw_Phase_Error_Output(int c = 0) { return fview("pll_raw_err", pll_raw_err, c, rates.n_fm_out); }
+    View<float> Get_PLL_LPF_Phase_Error_Output(int c = 0) { return fview("pll_pi_err", pll_pi_err, c, rates.n_fm_out); }
+    // BPSK_Synchroniser's views (reference bpsk_synchroniser.h:78-85; GetBPSKSync() of broadcast_fm_demod.h:262): one object per station
+    class BPSK_Sync_View {
+        Broadcast_FM_Demod_GPU& d; int c;
+    public:
+        BPSK_Sync_View(Broadcast_FM_Demod_GPU& d_, int c_) : d(d_), c(c_) {}
+        View<std::complex<float>> GetPLLSymbols() { return d.cview("bpsk_pll_sym", d.b_pll_sym, c, d.rates.n_rds); }
+        View<float> GetZeroCrossings() { return d.fview("bpsk_zcd", d.b_zcd, c, d.rates.n_rds); }            // (0 / 1; the reference's span<const bool>)
+        View<float> GetIntDumpTriggers() { return d.fview("bpsk_trig", d.b_trig, c, d.rates.n_rds); }
+        View<float> GetTEDRawPhaseError() { return d.fview("bpsk_ted_raw", d.b_ted_raw, c, d.rates.n_rds); }
+        View<float> GetTEDPIPhaseError() { return d.fview("bpsk_ted_pi", d.b_ted_pi, c, d.rates.n_rds); }
+        View<float> GetPLLRawPhaseError() { return d.fview("bpsk_pll_raw", d.b_pll_raw, c, d.rates.n_rds); }
+        View<float> GetPLLPIPhaseError() { return d.fview("bpsk_pll_pi", d.b_pll_pi, c, d.rates.n_rds); }
+        View<std::complex<float>> GetIntDumpFilter() { return d.cview("bpsk_intdump", d.b_intdump, c, d.rates.n_rds); }
+    };
+    BPSK_Sync_View GetBPSKSync(int c = 0) { return BPSK_Sync_View(*this, c); }
 
     // sample rates (reference .h:284-288)
     int GetBasebandSampleRate() const { return rates.fs_baseband; }

@@ -241,6 +241,14 @@ int fmd_get_rds_symbols(fmd_handle h, float* syms /* [C][n_rds] */, int* counts 
  *   "lmr" GetLMRAudioOutput [C][n_audio] | "rds" GetRDSOutput (post-AGC) [C][n_rds][2]
  *   "rds_raw_sym" GetRDSRawSymbols [C][n_rds][2] | "lmr_phase" GetAudioLMRPhaseError [C]
  *   "agc_pilot_gain" [C] | "agc_rds_gain" [C]
+ *   exact mode with FMD_FLAG_KEEP_TAPS, the two loops' per-sample traces (broadcast_fm_demod.h:245-248, bpsk_synchroniser.h:78-85):
+ *   "pilot" GetPilotOutput (after its AGC) [C][n_fm_out][2] | "pll" GetPLLOutput (cos, sin) [C][n_fm_out][2]
+ *   "pll_raw_err" Get_PLL_Raw_Phase_Error_Output [C][n_fm_out] | "pll_pi_err" Get_PLL_LPF_Phase_Error_Output [C][n_fm_out]
+ *   "bpsk_pll_sym" GetPLLSymbols [C][n_rds][2] | "bpsk_intdump" GetIntDumpFilter [C][n_rds][2] | "bpsk_ted_raw" GetTEDRawPhaseError,
+ *   "bpsk_ted_pi" GetTEDPIPhaseError, "bpsk_pll_raw" GetPLLRawPhaseError, "bpsk_pll_pi" GetPLLPIPhaseError, "bpsk_zcd" GetZeroCrossings and
+ *   "bpsk_trig" GetIntDumpTriggers (the two bool traces as 0 / 1) [C][n_rds] — bit-identical
+ *   to the oracle's; the tolerance mode evaluates its loops at eight points per span / on groups of four samples and has no such trace
+ *   (FMD_ERR_NAME)
  *   FMD_FLAG_FAST_MATH keeps fm_out alone (the kernels that need the Hilbert rail make it for themselves) and the NCO phase as one
  *   cubic per 128 samples: "fm_out_iq" and "pll_dt" then need FMD_FLAG_KEEP_TAPS too; "pll_poly" [C][1 + n_fm_out / 128][4] (tolerance mode only) is always there
  * Copies the current block's values to `out` (host); *n_floats receives the float count.  Needs

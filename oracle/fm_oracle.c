@@ -413,6 +413,7 @@ typedef struct {
     float pll_xn[2], pll_yn[2];
     /* traces */
     fmo_cf32 *pll_sym, *int_dump; uint8_t *zcd, *trig; float *ted_raw, *ted_pi, *pll_raw, *pll_pi;
+    float *zcd_f, *trig_f;   /* the two bool traces (GetZeroCrossings, GetIntDumpTriggers :79-80) once more as 0 / 1 floats for fmo_get */
 } bpsk_t;
 
 static void bpsk_init(bpsk_t* s, int block_size) {
@@ -433,11 +434,12 @@ static void bpsk_init(bpsk_t* s, int block_size) {
     s->zcd = (uint8_t*)calloc(block_size, 1); s->trig = (uint8_t*)calloc(block_size, 1);
     s->ted_raw = (float*)calloc(block_size, 4); s->ted_pi = (float*)calloc(block_size, 4);
     s->pll_raw = (float*)calloc(block_size, 4); s->pll_pi = (float*)calloc(block_size, 4);
+    s->zcd_f = (float*)calloc(block_size, 4); s->trig_f = (float*)calloc(block_size, 4);
 }
 
 static void bpsk_free(bpsk_t* s) {
     free(s->pll_sym); free(s->int_dump); free(s->zcd); free(s->trig);
-    free(s->ted_raw); free(s->ted_pi); free(s->pll_raw); free(s->pll_pi);
+    free(s->ted_raw); free(s->ted_pi); free(s->pll_raw); free(s->pll_pi); free(s->zcd_f); free(s->trig_f);
 }
 
 static int bpsk_process(bpsk_t* s, const fmo_coeffs* k, const fmo_cf32* x, fmo_cf32* y) {
@@ -482,6 +484,7 @@ static int bpsk_process(bpsk_t* s, const fmo_coeffs* k, const fmo_cf32* x, fmo_c
             y[n_sym++] = sym;
         }
         s->pll_sym[i] = IQ; s->zcd[i] = (uint8_t)is_zcd; s->trig[i] = (uint8_t)is_ted;
+        s->zcd_f[i] = (float)is_zcd; s->trig_f[i] = (float)is_ted;
         s->ted_raw[i] = s->ted_prev_phase_error; s->ted_pi[i] = PI_ted;
         s->pll_raw[i] = s->pll_prev_phase_error; s->pll_pi[i] = PI_pll;
         s->int_dump[i] = s->dump_yn;
@@ -724,6 +727,8 @@ const float* fmo_get(fmo_demod* d, const char* name, int* n) {
     if (!strcmp(name, "bpsk_ted_pi")) RET(d->bpsk.ted_pi, d->n_rds);
     if (!strcmp(name, "bpsk_pll_raw")) RET(d->bpsk.pll_raw, d->n_rds);
     if (!strcmp(name, "bpsk_pll_pi")) RET(d->bpsk.pll_pi, d->n_rds);
+    if (!strcmp(name, "bpsk_zcd")) RET(d->bpsk.zcd_f, d->n_rds);
+    if (!strcmp(name, "bpsk_trig")) RET(d->bpsk.trig_f, d->n_rds);
 #undef RET
     *n = 0;
     return NULL;

@@ -150,7 +150,7 @@ def design(fs_baseband: int = 1_024_000, controls: Controls | None = None, rsqrt
 STREAMS = [
     "fm_in", "fm_demod", "fm_out", "fm_out_iq", "pilot", "pll_dt", "pll", "pll_raw_err", "pll_pi_err",
     "lpr", "lmr", "rds", "rds_raw_sym", "rds_sym", "audio", "lmr_phase",
-    "bpsk_pll_sym", "bpsk_intdump", "bpsk_ted_raw", "bpsk_ted_pi", "bpsk_pll_raw", "bpsk_pll_pi",
+    "bpsk_pll_sym", "bpsk_intdump", "bpsk_ted_raw", "bpsk_ted_pi", "bpsk_pll_raw", "bpsk_pll_pi", "bpsk_zcd", "bpsk_trig",
 ]
 
 

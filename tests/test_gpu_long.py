@@ -194,9 +194,9 @@ def test_tolerance_mode_rds_stage_on_pipelined_wavefronts(pkg):
             "median_station_p99_of_the_rest": float(np.median([s["p99_of_the_rest"] for s in stats]))}
         print("RDS soft symbols against the oracle, in lock:", summary[f"keep_taps_{int(keep)}"])
         assert len(stats) >= int(np.ceil(0.9 * n_st)), (keep, len(stats))                 # at least 90 % of the stations are compared
-        assert max(s["median"] for s in stats) <= 1e-4, keep                                 # every station: the typical symbol within 1e-4
-        assert float(np.median([s["rms"] for s in stats])) <= 2e-4, keep                     # the typical station: RMS within 2e-4 (moved symbols included)
-        assert moved <= 0.02 * total, (keep, moved, total)                                   # tipped clock decisions: the reference's own builds move 1.4 % of theirs
+        assert max(s["median"] for s in stats) <= 4e-5, keep                                 # every station: the typical symbol within 4e-5 (measured 2.0e-5 on the worst; the north star's figure is 1e-4)
+        assert float(np.median([s["rms"] for s in stats])) <= 6e-5, keep                     # the typical station: RMS within 6e-5, moved symbols included (measured 2.6e-5)
+        assert moved <= 0.003 * total, (keep, moved, total)                                  # tipped clock decisions: measured 0.14 % (the reference's own two builds move 1.4 % of theirs)
         # ... and the symbols that did not move by 1e-2, on every station: inside what the reference's own two builds show for theirs (1.1e-3 on
         # their worst station, 5e-4 on their typical one: a moved decision's neighbours trail it)
         assert max(s["rms_of_the_rest"] for s in stats) <= 1.1e-3, keep
@@ -204,7 +204,7 @@ def test_tolerance_mode_rds_stage_on_pipelined_wavefronts(pkg):
         # station move with a tipped clock decision — as in the reference's own builds — and the p99 is taken over the ones that did not):
         # the typical station keeps the old bar; the worst station — the one with the most tipped decisions, whose neighbouring symbols trail
         # them — measured 3.0e-3 (round 5), bounded at 4e-3.  THE BAR CHANGED in round 4: it was p99 <= 1.4e-3 over ALL symbols of every station.
-        assert float(np.median([s["p99_of_the_rest"] for s in stats])) <= 1.4e-3, keep
+        assert float(np.median([s["p99_of_the_rest"] for s in stats])) <= 2e-4, keep      # (measured 9.3e-5; rounds 1-5 asserted 1.4e-3: VERDICT r5 weak 2 — the bars now sit within 2x of what profiles/round5/parity_metrics.json records)
         assert max(s["p99_of_the_rest"] for s in stats) <= 4e-3, keep
     F.record_parity_metrics("rds_soft_symbols_24_stations_2_s", summary)
     same = sum(int(np.array_equal(out[False][0][c], out[True][0][c])) for c in range(n_st))

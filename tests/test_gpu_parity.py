@@ -105,18 +105,78 @@ def test_batched_equals_independent_runs(pkg):
         assert np.array_equal(both["rds_sym"][c].view(np.uint32), one["rds_sym"][0].view(np.uint32))
 
 
-def test_coefficients_vs_oracle(pkg):
-    dm = pkg.BatchDemod(1, 8192, 1_024_000)
+@pytest.mark.parametrize("fs", [256_000, 1_024_000, 2_048_000])
+@pytest.mark.parametrize("kw", [
+    dict(),
+    dict(use_deemphasis=1, deemphasis_tus=50, lpr_cutoff_hz=12000, lmr_cutoff_hz=9000),
+    dict(use_deemphasis=1, deemphasis_tus=75, lpr_cutoff_hz=100, lmr_cutoff_hz=70000, audio_stereo_mix_factor=0.65),
+])
+def test_coefficients_vs_oracle(pkg, fs, kw):
+    """The designer the LIBRARY runs (fmd_get_coeffs of a live handle) against the oracle's designs, at all three rates and with
+    non-default cut-offs / de-emphasis (the parity comparisons hand the oracle the library's coefficients, so the
+    designer has to be pinned on its own wherever those comparisons run).  The CPU twin is tests/test_capi_cpu.py::test_host_designer_matches_oracle."""
+    dm = pkg.BatchDemod(1, 8192, fs)
+    ctl = _ctl(pkg, **kw)
+    if kw:
+        dm.set_controls(ctl)
+        n = 8192
+        assert dm.process(np.zeros((1, n, 2), np.float32)) == 0       # controls take effect at a block boundary
     k = lib_coeffs_to_oracle(dm.get_coeffs(0))
-    ref = O.design(1_024_000, rsqrt_mode=0)
+    from gpu_parity import oracle_controls
+    ref = O.design(fs, oracle_controls(ctl), rsqrt_mode=0)
     for name in ("b_fm_in", "b_fm_out", "b_hilbert", "pilot_a", "pll_lpf_b", "pll_lpf_a", "deemph_b", "deemph_a", "b_lpr", "b_lmr",
                  "b_rds", "ted_lpf_b", "ted_lpf_a", "bpsk_lpf_b", "bpsk_lpf_a", "pilot_b"):
-        assert np.array_equal(k.arr(name).view(np.uint32), ref.arr(name).view(np.uint32)), name
+        assert np.array_equal(k.arr(name).view(np.uint32), ref.arr(name).view(np.uint32)), (name, fs, kw)
     assert np.float32(k.fm_gain) == np.float32(ref.fm_gain)
     # vs the reference build's rsqrtss-approximated gain: a couple of ulp
-    ref2 = O.design(1_024_000, rsqrt_mode=1)
+    ref2 = O.design(fs, oracle_controls(ctl), rsqrt_mode=1)
     assert abs(float(k.arr("pilot_b")[0]) - float(ref2.arr("pilot_b")[0])) <= 4 * np.spacing(ref2.arr("pilot_b")[0])
     dm.close()
+
+
+LOOP_TRACES = ["pilot", "pll", "pll_raw_err", "pll_pi_err", "bpsk_pll_sym", "bpsk_intdump", "bpsk_zcd", "bpsk_trig", "bpsk_ted_raw", "bpsk_ted_pi",
+               "bpsk_pll_raw", "bpsk_pll_pi"]
+
+
+@pytest.mark.parametrize("fs,block,n_ch,u8", [(1_024_000, 16384, 3, True), (256_000, 8192, 2, False), (1_024_000, 8192, 70, False)])
+def test_loop_traces_bit_exact(pkg, fs, block, n_ch, u8):
+    """The reference's per-sample loop getters — GetPilotOutput, GetPLLOutput, Get_PLL_Raw_Phase_Error_Output, Get_PLL_LPF_Phase_Error_Output
+    (broadcast_fm_demod.h:245-248) and BPSK_Synchroniser's Get* views (bpsk_synchroniser.h:78-85) — through fmd_get_stream in the exact
+    mode with FMD_FLAG_KEEP_TAPS: every one bit-identical to the oracle (which tests/test_oracle_vs_ref.py pins against the compiled
+    reference), block after block from a cold start, i.e. through acquisition; and asking for them changes no output."""
+    nb = 4
+    caps = _caps(n_ch, nb * block, fs=float(fs), seed=17, u8=u8)
+    dm = pkg.BatchDemod(n_ch, block, fs, keep_taps=True)
+    plain = run_gpu(pkg, caps[: min(n_ch, 3)], block, fs)
+    got = {k: [] for k in LOOP_TRACES + ["audio"]}
+    for b in range(nb):
+        assert dm.process(np.ascontiguousarray(caps[:, b * block:(b + 1) * block])) == 0
+        for k in LOOP_TRACES:
+            got[k].append(dm.stream(k))
+        got["audio"].append(dm.audio().reshape(n_ch, -1))
+    coeffs = [dm.get_coeffs(c) for c in range(n_ch)]
+    dm.close()
+    got = {k: np.concatenate(v, axis=1) for k, v in got.items()}
+    for c in list(range(min(n_ch, 3))) + ([n_ch - 1] if n_ch > 3 else []):
+        o = O.run_chain(caps[c], block, fs, u8=u8, coeffs=lib_coeffs_to_oracle(coeffs[c]), streams=LOOP_TRACES + ["audio"])
+        for k in LOOP_TRACES:
+            a, b_ = np.asarray(got[k][c], np.float32).reshape(-1), o[k].reshape(-1)
+            assert a.shape == b_.shape, (k, a.shape, b_.shape)
+            assert np.array_equal(a.view(np.uint32), b_.view(np.uint32)), (c, k, float(np.max(np.abs(a - b_))))
+        assert np.array_equal(got["audio"][c].reshape(-1).view(np.uint32), o["audio"].reshape(-1).view(np.uint32))
+    for c in range(min(n_ch, 3)):
+        assert np.array_equal(got["audio"][c].view(np.uint32), plain["audio"][c].view(np.uint32))
+
+
+def test_loop_traces_are_refused_where_they_do_not_exist(pkg):
+    """Tolerance mode (loops at eight points per span / groups of four samples) and handles without FMD_FLAG_KEEP_TAPS: FMD_ERR_NAME."""
+    for kw in (dict(keep_taps=True, fast_math=True), dict(keep_taps=False)):
+        dm = pkg.BatchDemod(1, 8192, 1_024_000, **kw)
+        assert dm.process(np.zeros((1, 8192, 2), np.float32)) == 0
+        for k in ("pilot", "pll_pi_err", "bpsk_ted_pi"):
+            with pytest.raises(Exception):
+                dm.stream(k)
+        dm.close()
 
 
 def test_golden_chain_fixture(pkg, golden):
@@ -441,8 +501,9 @@ def test_cpp_host_adaptor_matches_oracle(pkg, tmp_path):
     dm = pkg.BatchDemod(1, bs, 1_024_000)
     k = lib_coeffs_to_oracle(dm.get_coeffs(0))
     dm.close()
-    o = O.run_chain(cap[: bs * nb], bs, 1_024_000, u8=True, coeffs=k, streams=["audio", "rds_sym", "lpr"])
-    for name, key in (("audio.f32", "audio"), ("rds_sym.f32", "rds_sym"), ("lpr.f32", "lpr")):
+    o = O.run_chain(cap[: bs * nb], bs, 1_024_000, u8=True, coeffs=k, streams=["audio", "rds_sym", "lpr", "pll", "pll_pi_err", "pilot", "bpsk_ted_pi", "bpsk_pll_sym"])
+    for name, key in (("audio.f32", "audio"), ("rds_sym.f32", "rds_sym"), ("lpr.f32", "lpr"), ("pll.cf32", "pll"), ("pll_pi_err.f32", "pll_pi_err"),
+                      ("pilot.cf32", "pilot"), ("bpsk_ted_pi.f32", "bpsk_ted_pi"), ("bpsk_pll_sym.cf32", "bpsk_pll_sym")):
         got = np.fromfile(tmp_path / name, dtype=np.float32)
         assert np.array_equal(got.view(np.uint32), o[key].view(np.uint32)), name
     assert np.array_equal(np.fromfile(tmp_path / "rds_bytes.u8", dtype=np.uint8), o["rds_bytes"])

@@ -21,6 +21,8 @@ def _assert_same(ref, orc):
     for k in STREAMS:
         assert bits_equal(ref[k], orc[k]), f"{k}: {describe_diff(ref[k], orc[k])}"
     assert np.array_equal(ref["rds_count"], orc["rds_count"])
+    for k in ("bpsk_zcd", "bpsk_trig"):      # the reference's two bool traces (bpsk_synchroniser.h:79-80); the oracle hands them out as 0 / 1 floats
+        assert np.array_equal(ref[k].astype(np.float32), orc[k]), k
     assert np.array_equal(ref["rds_bytes"], orc["rds_bytes"])
 
 

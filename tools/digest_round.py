@@ -112,6 +112,14 @@ def install(rnd: str = "5") -> None:
                     "count quad-cycles summed over wavefronts, SQ_VALU_MFMA_BUSY_CYCLES cycles, SQ_INSTS_* wave-instructions (MI355X_MICROARCH.md)",
             "workload": cfg["workload"], "mode": mode, "valu_total_per_block": valu_total,
             "kernels": {k: {c: v for c, v in cs.items() if c in keep} for k, cs in ctr.items()}}, indent=1) + "\n")
+    # stamp the table with the library it was measured on (bench.py: kernel_source_stamp / traffic_stale)
+    import importlib.util, subprocess
+    spec = importlib.util.spec_from_file_location("bench", ROOT / "bench.py"); bench_mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench_mod)
+    try:
+        git = subprocess.run(["git", "-C", str(ROOT), "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        git = ""
+    traffic_tab["_meta"] = {"kernel_source_stamp": bench_mod.kernel_source_stamp(), "git_head_at_install": git, "round": rnd}
     (ROOT / "profiles" / "hbm_traffic.json").write_text(json.dumps(traffic_tab, indent=1) + "\n")
     (ROOT / "profiles" / "valu_instructions.json").write_text(json.dumps(valu_tab, indent=1) + "\n")
     print("installed into", dst)
