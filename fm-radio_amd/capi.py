@@ -158,6 +158,8 @@ def load_library():
     L.fmd_design_pll_span.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.fmd_profile_enable.argtypes = [H, C.c_int]
     L.fmd_debug_split_front.argtypes = [H, C.c_int]
+    L.fmd_debug_set_chain.argtypes = [H, C.c_int]
+    L.fmd_debug_chain_blocks.argtypes = [H, C.POINTER(C.c_long)]
     L.fmd_profile_read.argtypes = [H, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]
     L.fmd_chan_design.argtypes = [C.c_double, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.fmd_chan_create.argtypes = [C.POINTER(ChanConfig), C.POINTER(C.c_void_p)]
@@ -328,6 +330,15 @@ class BatchDemod:
 
     def synchronize(self):
         self._check(self.L.fmd_synchronize(self.h))
+
+    def set_chain(self, on: bool) -> None:
+        """fmd_debug_set_chain: False keeps the three-launch form of the tolerance mode's steady blocks (the parity A/B of k_chain)."""
+        self._check(self.L.fmd_debug_set_chain(self.h, 1 if on else 0))
+
+    def chain_blocks(self) -> int:
+        n = C.c_long(0)
+        self._check(self.L.fmd_debug_chain_blocks(self.h, C.byref(n)))
+        return int(n.value)
 
     def set_output_lag(self, on: bool) -> None:
         """fmd_set_output_lag: with on=True the device-side output calls (wait_outputs, release_outputs, audio_tensor, audio_pcm16_into,

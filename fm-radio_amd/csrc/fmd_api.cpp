@@ -32,7 +32,7 @@ static const char* const kStageName[ST_COUNT] = {"k_front", "k_deemphasis+k_hilb
 // ... and of the tolerance mode's kernels, as they appear in rocprofv3 kernel traces
 static const char* const kStageNameFast[ST_COUNT] = {"k_front_mfma", "k_deemphasis", "k_pilot_power", "k_pll_sparse", "k_extract_bp", "k_rds_sync", "k_predecim_mfma"};
 
-struct ProfiledBlock { hipEvent_t t0[ST_COUNT], t1[ST_COUNT]; bool used[ST_COUNT]; };
+struct ProfiledBlock { hipEvent_t t0[ST_COUNT], t1[ST_COUNT]; bool used[ST_COUNT]; bool chain = false; };
 
 struct fmd_handle_s {
     fmd_config cfg{};
@@ -64,6 +64,10 @@ struct fmd_handle_s {
     // NEXT block is submitted (behind that block's front end) or when somebody asks for the outputs — see process_dev
     bool lazy_extract = false, lazy_capable = false;
     bool no_fused_pll = false;               // development A/B: the deferred pilot stage as a launch of its own
+    bool uniform_cutoffs = true;             // every station has the same L+R / L-R cut-offs (one set of tap tables): what k_chain needs of the controls
+    bool chain_off = true;                   // the one-launch form of a steady block (k_chain) is OFF unless fmd_debug_set_chain(h, 1) / FMD_CHAIN=1 (development builds) asks for it: measured slower, DESIGN.md section 3
+    long chain_blocks = 0;                   // blocks run as k_chain since create / reset
+    bool last_block_chain = false;
     bool pll_eager = false;                  // development A/B: the pilot stage queued at submission on its own queue (round 3's arrangement)
     bool split_queues = false;               // the front end's and the extract stage's queues on disjoint sets of CUs (hipExtStreamCreateWithCUMask): the two run side by side
     bool front_with_predecim = true;         // 1.024 / 2.048 MSa/s, deferred schedule: the front end follows the first decimator on ITS queue
@@ -342,6 +346,8 @@ int upload_controls(fmd_handle h, hipStream_t s) {
         }
         HIP_TRY(h, hipMemcpyAsync(b.aud_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, s));
         HIP_TRY(h, hipStreamSynchronize(s));
+        h->uniform_cutoffs = true;
+        for (int c = 1; c < C; c++) if (idx[(size_t)c * 2] != idx[0] || idx[(size_t)c * 2 + 1] != idx[1]) { h->uniform_cutoffs = false; break; }
     }
     HIP_TRY(h, hipMemcpyAsync(b.b_lpr, lpr.data(), lpr.size() * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(b.b_lmr, lmr.data(), lmr.size() * 4, hipMemcpyHostToDevice, s));
@@ -587,6 +593,7 @@ int zero_history(fmd_handle h, hipStream_t s) {
     for (hipEvent_t& e : h->x_done) e = nullptr;
     h->ev_consumed = nullptr;
     h->out_slot = 0; h->sub_slot = 0; h->have_out = false; h->out_block = -1;
+    h->chain_blocks = 0; h->last_block_chain = false;
     h->epoch++;
     for (bool& u : h->slot_used) u = false;
     for (bool& u : h->consumer_pending) u = false;
@@ -779,6 +786,47 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
     // the block after the last de-emphasised one: k_front maintains the Hilbert history (fo_tail) again and must not overwrite
     // what the previous block's k_hilbert, on its own stream, is still reading
     if (pipe && !h->ctx.any_deemph && h->last_block_deemph) HIP_TRY(h, hipStreamWaitEvent(sFq, h->ev_F[h->sub_slot], 0));
+    // Tolerance mode, 256 kSa/s cf32, a steady block: front end, pilot stage and extract stage as ONE launch (k_chain, fmd_kernels_chain.inc) on the
+    // front end's queue, the RDS stage behind it on its own.  Nothing of such a block is put off: its outputs are complete one launch and the
+    // RDS stage after its submission, and no kernel of it waits for another queue.  Start-up blocks, de-emphasised or differently filtered
+    // stations, u8 captures, FMD_FLAG_KEEP_TAPS and un-pipelined handles keep the three launches; both forms leave the same histories.
+    const bool chain = pipe && !u8 && !ref.warm && !h->chain_off && h->uniform_cutoffs && !h->ctx.any_deemph && !h->ctx.deemph_in_tile && !h->last_block_deemph &&
+                       !(h->debug_skip & ~(1u << ST_RDS)) && chain_possible(h->ctx);
+    if (chain) {
+        { int rc = launch_deferred(h, true); if (rc) return rc; }       // (a start-up block ahead of this one: its put-off stages first, in order on this queue)
+        if (h->consumer_pending[slot]) {
+            HIP_TRY(h, hipStreamWaitEvent(sF, h->ev_C[slot], 0));
+            HIP_TRY(h, hipStreamWaitEvent(sR, h->ev_C[slot], 0));
+            h->consumer_pending[slot] = false;
+        }
+        const int nx = (slot + 1) % kSlots;      // (the block writes the histories in front of the next slot's rows: see the pilot stage below)
+        if (h->slot_used[nx] && h->x_done[nx] && h->last_x_stream != sF) HIP_TRY(h, hipStreamWaitEvent(sF, h->x_done[nx], 0));
+        if (h->last_p_event && h->last_p_stream != sF) HIP_TRY(h, hipStreamWaitEvent(sF, h->last_p_event, 0));
+        if (h->last_x_event && h->last_x_stream != sF) HIP_TRY(h, hipStreamWaitEvent(sF, h->last_x_event, 0));
+        SlotRef r = ref;
+        if (pm && prof_stage(ST_FRONT)) { r.t0 = pm->t0[ST_FRONT]; r.t1 = pm->t1[ST_FRONT]; pm->used[ST_FRONT] = true; pm->chain = true; }
+        if (!r.t1) r.done = h->ev_E[slot];
+        dep = r.t1 ? r.t1 : h->ev_E[slot];
+        e = launch_stage_chain(h->ctx, r, d_iq, sF);
+        if (e != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_chain launch: %s", hipGetErrorString(e));
+        if (ordered) HIP_TRY(h, hipStreamWaitEvent(s, dep, 0));          // the caller may reuse `iq` in stream order after this call
+        HIP_TRY(h, hipEventRecord(h->ev_F[slot], sF));                   // fmd_wait_input: an event that outlives this call
+        h->ev_consumed = h->ev_F[slot];
+        h->last_p_stream = sF; h->last_p_event = dep; h->last_x_stream = sF; h->last_x_event = dep; h->x_done[slot] = dep;
+        HIP_TRY(h, hipStreamWaitEvent(sR, dep, 0));
+        if ((e = run(ST_RDS, sR, launch_stage_rds, h->ev_X[slot])) != hipSuccess) return fail(h, FMD_ERR_DEVICE, "k_rds_sync launch: %s", hipGetErrorString(e));
+        if (dep != h->ev_X[slot]) HIP_TRY(h, hipEventRecord(h->ev_X[slot], sR));
+        h->last_block_deemph = false;
+        h->slot_used[slot] = true;
+        h->sub_slot = slot;
+        h->out_slot = slot; h->have_out = true; h->out_block = h->n_blocks;
+        h->n_blocks++;
+        h->chain_blocks++; h->last_block_chain = true;
+        h->last_stream = s;
+        poison.armed = false;
+        return FMD_OK;
+    }
+    h->last_block_chain = false;
     hipEvent_t input_done = nullptr;               // fires when the caller's buffer has been consumed
     if (predecim) {
         SlotRef r = ref;
@@ -1050,6 +1098,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     h->lazy_capable = h->pipelined && h->ctx.fast && (size_t)d.C * d.n_fm_out >= (size_t)1024 * 8192 && !dev_env("FMD_NO_LAZY_EXTRACT");
     h->lazy_extract = h->lazy_capable;
     h->no_fused_pll = dev_env("FMD_NO_FUSED_PLL") != nullptr;
+    h->chain_off = dev_env("FMD_CHAIN") == nullptr;
     h->pll_eager = dev_env("FMD_PLL_EAGER") != nullptr;
     if (dev_env("FMD_FRONT_OWN_QUEUE")) h->front_with_predecim = false;
 
@@ -1641,6 +1690,20 @@ int fmd_debug_split_front(fmd_handle h, int on) {
     return FMD_OK;
 }
 
+int fmd_debug_set_chain(fmd_handle h, int on) {
+    if (!h) return FMD_ERR_ARG;
+    int rc = fmd_synchronize(h);
+    if (rc) return rc;
+    h->chain_off = on == 0;
+    return FMD_OK;
+}
+
+int fmd_debug_chain_blocks(fmd_handle h, long* blocks) {
+    if (!h || !blocks) return FMD_ERR_ARG;
+    *blocks = h->chain_blocks;
+    return FMD_OK;
+}
+
 int fmd_profile_enable(fmd_handle h, int on) {
     if (!h) return FMD_ERR_ARG;
     h->profiling = on < 0 ? 0 : (on > 3 ? 3 : on);
@@ -1661,6 +1724,7 @@ int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out) {
             const char* nm = h->ctx.fast ? kStageNameFast[i] : kStageName[i];
             if (h->ctx.fast && i == ST_EXTRACT && h->ctx.d.n_audio % 256 == 0) nm = "k_extract_bp";      // (round 5: fmd_kernels_bp.inc)
             if (i == ST_FRONT && front_takes_capture(h->ctx)) nm = "k_front_pre_mfma";
+            if (i == ST_FRONT && pm->chain) nm = "k_chain";                                             // (round 6: fmd_kernels_chain.inc)
             for (int j = 0; j < n; j++) if (std::strncmp(out[j].name, nm, sizeof(out[j].name)) == 0) { slot = j; break; }
             if (slot < 0) {
                 if (n >= cap) continue;

@@ -3000,6 +3000,24 @@ extern "C" int fmd_debug_read_x_probe2(unsigned long long* out16) {
 }
 namespace fmd {
 #endif
+}  // namespace fmd
+// development: how many k_chain workgroups the runtime places on one CU (registers, LDS)
+extern "C" int fmd_debug_chain_occupancy(void) {
+    int n = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fmd::k_chain, 320, fmd::ChainLds::BYTES) != hipSuccess) return -1;
+    return n;
+}
+namespace fmd {
+#ifdef FMD_C_PROBE
+}  // namespace fmd
+extern "C" int fmd_debug_read_c_probe(unsigned long long* out32) {
+    return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(fmd::g_c_probe), 32 * sizeof(unsigned long long));
+}
+extern "C" int fmd_debug_read_c_start(unsigned long long* out2048) {
+    return (int)hipMemcpyFromSymbol(out2048, HIP_SYMBOL(fmd::g_c_start), 2048 * sizeof(unsigned long long));
+}
+namespace fmd {
+#endif
 #ifdef FMD_RDS_PROBE
 }  // namespace fmd
 extern "C" int fmd_debug_read_rds_probe(unsigned long long* out16) {
@@ -3011,9 +3029,8 @@ namespace fmd {
 // RDS stage follows as before.  chain_possible: what the kernel's geometry needs of the configuration (the host adds what it needs of the
 // block: no start-up block, no de-emphasis, one set of cut-offs for all stations — fmd_api.cpp).
 bool chain_possible(const LaunchCtx& ctx) {
-    static const bool off = dev_env("FMD_NO_CHAIN") != nullptr;      // (A/B hook)
     const Dims& d = ctx.d;
-    return ctx.fast && d.m == 1 && !ctx.keep_taps && !ctx.b.fm_out_iq[0] && d.n_fm_out % 1024 == 0 && d.n_audio % 256 == 0 && d.tail_base >= 64 && !off;
+    return ctx.fast && d.m == 1 && !ctx.keep_taps && !ctx.b.fm_out_iq[0] && d.n_fm_out % 1024 == 0 && d.n_audio % 256 == 0 && d.tail_base >= 64;
 }
 hipError_t launch_stage_chain(const LaunchCtx& ctx, SlotRef r, const void* d_iq, hipStream_t s) {
     const Dims& d = ctx.d;
@@ -3031,7 +3048,9 @@ hipError_t launch_stage_chain(const LaunchCtx& ctx, SlotRef r, const void* d_iq,
     a.lmr_est_prev = lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr;
     a.field_cur = lmr_field(r.par); a.field_prev = lmr_field(r.par ^ 1); a.rds_pow = b.rds_pow[r.buf];
     a.spec_stats = b.spec_stats;
-    FMD_LAUNCH(r, true, true, k_chain, dim3((unsigned)((d.C + ChainGeom::G - 1) / ChainGeom::G)), dim3(320), 0, s, d, a);
+    static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain), hipFuncAttributeMaxDynamicSharedMemorySize, ChainLds::BYTES);
+    if (lds_ok != hipSuccess) return lds_ok;
+    FMD_LAUNCH(r, true, true, k_chain, dim3((unsigned)((d.C + ChainGeom::G - 1) / ChainGeom::G)), dim3(320), ChainLds::BYTES, s, d, a);
     if (!lmr_inline(ctx)) {   // P_{b+1} behind block b (launch_stage_extract)
         if (ctx.fast && ctx.d.n_est <= kLmrInlineMax)
             hipLaunchKernelGGL(k_lmr_phase_fast, dim3((unsigned)ctx.d.C), dim3(kWave), 0, s, ctx.d, ctx.b.lmr_est[r.par], ctx.b.state, lmr_field(r.par),

@@ -75,6 +75,16 @@ int fmd_profile_enable(fmd_handle h, int on);
  * Between blocks only. */
 int fmd_debug_split_front(fmd_handle h, int on);
 int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out);
+/* Tolerance mode, 256 kSa/s cf32: on = 1 runs a steady block's front end, pilot stage and extract stage as ONE launch (k_chain,
+ * fm-radio_amd/csrc/fmd_kernels_chain.inc: fm_out, the pilot points' sums and the span cubics stay in LDS) instead of the three launches
+ * that are the default.  Round 6's measured A/B (profiles/round6/chain_*): 22 % fewer HBM bytes (832 MB a block
+ * against 1069), correct — within 1.1e-6 RMS of the three-launch form's audio, the same distance from the oracle — and SLOWER (0.268 ms against
+ * 0.237 without the RDS stage, 0.44 against 0.25 with it): two 80 KB workgroups per CU are all the LDS admits, ten wavefronts a CU do not
+ * hide the chain's latencies, and the RDS stage's workgroups take slots from a grid that needs every one of them.  Kept as a development switch and as the parity test of both forms.
+ * Between blocks only; both forms leave the same histories, so a handle may change between them at any block.
+ * fmd_debug_chain_blocks: how many blocks since create / reset ran as k_chain. */
+int fmd_debug_set_chain(fmd_handle h, int on);
+int fmd_debug_chain_blocks(fmd_handle h, long* blocks);
 
 #ifdef __cplusplus
 }
