@@ -349,7 +349,9 @@ __device__ __forceinline__ int2 raw_u8(const uchar2* __restrict__ in_c, const fl
     return make_int2((int)v.x - 127, (int)v.y - 127);
 }
 
-template <int TT, int WU, bool TIES = false>
+// DEM_READY (round 6, cf32 captures away from the block's start): the caller has written the discriminator output's bf16 halves itself — the phase
+// difference as ONE arctangent of x[n] conj(x[n-1]), straight from the loaded samples (discriminator_pairs below) — and has passed a barrier.
+template <int TT, int WU, bool TIES = false, bool DEM_READY = false>
 __device__ __forceinline__ void front_from_phases(const Dims& d, float* smem, const float* theta, uint32_t* dem32, int c, int o0, int tid, float fm_gain,
                                                   const float* __restrict__ deemph, const FrontOps& op, float* __restrict__ fo_pl,
                                                   float4* __restrict__ pv_pl, const PllSparseTab* __restrict__ sp,
@@ -365,7 +367,7 @@ __device__ __forceinline__ void front_from_phases(const Dims& d, float* smem, co
     unsigned long long fp_t = __builtin_readcyclecounter();
 #endif
     // phase difference, wrap, scale: two samples per thread and step, split into bf16 halves, in place over the phases
-    {
+    if constexpr (!DEM_READY) {
         const float gain_t = fm_gain * bits_f32(kTwoPiBits);           // the discriminator's gain per turn
         constexpr int NPW = G::NWB / 2;                              // words per half
         constexpr int PERP = (NPW + 255) / 256;
@@ -403,7 +405,7 @@ __device__ __forceinline__ void front_from_phases(const Dims& d, float* smem, co
         }
     }
     F_STAMP(3);
-    __syncthreads();
+    if constexpr (!DEM_READY) __syncthreads();
     F_STAMP(4);
     // a3: decimate-by-2 FIR: wavefront w takes the 16-column tiles w, w + 4, ... (a column = 16 consecutive outputs).
     // fm_out goes to its plane undelayed (the rows start with the previous block's tail, k_pll_sparse); the consumers delay it by 32
@@ -526,6 +528,58 @@ __global__ __launch_bounds__(256, FUSED ? 6 : 5) void k_front_mfma(Dims d, const
 #endif
     // a0-a2: staging, arctangent (all loads first)
     bool staged = false;
+// Round 6 A/B (profiles/round6/front_conj_ab.txt): the cf32 discriminator as one arctangent of x[n] conj(x[n-1]) straight from
+// the loaded samples (no phase array in LDS, one barrier in the tile instead of three) against round 5's two arctangents through LDS: same
+// results to 1e-6, and SLOWER — k_front_mfma 0.163 ms against 0.152 in the step (4096 stations), 0.348 against 0.32 at 8192: the 8-byte load
+// of the sample in front of every pair is one more vector-memory instruction per two samples on a kernel that already keeps the memory pipe
+// and the vector ALU busy together, and what it saves (LDS round trips, two barriers) was hidden by the six workgroups a CU holds.
+// Kept behind the macro; k_chain (fmd_kernels_chain.inc) uses the form where it has no LDS for a phase array.
+#ifndef FMD_FRONT_CONJ
+#define FMD_FRONT_CONJ 0
+#endif
+#if FMD_FRONT_CONJ
+    if constexpr (sizeof(InT) == 8) {
+        // cf32 input away from the block's start (round 6): the discriminator's phase difference as ONE arctangent of
+        // x[n] conj(x[n-1]) — the reference takes the two samples' arctangents and wraps their difference (fm_demod.cpp:30-45): the same angle,
+        // in (-1/2, 1/2] turns by construction — straight from the loaded samples: word w of the output (elements 2 w, 2 w + 1) needs the
+        // tile's samples 2 w, 2 w + 1, 2 w + 2 = the 16-byte pair at the even block sample g_lo + 2 w + 1 and the 8 bytes in front of it.  No
+        // phase array in LDS (one write and 1.5 reads per sample), no wrap, and one barrier in the tile instead of three.
+        if (tile != 0) {
+            constexpr int NWORD = (NW - 1 + 1) / 2;                       // 1055 words hold the NW - 1 differences (the last word's second element is 0)
+            constexpr int PERW = NWORD / 256, RESTW = NWORD - 256 * PERW;  // (1024-sample tiles: four full rounds and 31 words for the first lanes)
+            const float gain_t = fm_gain * bits_f32(kTwoPiBits);
+            uint32_t* dem_hi32 = reinterpret_cast<uint32_t*>(smem);
+            uint32_t* dem_lo32 = dem_hi32 + G::NWB / 2;
+            const float2* base = in_c + (g_lo + 1);                       // (even sample: 16-byte aligned)
+            float4 qb[PERW + 1]; float2 pb[PERW + 1];
+#pragma unroll
+            for (int r = 0; r < PERW; r++) { const int w = tid + 256 * r; qb[r] = ld_stream(reinterpret_cast<const float4*>(base + 2 * w)); pb[r] = base[2 * w - 1]; }
+            if (tid < RESTW) { const int w = 256 * PERW + tid; qb[PERW] = ld_stream(reinterpret_cast<const float4*>(base + 2 * w)); pb[PERW] = base[2 * w - 1]; }
+            auto pair = [&](const float4& q, const float2& p, int w) __attribute__((always_inline)) {
+                const float re0 = fmaf(q.x, p.x, q.y * p.y), im0 = fmaf(q.y, p.x, -(q.x * p.y));        // x[2w+1] conj(x[2w])
+                const float re1 = fmaf(q.z, q.x, q.w * q.y), im1 = fmaf(q.w, q.x, -(q.z * q.y));        // x[2w+2] conj(x[2w+1])
+                const float d0 = fast_atan2_turns(im0, re0) * gain_t;
+                const float d1 = (2 * w + 1 < NW - 1) ? fast_atan2_turns(im1, re1) * gain_t : 0.0f;
+                uint32_t h0, l0, h1, l1;
+                split_bf16(d0, h0, l0); split_bf16(d1, h1, l1);
+                dem_hi32[w] = pack_hi16(h0, h1); dem_lo32[w] = pack_hi16(l0, l1);
+            };
+#pragma unroll
+            for (int r = 0; r < PERW; r++) pair(qb[r], pb[r], tid + 256 * r);
+            if (tid < RESTW) pair(qb[PERW], pb[PERW], 256 * PERW + tid);
+            else if (256 * PERW + tid < G::NWB / 2) { dem_hi32[256 * PERW + tid] = 0u; dem_lo32[256 * PERW + tid] = 0u; }      // (the padding under the zero taps)
+            F_STAMP(0);
+            __syncthreads();
+            F_STAMP(1);
+            front_from_phases<TT, WU, false, true>(d, smem, theta, reinterpret_cast<uint32_t*>(smem), c, o0, tid, fm_gain, deemph, op, fo_pl, pv_pl, sp);
+            if (tile == tiles - 1) {
+                float2* tout = tail_out + (size_t)c * d.tail_base;
+                for (int idx = tid; idx < d.tail_base; idx += 256) tout[idx] = load_iq(in_c, (unsigned)(d.N - d.tail_base + idx));
+            }
+            return;
+        }
+    }
+#else      // (round 5's form, kept for the A/B: tools/build_variant.sh name "-DFMD_FRONT_CONJ=0")
     if constexpr (sizeof(InT) == 8) {
         // cf32 input away from the block's start: 16 bytes per lane (two samples).  The tile starts at an odd sample (TAIL is odd): the
         // pairs start one sample earlier, pair q = samples 2 q - 1 and 2 q of the tile; what is left behind the full rounds, one per thread.
@@ -549,6 +603,7 @@ __global__ __launch_bounds__(256, FUSED ? 6 : 5) void k_front_mfma(Dims d, const
             staged = true;
         }
     }
+#endif
     if constexpr (sizeof(InT) == 2 && (NW + 1) / 8 >= 256) {
         // u8 input away from the block's start: 16 bytes per lane are eight samples (the tile starts at sample 1 of such a group:
         // octet o = samples 8 o - 1 .. 8 o + 6 of the tile); one full round, the rest one sample per thread.
