@@ -691,7 +691,7 @@ def main() -> None:
         # side's for the dominant kernel's launch, every side is printed beside it (and for the whole step in `whole_step`).
         sides = roof_sides(fs, args.u8, C * block, avg_ms * 1e-3)
         step_sides = roof_sides(fs, args.u8, C * block * K, el) if world == 1 else None
-        side = sides[sides["bound"]]
+        side = sides["mfma_bf16x3" if sides["bound"] == "mfma" else "hbm"]
         meta = traffic_meta()
         stamp = kernel_source_stamp()
         roofline = {"bound": sides["bound"], "kernel": dom[0], "achieved": side["achieved"], "peak": side["peak"], "unit": side["unit"],
