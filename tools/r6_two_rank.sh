@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 6: the multi-GPU path's baseline on the one-GPU box — two ranks sharing cuda:0 (`bench.py --gpus 2 --share-gpu`), every gather
-# mode, with `gather_verified` and what the gather costs the step (against `--gather none`).  No scaling figure: the first real 8-GPU run has
+# mode, with `gather_verified` and what the gather costs the step (against `--gather none`).  Two ranks on one device cannot form an RCCL communicator ("Duplicate GPU
+# detected"): the collective runs over gloo here — plumbing and bookkeeping, not xGMI; libfmdgather.so's same-device rotation is covered by tests/test_multi_gpu_host.py below.  No scaling figure: the first real 8-GPU run has
 # these lines to diverge from.  Output: gpurun_out/r6_two_rank/.
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 export GPU_MAX_HW_QUEUES=8 HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -9,7 +10,7 @@ P=29540
 for mode in none rotate root all; do
   for ch in 2048 4096; do
     P=$((P + 1))
-    python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $P bench.py --gpus 2 --share-gpu --channels $ch --gather $mode --steps 40 --warmup 3 \
+    python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $P bench.py --gpus 2 --share-gpu --backend gloo --channels $ch --gather $mode --steps 40 --warmup 3 \
       2> $O/err_${mode}_$ch.txt | tail -1 > $O/line_${mode}_$ch.json
     python3 - $O/line_${mode}_$ch.json $mode $ch <<'PY' | tee -a $O/summary.jsonl
 import json, sys
