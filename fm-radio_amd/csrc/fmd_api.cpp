@@ -800,7 +800,7 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
             h->consumer_pending[slot] = false;
         }
         const int nx = (slot + 1) % kSlots;      // (the block writes the histories in front of the next slot's rows: see the pilot stage below)
-        if (h->slot_used[nx] && h->x_done[nx] && h->last_x_stream != sF) HIP_TRY(h, hipStreamWaitEvent(sF, h->x_done[nx], 0));
+        if (h->slot_used[nx] && h->x_done[nx]) HIP_TRY(h, hipStreamWaitEvent(sF, h->x_done[nx], 0));      // (whichever queue that extract stage ran on)
         if (h->last_p_event && h->last_p_stream != sF) HIP_TRY(h, hipStreamWaitEvent(sF, h->last_p_event, 0));
         if (h->last_x_event && h->last_x_stream != sF) HIP_TRY(h, hipStreamWaitEvent(sF, h->last_x_event, 0));
         SlotRef r = ref;
