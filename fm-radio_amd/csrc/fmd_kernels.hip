@@ -161,6 +161,17 @@ __device__ __forceinline__ uint4 ld_stream(const uint4* p) {
     return *p;
 #endif
 }
+// (A/B, -DFMD_NT_MID=1: the planes one kernel writes and the next reads ONCE — fm_out into the extract stage — with non-temporal loads)
+#ifndef FMD_NT_MID
+#define FMD_NT_MID 0
+#endif
+__device__ __forceinline__ float4 ld_mid(const float4* p) {
+#if FMD_NT_MID
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p)); return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
 __device__ __forceinline__ void st_stream(float4* p, const float4& v) {
 #if FMD_NT_OUT
     __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f4*>(p));
@@ -1117,7 +1128,7 @@ __device__ __forceinline__ ChunkRegsC chunk_load_c(const float2* __restrict__ ba
     const int lane = threadIdx.x & (kWave - 1), row = lane >> 4, col = lane & 15;
     ChunkRegsC r;
 #define FMD_LD(k) { int ch = c0 + 4 * k + row; ch = ch < C ? ch : C - 1; \
-                    r.v##k = *reinterpret_cast<const float4*>(base + (size_t)ch * n + t0 + 2 * col); }
+                    r.v##k = ld_mid(reinterpret_cast<const float4*>(base + (size_t)ch * n + t0 + 2 * col)); }
     FMD_FOR16(FMD_LD)
 #undef FMD_LD
     return r;
