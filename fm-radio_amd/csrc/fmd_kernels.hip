@@ -3114,7 +3114,8 @@ hipError_t launch_stage_chain(const LaunchCtx& ctx, SlotRef r, const void* d_iq,
     a.lmr_est_prev = lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr;
     a.field_cur = lmr_field(r.par); a.field_prev = lmr_field(r.par ^ 1); a.rds_pow = b.rds_pow[r.buf];
     a.spec_stats = b.spec_stats;
-    static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain), hipFuncAttributeMaxDynamicSharedMemorySize, ChainLds::BYTES);
+    // (more than 64 KB of dynamic LDS has to be asked for; per call: a process may drive several devices)
+    const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain), hipFuncAttributeMaxDynamicSharedMemorySize, ChainLds::BYTES);
     if (lds_ok != hipSuccess) return lds_ok;
     FMD_LAUNCH(r, true, true, k_chain, dim3((unsigned)((d.C + ChainGeom::G - 1) / ChainGeom::G)), dim3(320), ChainLds::BYTES, s, d, a);
     if (!lmr_inline(ctx)) {   // P_{b+1} behind block b (launch_stage_extract)
