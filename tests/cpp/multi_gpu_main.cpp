@@ -9,6 +9,10 @@
 //   fmd_get_audio / fmd_get_rds_bytes return (PCM16: the reference scraper's conversion of it, fm_scraper.cpp:79-82).
 //   Pass 2, fresh handles, two blocks in flight ahead of the collector: the gathered blocks must equal pass 1's bit for bit.
 //   failrank: a third pass in which one rank's submission fails: Collect() throws and the host tears down (abort path).
+//   misuse: the C ABI directly, one rank: a second fmd_gather_submit without a new block and a skipped block are REFUSED
+//       (FMD_ERR_ARG; each on a fresh gather); a handle reset between two blocks (fmd_outputs_epoch changes) is re-based and gathers on.
+//       (A handle under fmd_set_output_lag whose stages are put off — 1024 stations and more — shows block k - 1: the same refusal, covered
+//       without a GPU by tests/cpp/gather_plan_main.cpp; batches this small queue every block at submission and gather normally.)
 //   Prints one JSON line; exit code 0 only if everything matched.
 #include <chrono>
 #include <cstdio>
@@ -30,8 +34,8 @@ int main(int argc, char** argv) {
     const std::string path = argv[1];
     const int R = atoi(argv[2]), C = atoi(argv[3]), N = atoi(argv[4]), fs = atoi(argv[5]), nb = atoi(argv[6]);
     const bool pcm = std::string(argv[7]) == "pcm16", loopback = atoi(argv[8]) != 0;
-    bool fast = false, rotate = false, failrank = false;
-    for (int i = 9; i < argc; i++) { fast = fast || std::string(argv[i]) == "fast"; rotate = rotate || std::string(argv[i]) == "rotate"; failrank = failrank || std::string(argv[i]) == "failrank"; }
+    bool fast = false, rotate = false, failrank = false, misuse = false;
+    for (int i = 9; i < argc; i++) { fast = fast || std::string(argv[i]) == "fast"; rotate = rotate || std::string(argv[i]) == "rotate"; failrank = failrank || std::string(argv[i]) == "failrank"; misuse = misuse || std::string(argv[i]) == "misuse"; }
     FILE* fp = fopen(path.c_str(), "rb");
     if (!fp) return 2;
     std::vector<uint8_t> data((size_t)R * C * nb * N * 2);
@@ -143,7 +147,42 @@ int main(int argc, char** argv) {
             teardown_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (threw != 1) mismatches2 += 1000;
         }
-        printf("{\"failed_rank_threw\": %d, \"failed_rank_run_ms\": %.1f, ", threw, teardown_ms);
+        // Pass 4 (misuse): what fmd_gather_submit must refuse, and the one renumbering it must follow
+        int misuse_ok = -1;
+        if (misuse) {
+            misuse_ok = 1;
+            auto scenario = [&](int kind) -> bool {      // 0: repeated submit, 1: skipped block, 3: reset between blocks (must WORK)
+                HIPC(hipSetDevice(devs[0]));
+                fmd_handle h = nullptr;
+                fmd_config cfg{C, N, fs, devs[0], dflags};
+                if (fmd_create(&cfg, &h) != FMD_OK) return false;
+                const int one_dev[1] = {devs[0]};
+                fmd_gather_config gc{1, one_dev, 0, fmt, gflags & FMD_GATHER_LOOPBACK_RCCL};
+                fmd_gather g = nullptr;
+                if (fmd_gather_create(&gc, &h, &g) != FMD_OK) { fmd_destroy(h); return false; }
+                const void* va; const uint8_t* vb; const int* vc; int vcap;
+                bool ok = true;
+                auto block = [&](int b) { return fmd_submit_u8_dev(h, d_in[0][(size_t)b], C, N, nullptr) == FMD_OK; };
+                if (kind == 0) {
+                    ok = ok && block(0) && fmd_gather_submit(g, 0) == FMD_OK && fmd_gather_wait(g, &va, &vb, &vc, &vcap) == FMD_OK;
+                    ok = ok && fmd_gather_submit(g, 0) == FMD_ERR_ARG;                       // the same block again
+                } else if (kind == 1) {
+                    ok = ok && block(0) && block(1) && fmd_gather_submit(g, 0) == FMD_ERR_ARG;      // block 1 is not the gather's block 0
+                } else {
+                    ok = ok && block(0) && fmd_gather_submit(g, 0) == FMD_OK && fmd_gather_wait(g, &va, &vb, &vc, &vcap) == FMD_OK;
+                    ok = ok && fmd_reset(h) == FMD_OK;
+                    ok = ok && block(1) && fmd_gather_submit(g, 0) == FMD_OK && fmd_gather_wait(g, &va, &vb, &vc, &vcap) == FMD_OK;     // the handle's block 0 again, the gather's block 1
+                    ok = ok && block(2) && fmd_gather_submit(g, 0) == FMD_OK && fmd_gather_wait(g, &va, &vb, &vc, &vcap) == FMD_OK;
+                }
+                if (kind != 3) fmd_gather_abort(g);
+                fmd_gather_destroy(g);
+                fmd_destroy(h);
+                return ok;
+            };
+            for (int kind : {0, 1, 3}) if (!scenario(kind)) { misuse_ok = 0; fprintf(stderr, "misuse scenario %d\n", kind); }
+            if (misuse_ok != 1) mismatches2 += 1000;
+        }
+        printf("{\"misuse_handled\": %d, \"failed_rank_threw\": %d, \"failed_rank_run_ms\": %.1f, ", misuse_ok, threw, teardown_ms);
         printf("\"ranks\": %d, \"devices\": %d, \"stations_per_rank\": %d, \"blocks\": %d, \"format\": \"%s\", \"loopback_rccl\": %s, \"rotate\": %s, \"lockstep_mismatches\": %ld, "
                "\"pipelined_mismatches\": %ld, \"rds_bytes_gathered\": %ld, \"remote_bytes_per_block\": %zu}\n",
                R, ndev, C, nb, pcm ? "pcm16" : "f32", loopback ? "true" : "false", rotate ? "true" : "false", mismatches, mismatches2, bytes_total, remote);

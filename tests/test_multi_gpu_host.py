@@ -87,3 +87,24 @@ def test_a_failed_rank_turns_into_an_error_not_a_hang(tmp_path, ranks, loopback,
                        capture_output=True, text=True, timeout=120)
     info = json.loads(r.stdout.strip().splitlines()[-1])
     assert info["failed_rank_threw"] == 1 and info["failed_rank_run_ms"] < 60_000, (info, r.stderr[-1000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loopback", [0, 1])
+def test_gather_refuses_a_repeated_and_a_skipped_block_and_follows_a_reset(tmp_path, loopback):
+    """fmd_gather_submit tells a handle whose numbering RESTARTED (fmd_reset: fmd_outputs_epoch changes — re-based, the
+    gather goes on) from a second submit without a new block and from a skipped block (both FMD_ERR_ARG; round 5 inferred the restart from
+    "block <= last" and waved the first through; a lagged handle's "block before" is the same refusal: tests/test_gather_plan_cpu.py).  Through the C ABI, one rank, copy hand-over and
+    RCCL loop-back; the bookkeeping alone runs without a GPU in tests/test_gather_plan_cpu.py."""
+    import fmradio_loader
+    fmradio_loader.load().load_library()
+    exe = build_driver(tmp_path)
+    c_local, bs, fs, nb = 4, 16384, 256_000, 4
+    base = np.stack([synth.to_u8(synth.fm_capture(nb * bs, fs=float(fs), seed=5800, channel=c)["iq"]) for c in range(2)])
+    caps = base[np.arange(c_local) % 2]
+    f = tmp_path / "caps.u8"
+    np.ascontiguousarray(caps).tofile(f)
+    r = subprocess.run([str(exe), str(f), "1", str(c_local), str(bs), str(fs), str(nb), "pcm16", str(loopback), "fast", "misuse"], capture_output=True, text=True, timeout=300)
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["misuse_handled"] == 1, (info, r.stderr[-1500:])
+    assert r.returncode == 0, r.stderr[-1500:]
