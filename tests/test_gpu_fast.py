@@ -556,3 +556,58 @@ def test_one_launch_form_of_a_steady_block_matches_the_three_launch_form(pkg):
     assert worst["one_vs_three"] <= 5e-6 and worst["mixed_vs_three"] <= 5e-6, worst        # (measured 1.2e-6)
     assert worst["one_vs_oracle"] <= TOL_RMS and worst["one_vs_oracle"] <= 1.25 * worst["three_vs_oracle"] + 2e-6, worst
     record_parity_metrics("one_launch_form_k_chain_11_stations_12_blocks", worst)
+    # Repetition on fresh handles, 64 stations (8 workgroups: beside the RDS stage's workgroup of the block before, whose LDS they inherit): the
+    # kernel must not depend on what it finds in LDS — round 6 found quad 303 of a window (behind its last sample, under zero taps) unwritten:
+    # 0 x a NaN pattern left by another kernel made column 15 of every tile NaN on 3 of 4 runs on some boxes and never on others
+    caps64 = caps[np.arange(64) % n_ch][:, :4 * bs]
+    blocks = [torch.from_numpy(np.ascontiguousarray(caps64[:, b * bs:(b + 1) * bs])).cuda() for b in range(4)]
+    def short(chain):
+        dm = pkg.BatchDemod(64, bs, fs, fast_math=True)
+        out = []
+        for b in range(4):
+            dm.set_chain(chain)
+            assert dm.submit(blocks[b]) == 0
+            dm.synchronize()
+            out.append((dm.audio().reshape(64, -1).copy(), dm.rds_symbols()[1].copy()))
+        dm.close()
+        return out
+    ref = short(False)
+    for rep in range(8):
+        got = short(True)
+        for b in range(4):
+            assert not np.isnan(got[b][0]).any(), (rep, b)
+            assert rms(got[b][0].astype(np.float64) - ref[b][0]) <= 5e-6 and np.array_equal(got[b][1], ref[b][1]), (rep, b)
+
+
+def test_one_launch_form_leaves_a_complete_state(pkg):
+    """fmd_get_state / fmd_set_state across k_chain blocks: a station's state taken after four one-launch blocks and restored into another
+    handle (other batch size, other block parity, three-launch form) continues bit-identically to what the FIRST handle produces when IT goes
+    on in the three-launch form — i.e. the one-launch form keeps every history the other form reads (IQ tail, fm_out tail, the pilot points'
+    last columns, the last span's cubic, the loop state, the L-R estimates) — through fmd_process_* (the caller's stream ordered behind the
+    library's read) as well as fmd_submit_*."""
+    import torch
+    fs, bs, nb = 256_000, 16384, 9
+    caps = _caps(9, nb * bs, float(fs), seed=9800)
+    a = pkg.BatchDemod(9, bs, fs, fast_math=True)
+    a.set_chain(True)
+    for b in range(5):                                   # block 0: start-up (three launches); 1 .. 4 as k_chain, alternately submitted and processed
+        t = torch.from_numpy(np.ascontiguousarray(caps[:, b * bs:(b + 1) * bs])).cuda()
+        assert (a.process(t) if b % 2 else a.submit(t)) == 0
+    a.synchronize()
+    assert a.chain_blocks() == 4
+    blob = a.get_state(7)
+    a.set_chain(False)
+    other = _caps(3, 2 * bs, float(fs), seed=9801)
+    bdm = pkg.BatchDemod(3, bs, fs, fast_math=True)
+    for b in range(2):
+        bdm.process(other[:, b * bs:(b + 1) * bs])
+    bdm.set_state(1, blob)
+    for b in range(5, nb):
+        a.process(caps[:, b * bs:(b + 1) * bs])
+        x = np.ascontiguousarray(other[:, :bs]).copy()
+        x[1] = caps[7, b * bs:(b + 1) * bs]
+        bdm.process(x)
+        assert np.array_equal(a.audio()[7].view(np.uint32), bdm.audio()[1].view(np.uint32)), b
+        sa, ca = a.rds_symbols(); sb, cb = bdm.rds_symbols()
+        assert ca[7] == cb[1] and np.array_equal(sa[7, :ca[7]].view(np.uint32), sb[1, :cb[1]].view(np.uint32)), b
+    a.close(); bdm.close()
