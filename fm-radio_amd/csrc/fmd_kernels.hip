@@ -2805,6 +2805,15 @@ static hipError_t launch_front(const LaunchCtx& ctx, SlotRef r, const InT* d_iq,
         if (ctx.fast) return launch_front<InT, TT, true>(ctx, r, d_iq, s, pll);
     }
     if constexpr (TT == 512) {
+        if constexpr (FAST && sizeof(InT) == 8) {
+            // cf32 captures, round 6: 2048-output tiles for batches that still give the chip 12 288 workgroups (3072 stations' worth of 64 ms blocks) —
+            // half as many workgroups fetch the FIR's operand images (7 KB each from L2: 230 MB a block at 1024-output tiles) and recompute a
+            // tile's 63-sample halo: k_front_mfma 0.154 -> 0.142 ms in the step, 268 -> 278 GSa/s at 4096 stations, +2.5 % at 8192; at 2048 stations
+            // (8192 workgroups) 1024-output tiles are 1 % better (profiles/round6/front_tile_ab.txt).  FMD_FRONT_CF32_TILE (development builds) forces one.
+            static const int forced = dev_env("FMD_FRONT_CF32_TILE") ? atoi(dev_env("FMD_FRONT_CF32_TILE")) : 0;
+            const bool big = forced ? forced == 2048 : (long)d.C * (d.n_fm_out / 2048) >= 12288;
+            if (big && d.n_fm_out % 2048 == 0 && !ctx.deemph_in_tile) return launch_front<InT, 2048, FAST>(ctx, r, d_iq, s, pll);
+        }
         if constexpr (FAST && sizeof(InT) == 2) {   // u8 captures: 2048-output tiles (4 KB of input per 1024-output workgroup leaves too few bytes in flight per CU)
             static const bool t1024 = dev_env("FMD_FRONT_U8_T1024") != nullptr;      // (A/B hook)
             if (d.n_fm_out % 2048 == 0 && !ctx.deemph_in_tile && !t1024) return launch_front<InT, 2048, FAST>(ctx, r, d_iq, s, pll);
