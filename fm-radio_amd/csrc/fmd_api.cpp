@@ -348,6 +348,7 @@ int upload_controls(fmd_handle h, hipStream_t s) {
         HIP_TRY(h, hipStreamSynchronize(s));
         h->uniform_cutoffs = true;
         for (int c = 1; c < C; c++) if (idx[(size_t)c * 2] != idx[0] || idx[(size_t)c * 2 + 1] != idx[1]) { h->uniform_cutoffs = false; break; }
+        h->ctx.uniform_cutoffs = h->uniform_cutoffs ? 1 : 0;
     }
     HIP_TRY(h, hipMemcpyAsync(b.b_lpr, lpr.data(), lpr.size() * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(b.b_lmr, lmr.data(), lmr.size() * 4, hipMemcpyHostToDevice, s));
@@ -1695,6 +1696,14 @@ int fmd_debug_set_chain(fmd_handle h, int on) {
     int rc = fmd_synchronize(h);
     if (rc) return rc;
     h->chain_off = on == 0;
+    return FMD_OK;
+}
+
+int fmd_debug_extract_pairing(fmd_handle h, int mode) {
+    if (!h || mode < 0 || mode > 2) return FMD_ERR_ARG;
+    int rc = fmd_synchronize(h);
+    if (rc) return rc;
+    h->ctx.extract_pairing = mode;
     return FMD_OK;
 }
 

@@ -229,6 +229,8 @@ struct LaunchCtx {
     int deemph_in_tile;     // FMD_FLAG_FAST_MATH: the de-emphasis IIR runs inside k_front's tile (every filtering channel's pole <= 0.905, i.e. up to ~79 us)
     int split_front;        // fmd_debug_split_front: 1.024 / 2.048 MSa/s tolerance mode with k_predecim_mfma and k_front_mfma as two kernels (the parity check of k_front_pre_mfma)
     int bytes_cap;
+    int uniform_cutoffs;                  // every station has the same L+R / L-R cut-offs: one set of k_extract_bp's tap tables serves any of them
+    int extract_pairing;                  // k_extract_bp with two stations per workgroup: 0 = where it pays (launch_extract_ta), 1 = wherever possible (tests), 2 = never
     int pll_time_parallel_max_channels;   // batches up to this size use the time-parallel PLL kernel, larger ones the low-work one
     int pll_k16_max_channels;             // (channels x m) up to this: 16 lanes per channel, above: 8
 };

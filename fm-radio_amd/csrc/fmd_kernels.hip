@@ -3021,9 +3021,19 @@ static void launch_extract_ta(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
         constexpr int kNtMax = 0x7fff;
         for (int v = (tiles + 3) / 4 < kNtMax ? (tiles + 3) / 4 : kNtMax; v >= 1; v--) if ((long)((tiles + 4 * v - 1) / (4 * v)) * d.C >= 1536) { nt = v; break; }
         if (const char* e = dev_env("FMD_BP_NT")) { const int v = atoi(e); if (v > 0 && v <= kNtMax) nt = v; }      // (development A/B)
-        const int grid_x = (tiles + 4 * nt - 1) / (4 * nt) * d.C;
+        int grid_x = (tiles + 4 * nt - 1) / (4 * nt) * d.C;
+        // round 6: two stations per workgroup (tables and the block edge's matrix fetched once for both) where a station is one workgroup anyway,
+        // every station has the same cut-offs and the pairs still are 1536 workgroups; ctx.extract_pairing: 1 forces it (tests), 2 switches it off
+        const bool one_wg_per_station = 4 * nt >= tiles;
+        const bool pair = ctx.uniform_cutoffs && one_wg_per_station && 2 * tiles <= 4 * kNtMax && d.C >= 2 &&
+                          (ctx.extract_pairing == 1 || (ctx.extract_pairing == 0 && (d.C + 1) / 2 >= 1536 && !dev_env("FMD_BP_NOPAIR")));
+        if (pair) { nt = (2 * tiles + 3) / 4; grid_x = (d.C + 1) / 2; }
         if (dev_env("FMD_BP_NOEDGE")) nt |= 0x10000;                     // (development, timing only: the first tile's sums over the previous block skipped)
-        FMD_LAUNCH(r, true, true, k_extract_bp, dim3((unsigned)grid_x), dim3(TA), 0, s, d, nt, b.fo_pl[r.buf], b.pll_poly[r.buf],
+        if (pair) FMD_LAUNCH(r, true, true, k_extract_bp<2>, dim3((unsigned)grid_x), dim3(TA), 0, s, d, nt, b.fo_pl[r.buf], b.pll_poly[r.buf],
+                   b.bp_tab, b.aud_idx, b.rds_bp_tab, b.bp_edge, b.mix,
+                   b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est[r.par], b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps,
+                   lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr, lmr_field(r.par), lmr_field(r.par ^ 1), b.rds_pow[r.buf]);
+        else FMD_LAUNCH(r, true, true, k_extract_bp<1>, dim3((unsigned)grid_x), dim3(TA), 0, s, d, nt, b.fo_pl[r.buf], b.pll_poly[r.buf],
                    b.bp_tab, b.aud_idx, b.rds_bp_tab, b.bp_edge, b.mix,
                    b.state, b.audio[r.buf], b.rds[r.buf], b.lmr_est[r.par], b.lpr[r.buf], b.lmr[r.buf], ctx.keep_taps,
                    lmr_inline(ctx) ? b.lmr_est[r.par ^ 1] : (const float*)nullptr, lmr_field(r.par), lmr_field(r.par ^ 1), b.rds_pow[r.buf]);

@@ -84,6 +84,9 @@ int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out);
  * Between blocks only; both forms leave the same histories, so a handle may change between them at any block.
  * fmd_debug_chain_blocks: how many blocks since create / reset ran as k_chain. */
 int fmd_debug_set_chain(fmd_handle h, int on);
+/* Tolerance mode: k_extract_bp with two stations per workgroup (the tap tables and the block edge's matrix fetched once for both; results bit-identical):
+ * 0 = where it pays (3072 stations and more with equal cut-offs, the default), 1 = wherever possible (so that tests reach it with a few stations), 2 = never. */
+int fmd_debug_extract_pairing(fmd_handle h, int mode);
 int fmd_debug_chain_blocks(fmd_handle h, long* blocks);
 
 #ifdef __cplusplus

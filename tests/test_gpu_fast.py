@@ -611,3 +611,41 @@ def test_one_launch_form_leaves_a_complete_state(pkg):
         sa, ca = a.rds_symbols(); sb, cb = bdm.rds_symbols()
         assert ca[7] == cb[1] and np.array_equal(sa[7, :ca[7]].view(np.uint32), sb[1, :cb[1]].view(np.uint32)), b
     a.close(); bdm.close()
+
+
+@pytest.mark.parametrize("n_ch", [6, 7])
+def test_extract_stage_with_two_stations_per_workgroup_is_bit_identical(pkg, n_ch):
+    """k_extract_bp<2> (round 6: tap tables and the block edge's matrix fetched once for two stations; the default from 3072 stations on) against
+    one station per workgroup: every output bit for bit, over the block edge (S_old), acquisition and an odd station count (the last
+    workgroup then has one station); stations with different cut-offs fall back to one per workgroup."""
+    fs, bs, nb = 256_000, 16384, 5
+    caps = _caps(n_ch, nb * bs, float(fs), seed=9900)
+    outs = {}
+    for mode in (1, 2):
+        dm = pkg.BatchDemod(n_ch, bs, fs, fast_math=True)
+        dm.set_extract_pairing(mode)
+        au, sy = [], []
+        for b in range(nb):
+            assert dm.process(np.ascontiguousarray(caps[:, b * bs:(b + 1) * bs])) == 0
+            au.append(dm.audio().copy()); s_, c_ = dm.rds_symbols(); sy.append((s_.copy(), c_.copy()))
+            if b == 2: lm = dm.stream("lmr_est").copy()
+        outs[mode] = (np.stack(au), sy, lm, dm.rds_bytes()[0].copy())
+        dm.close()
+    assert np.array_equal(outs[1][0].view(np.uint32), outs[2][0].view(np.uint32))
+    assert np.array_equal(outs[1][2].view(np.uint32), outs[2][2].view(np.uint32)) and np.array_equal(outs[1][3], outs[2][3])
+    for (sa, ca), (sb, cb) in zip(outs[1][1], outs[2][1]):
+        assert np.array_equal(ca, cb) and all(np.array_equal(sa[c, :ca[c]].view(np.uint32), sb[c, :cb[c]].view(np.uint32)) for c in range(n_ch))
+    # different cut-offs on one station: pairing is refused by the launcher (tables are per cut-off), outputs as without the request
+    from fm_radio_amd.capi import default_controls
+    dm = pkg.BatchDemod(n_ch, bs, fs, fast_math=True)
+    dm.set_extract_pairing(1)
+    ctl = default_controls(); ctl.lmr_cutoff_hz = 9000
+    dm.set_controls(ctl, 1)
+    ref = pkg.BatchDemod(n_ch, bs, fs, fast_math=True)
+    ref.set_extract_pairing(2)
+    ref.set_controls(ctl, 1)
+    for b in range(2):
+        blk = np.ascontiguousarray(caps[:, b * bs:(b + 1) * bs])
+        assert dm.process(blk) == 0 and ref.process(blk) == 0
+        assert np.array_equal(dm.audio().view(np.uint32), ref.audio().view(np.uint32))
+    dm.close(); ref.close()
