@@ -424,7 +424,7 @@ class BatchDemod:
         a = np.zeros(8, np.uint64)
         self._check(self.L.fmd_get_spec_stats(self.h, a.ctypes.data_as(C.c_void_p), 1 if reset else 0))
         out = {"pll": {"chunks": int(a[0]), "serial_chunks": int(a[1]), "exact_spans": int(a[2]), "spans": int(a[3]), "samples": int(a[4]),
-                       "samples_per_span": float(a[4]) / float(a[3]) if a[3] else 0.0}}
+                       "samples_per_span": float(a[4]) / float(a[3]) if a[3] else 0.0, "sequence_spans": int(a[5])}}
         if a[7]:
             out["pll_clock_mhz"] = float(a[6]) / float(a[7]) * 100.0
         return out

@@ -585,7 +585,7 @@ int zero_history(fmd_handle h, hipStream_t s) {
     }
     HIP_TRY(h, launch_reset_state(h->ctx, s));
     // everything is idle here (callers synchronise first): restart the per-wavefront PLL hand-over chain, watchdog flag included
-    if (b.pll_chain) HIP_TRY(h, hipMemsetAsync(b.pll_chain, 0, sizeof(unsigned) * ((size_t)h->pll_waves + 1), s));
+    if (b.pll_chain) HIP_TRY(h, hipMemsetAsync(b.pll_chain, 0, sizeof(unsigned) * (2 * (size_t)h->pll_waves + 1), s));      // (and the body hints behind it)
     h->pll_seq = 0;
     h->n_blocks = 0;
     h->warm_left = h->ctx.fast ? (int)((8192 + d.n_fm_out - 1) / d.n_fm_out) : 0;     // kPllWarmSamples of every station's life
@@ -1196,7 +1196,8 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     // (FMD_FLAG_KEEP_TAPS: k_pll_taps reads the loop's start state ahead of the PLL kernel — consecutive blocks' launches stay in stream order)
     h->pll_chained = h->pipelined && !h->ctx.fast && !h->ctx.keep_taps && time_parallel && effective_channels(d) <= 3328 && !(cfg->flags & (FMD_FLAG_PLL_STREAM_ORDER | FMD_FLAG_PLL_LOW_WORK));
     h->pll_waves = (effective_channels(d) <= h->ctx.pll_k16_max_channels) ? (d.C + 3) / 4 : (d.C + 7) / 8;
-    if (!rc) rc = dev_alloc(h, &b.pll_chain, (size_t)h->pll_waves + 1);
+    if (!rc) rc = dev_alloc(h, &b.pll_chain, 2 * (size_t)h->pll_waves + 1);
+    if (!rc) b.pll_hint = b.pll_chain + h->pll_waves + 1;
     if (rc) return bail(rc);
     rc = zero_history(h, h->own_stream);
     if (!rc) rc = upload_controls(h, h->own_stream);

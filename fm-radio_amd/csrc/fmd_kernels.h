@@ -210,6 +210,7 @@ struct Buffers {
     uint4*  bp_edge;                 // ... per cut-off slot [31 outputs][8 lanes][6] (fp16 pairs): the matrix of the block's first outputs' sums over the previous block's samples
     uint4*  front_mfma;              // FMD_FLAG_FAST_MATH only: Toeplitz operand images of k_front_mfma's two FIRs, [fir][k-step][hi/lo][lane]; m > 1: then k_predecim_mfma's
     unsigned int* pll_chain;         // [wavefronts of k_pilot_pll + 1] last block number each wavefront completed; [last] = watchdog flag
+    unsigned int* pll_hint;          // [wavefronts of k_pilot_pll] 1: the wavefront's stations left the previous block out of lock (it runs the kernel's sequence-capable body)
     unsigned long long* spec_stats;  // [8] speculation counters: pll {chunks, general, replayed, -}, rds {chunks, general, replayed, -}
 };
 

@@ -33,6 +33,7 @@
 #include "fmd_kernels.h"
 #include <hip/hip_ext.h>
 #include <cstdlib>
+#include <type_traits>
 #include "fmd_math.h"
 
 // launch with the stage's timing events attached to the dispatch packet when the caller asked for them
@@ -1332,8 +1333,13 @@ __global__ __launch_bounds__(kWave) void k_pll_taps(Dims d, const float2* __rest
 // with the reference forms.  (D) runs the integrator unclamped and checks at both ends of the span that the clamp could not
 // have acted (it moves < 4e-6 per sample); otherwise the span is verified with the exact predicated loop.
 //
-// A wavefront out of lock (acquisition, a station without pilot) commits ~1 sample per span; after a chunk that needed more
-// than 24 spans the wavefront runs the next chunks with the plain serial iteration (pll_step), backing off exponentially.
+// A loop out of lock (acquisition, a station without pilot) commits ~1 sample per span under that assumption.  Round 3: after a
+// chunk that needed more than 3x the fewest spans the wavefront runs the next chunks with the plain serial iteration (pll_step),
+// backing off exponentially — 3.7-3.9 ms a block for a batch with ANY such station against 0.76 in lock.  Round 6: the word still
+// moves by only a few ulp a sample, so such a wavefront speculates on the SEQUENCE of words instead (a cheap guess pass, then the
+// exact pass confirms word by word: pilot_pll_body's span, seq): K samples a span at ~1.8x a span's cost, 1.4-1.9 ms a block.
+// The kernel holds two bodies — round 3's unchanged for wavefronts whose stations held lock through the previous block, the
+// sequence-capable one for the others (Buffers::pll_hint, written by the wavefront itself) — so the all-locked batch pays nothing.
 //
 // Layout: one wavefront = 64 / K channels x K lanes (K = 16 or 8), one workgroup = one wavefront (12.6 KB LDS and 128 VGPRs
 // at K = 16: fits any hole a retiring FIR workgroup leaves; 24.8 KB and 169 VGPRs at K = 8).  128-sample chunks; LDS rings of two chunks per channel for the pilot samples and the
@@ -1391,17 +1397,16 @@ static constexpr int kSlowHoldMax = 16;       // longest run of serial chunks be
 // K = lanes (= consecutive samples) per channel.  K = 16 gives the shortest latency (4 channels per wavefront, 1024 wavefronts
 // for 4096 channels); K = 8 spends 30 % fewer VALU instructions (8 channels per wavefront share the serial parts) for ~25 %
 // more latency — better as soon as the chip, not a lone wavefront, is the limit.
-template <int K>
-__global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
-                                                     float* __restrict__ state, LoopCoeffs k, int power_field,
-                                                     unsigned long long* __restrict__ spec_stats,
-                                                     unsigned int* __restrict__ chain, unsigned int seq) {
+template <int K, bool SEQCAP>
+__device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
+                                               float* __restrict__ state, LoopCoeffs k, int power_field,
+                                               unsigned long long* __restrict__ spec_stats,
+                                               unsigned int* __restrict__ chain, unsigned int seq, unsigned int* __restrict__ hint,
+                                               float2 (*xin)[kPllRing], float (*dts)[kPllRing], float (*ex)[K + 4], float (*e1x)[K + 4], float (*fsq)[K + 4]) {
     constexpr int G = kWave / K, CH = kPllChunk, RING = kPllRing;
     constexpr int kPllSlowSpans = 3 * CH / K;     // a chunk that needed more spans than this is "out of lock"
-    __shared__ __attribute__((aligned(16))) float2 xin[G][RING];   // pilot samples, ring by (sample index & 255)
-    __shared__ __attribute__((aligned(16))) float dts[G][RING];    // results, same ring
-    __shared__ __attribute__((aligned(16))) float ex[G][K + 4];    // [0] = err_prev, [1 + i] = err_i of the current span
-    __shared__ __attribute__((aligned(16))) float e1x[G][K + 4];   // fma(err_i, b1, 0)
+    constexpr int kPllStuckSpans = 16;            // sequence-form spans in a row that committed one sample: serial chunks next
+    constexpr int kPllSeqSpans = (22 * CH) / (10 * K);
     __builtin_amdgcn_s_setprio(3);  // latency-bound recurrence: win issue arbitration against co-resident FIR waves
     const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
     const int lane = threadIdx.x, g = lane / K, j = lane % K;
@@ -1465,6 +1470,10 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
     int seq_left = 0, hold = 0;  // wave-uniform: serial chunks still to run / back-off
     unsigned long long n_exact = 0, n_seq = 0;   // wave-uniform counters (scalar registers)
     int n_spans = 0;
+    bool seq_form = false;       // (SEQCAP) wave-uniform: the spans run in the sequence form (below)
+    unsigned long long n_seq_spans = 0;
+    if constexpr (!SEQCAP) {
+    // ---- the constant-word form with the serial fall-back (round 3), for a wavefront whose stations all held lock through the previous block ----
     for (int q = 0; q < chunks; q++) {
         const int cend = (q + 1) * CH;
         int spans = 0;
@@ -1593,24 +1602,259 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
             else hold = 0;
         }
     }
+    } else {
+    // ---- the same with the sequence form for loops out of lock (round 6), for a wavefront that left the previous block out of lock ----
+    int stuck = 0;               // wave-uniform: consecutive sequence-form spans in which some channel committed one sample
+    // One span of every channel of the wavefront: (A)-(D) above.
+    // seq (round 6) — the form for a loop OUT of lock (a station without a pilot, acquisition): the frequency word then moves on every sample
+    // and a span under "F stays put" commits one sample, which is why such a wavefront used to fall back to the 78-operation serial
+    // iteration for whole chunks (4 ms a block: the exact mode's cliff).  But the word moves by only a few ulp a sample —
+    // it is the heavily low-passed error scaled by 1e-2 x 1e2 next to -19000, one ulp = 2^-9 Hz is a radian of phase error — and a
+    // phase that is wrong by those few ulp x Ts changes the next errors by 1e-6 rad, the word by 1e-6 of an ulp.  So the span is
+    // evaluated twice: a GUESS pass (constant F, hardware sine / cosine, minimax arctangent, the loop filter) whose only product is the
+    // sequence of words F_0 .. F_{K-1}, and the EXACT pass — (B) stepping the phase with that sequence, (C) in the reference's forms,
+    // (D) confirming word by word that the filter state behind sample i-1 yields exactly the F_i the phase was stepped with.  The
+    // induction is the same as for a constant word (sample 0's word is exact by construction), so is the commit; a wrong guess costs
+    // samples, never bits.  ~2.3 spans' worth of instructions per K samples instead of K serial iterations.
+    // One body with a wave-uniform flag, not two instantiations: the exact pass IS the reference-forms branch the other form falls back to
+    // (with the kernel's code doubled, the rare excursions into the second copy cost an all-locked batch 12 %: instruction cache).
+    // Returns (wave-uniform, seq only): few — some channel committed one sample; calm — no channel's guessed words changed more than twice
+    // inside the span, i.e. "F stays put" would have done about as well.
+    auto span = [&](const bool seq, const int cend, bool& few, bool& calm) __attribute__((always_inline)) {
+        const bool active = pos < cend;
+        const int rem = n - pos;                             // samples left in the block for this channel
+        // (A) S_0 = U(state, err_prev) and the exact frequency word of the span's first sample
+        float y1, ig;
+        {
+            const float t0 = fmaf(lx1, kc.b0, ly1 * kc.a0);
+            const float t1 = fmaf(err_prev, kc.b1, 0.0f);
+            y1 = (0.0f + t0) + t1;
+            ig = clampf(fmaf(err_prev, kc.ktsi, integ), -1.0f, 1.0f);
+        }
+        const float F = fmaf(clampf(ig + y1 * kc.c001, -1.0f, 1.0f), kc.m100, kc.m19000);
+        const int t = active ? pos + j : j;
+        const float2 x = xin[g][t & (RING - 1)];
+        const float p = gain * x.x, q2 = gain * x.y;
+        float Fq[K];                                         // seq: the word step i of (B) uses
+        float Fmine = F;                                     // ... and the one this lane's sample was stepped into with: what (D) confirms
+        float mine = 0.0f, e = 0.0f;
+        if (seq) {
+            // the guess pass
+            const float mg = fmaf((float)(j + 1), F * kc.ts, tph_prev);      // (the phase under a constant word, unwrapped: the hardware sine takes turns)
+            const float psg = fast_sin_turns(mg), pcg = fast_cos_turns(mg);
+            const float eg = fast_atan2f(fmaf(psg, p, q2 * pcg), fmaf(p, pcg, -(q2 * psg)));
+            ex[g][j + 1] = eg;
+            e1x[g][j] = fmaf(eg, kc.b1, 0.0f);
+            float gy1 = y1, gig = ig, gx1 = err_prev, my_gy1 = y1, my_gig = ig;
+#pragma unroll
+            for (int i = 1; i < K; i++) {
+                const float ei = ex[g][i], t1i = e1x[g][i - 1];
+                const float t0 = fmaf(gx1, kc.b0, gy1 * kc.a0);
+                gy1 = (0.0f + t0) + t1i; gx1 = ei;
+                gig = clampf(fmaf(ei, kc.ktsi, gig), -1.0f, 1.0f);
+                my_gy1 = (i == j) ? gy1 : my_gy1; my_gig = (i == j) ? gig : my_gig;
+            }
+            Fmine = fmaf(clampf(my_gig + my_gy1 * kc.c001, -1.0f, 1.0f), kc.m100, kc.m19000);    // (lane 0: S_0's word, F itself)
+            fsq[g][j] = Fmine;
+#pragma unroll
+            for (int i = 0; i < K; i++) Fq[i] = fsq[g][i];
+        }
+        bool reference_forms;
+        {
+            // (B) phase recurrence with the word(s); lane j keeps the phase after j+1 steps
+            float tph = tph_prev;
+#pragma unroll
+            for (int i = 0; i < K; i++) {
+                const float yy = fmaf(seq ? Fq[i] : F, kc.ts, tph);
+                tph = yy - rintf(yy);
+                mine = (i == j) ? tph : mine;
+            }
+            // (C) this lane's sample: phase detector with the short wraps and sines; the arctangent's short form for a loop in lock, the
+            // reference's in the sequence form (its operands are anywhere)
+            const float dc = mine + kc.q25;
+            const float dt_cos = dc - rintf(dc);
+            float zq_s, zq_c;
+            const float ps = cheb_sine_locked(mine, kc, zq_s), pc = cheb_sine_locked(dt_cos, kc, zq_c);
+            bool in_range = true;
+            const float res_im = fmaf(ps, p, q2 * pc), res_re = fmaf(p, pc, -(q2 * ps));
+            if (seq) e = fmd_atan2f(res_im, res_re);
+            else e = atan2f_locked(res_im, res_re, kc, in_range);
+            const bool lane_ok = in_range && (fminf(fabsf(zq_s), fabsf(zq_c)) != 0.0f);
+            // a short form was outside its domain somewhere (loop out of lock, or an exact tie): reference forms for all
+            reference_forms = __builtin_amdgcn_ballot_w64(active && !lane_ok && j < rem) != 0ull;
+        }
+        if (reference_forms) {
+            n_exact++;
+            float tp = tph_prev, mm = 0.0f;
+#pragma unroll
+            for (int i = 0; i < K; i++) { const float yy = fmaf(seq ? Fq[i] : F, kc.ts, tp); tp = yy - round_half_away(yy); mm = (i == j) ? tp : mm; }
+            float dcg = mm + 0.25f; dcg = dcg - round_half_away(dcg);
+            const float psg = cheb_sine_scalar(mm), pcg = cheb_sine_scalar(dcg);
+            e = fmd_atan2f(fmaf(psg, p, q2 * pcg), fmaf(p, pcg, -(q2 * psg)));
+            mine = mm;
+        }
+        ex[g][j + 1] = e;
+        e1x[g][j] = fmaf(e, kc.b1, 0.0f);
+        if (active) dts[g][t & (RING - 1)] = mine;           // speculative; samples past the commit point are rewritten
+        float ev[K], t1v[K];
+#pragma unroll
+        for (int i = 0; i < K; i++) { ev[i] = ex[g][i + 1]; t1v[i] = e1x[g][i]; }
+        // (D) loop filter over the span, identically in every lane of the channel; lane i keeps S_i = (y1_i, ig_i)
+        float fy1 = y1, fig = ig, fx1 = err_prev, my_y1 = y1, my_ig = ig;
+#pragma unroll
+        for (int i = 1; i < K; i++) {
+            const float t0 = fmaf(fx1, kc.b0, fy1 * kc.a0);
+            fy1 = (0.0f + t0) + t1v[i - 1]; fx1 = ev[i - 1];
+            fig = fmaf(ev[i - 1], kc.ktsi, fig);
+            my_y1 = (i == j) ? fy1 : my_y1; my_ig = (i == j) ? fig : my_ig;
+        }
+        // the integrator moves < 4e-6 per sample: its clamp acted nowhere in the span iff both ends are well inside
+        const bool integ_clamped = !((fabsf(ig) <= 0.99f) && (fabsf(fig) <= 0.99f));
+        const float Fj = fmaf(clampf(my_ig + my_y1 * kc.c001, -1.0f, 1.0f), kc.m100, kc.m19000);
+        const bool ok_j = (f32_bits(Fj) == f32_bits(Fmine)) && (j < rem);
+        const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok_j || j == 0);
+        int m = __builtin_ctz(~((unsigned int)(okm >> (g * K)) & ((1u << K) - 1u)) | (1u << K));   // first invalid sample (K = none)
+        float nx, ny, ni, ne, nt;
+        if (__builtin_amdgcn_ballot_w64(active && integ_clamped) != 0ull) {
+            // a saturated integrator (never in lock): verify with the exact clamps, predicated
+            float x1 = err_prev, yy1 = y1, ig2 = ig;
+            bool valid = true;
+            m = 1;
+            for (int i = 1; i < K; i++) {
+                const float ei = ex[g][i];
+                const float t0 = fmaf(x1, k.pll_b0, yy1 * k.pll_a0), t1 = fmaf(ei, k.pll_b1, 0.0f);
+                const float ny1 = (0.0f + t0) + t1;
+                const float ni1 = clampf(fmaf(ei, 0.1f * (1.0f / 128000.0f), ig2), -1.0f, 1.0f);
+                const float Fi = fmaf(clampf((ni1 + ny1 * 0.01f) * 1.0f, -1.0f, 1.0f), -100.0f, -19000.0f);
+                valid = valid && (f32_bits(Fi) == f32_bits(seq ? fsq[g][i] : F)) && (i < rem);
+                if (valid) { x1 = ei; yy1 = ny1; ig2 = ni1; m = i + 1; }
+            }
+            nx = x1; ny = yy1; ni = ig2; ne = ex[g][m]; nt = dts[g][(pos + m - 1) & (RING - 1)];
+        } else {
+            // resume state S_{m-1}, err_{m-1}, tph_{m-1}: held by lane m-1 of the channel
+            const int src = (g * K + m - 1) * 4;
+            ny = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_y1)));
+            ni = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(my_ig)));
+            ne = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(e)));
+            nt = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(mine)));
+            nx = ex[g][m - 1];                               // err_{m-2} (ex[g][0] = err_prev)
+        }
+        if (seq) {
+            few = __builtin_amdgcn_ballot_w64(active && m == 1 && rem > 1) != 0ull;
+            const float Fprev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Fmine), 0x111, 0xf, 0xf, true));      // row_shr:1 (a channel's lanes share a row)
+            const unsigned long long chg = __builtin_amdgcn_ballot_w64(active && j > 0 && f32_bits(Fmine) != f32_bits(Fprev));
+            calm = __builtin_amdgcn_ballot_w64(__builtin_popcount((unsigned int)(chg >> (g * K)) & ((1u << K) - 1u)) >= 3) == 0ull;
+        }
+        if (active) {
+            lx1 = nx; ly1 = ny; integ = ni; err_prev = ne; tph_prev = nt; pos += m;
+        }
+        ex[g][0] = err_prev;
+    };
+    for (int q = 0; q < chunks; q++) {
+        const int cend = (q + 1) * CH;
+        int spans = 0;
+        bool serial = seq_left > 0;
+        if (!serial) {
+            // Which form: "F stays put" until a chunk has taken kPllSeqSpans spans (2.2 x the fewest: on some channel that form commits fewer
+            // than K / 2.2 samples a span, what the sequence form costs) — the rest of the chunk and the following chunks in the sequence
+            // form, until a chunk's spans were calm three times out of four.  One scalar compare a span in the constant-word form.
+            // (Round 3's rule — a whole chunk of one-sample spans, then serial chunks with an exponential back-off and a speculative chunk
+            // to probe — spent a third of an unlocked wavefront's time in the probes.)
+            int seq_spans = 0, calm_spans = 0;
+            while (__builtin_amdgcn_ballot_w64(pos < cend) != 0ull) {
+                bool few = false, calm = false;
+                spans++;
+                const bool sq = seq_form;
+                span(sq, cend, few, calm);             // (one call site: one copy of the body)
+                if (!sq) {
+#ifndef FMD_PLL_NOSEQ
+                    if (spans >= kPllSeqSpans) seq_form = true;
+#endif
+                } else {
+                    seq_spans++;
+                    calm_spans += calm ? 1 : 0;
+                    stuck = few ? stuck + 1 : 0;
+                    if (stuck >= kPllStuckSpans) break;
+                }
+            }
+            n_seq_spans += (unsigned long long)seq_spans;
+            if (seq_form && stuck >= kPllStuckSpans) {
+                // one sample a span in the sequence form too (a guess pass that cannot predict the words: not seen on any signal of the tests;
+                // NaN input does it): the rest of this chunk and the next ones serially, doubling each time in a row
+                serial = true;
+                seq_left = 1 + (hold ? hold : 1); hold = hold ? (2 * hold < kSlowHoldMax ? 2 * hold : kSlowHoldMax) : 1; stuck = 0;
+            } else {
+                if (seq_form && seq_spans == spans && 4 * calm_spans >= 3 * seq_spans) seq_form = false;
+                if (spans <= kPllSlowSpans) hold = 0;
+            }
+        }
+        if (serial) {
+            // ---- neither form commits: the plain serial iteration, computed identically by the 16 lanes of a channel ----
+            seq_left--; n_seq++;
+            PllState S{lx1, ly1, integ, err_prev, tph_prev};
+            while (__builtin_amdgcn_ballot_w64(pos < cend) != 0ull) {
+                if (pos < cend) {
+                    const float2 x = xin[g][pos & (RING - 1)];
+                    dts[g][pos & (RING - 1)] = pll_step(S, gain * x.x, gain * x.y, k);
+                    pos++;
+                }
+            }
+            lx1 = S.lx1; ly1 = S.ly1; integ = S.integ; err_prev = S.err; tph_prev = S.tph;
+            ex[g][0] = err_prev;
+        }
+        // chunk q is final in every channel: drain it, refill its half of the ring with chunk q+2, prefetch chunk q+3
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        {   // results of chunk q
+            const float* row = &dts[g][(q & 1) * CH + 4 * j];
+            float* o = pll_dt + (size_t)cs * n + (size_t)q * CH + 4 * j;
+#define FMD_PLL_DRAIN(r) if constexpr (r < NST) { const float4 v_ = *reinterpret_cast<const float4*>(row + 4 * K * r); if (live) *reinterpret_cast<float4*>(o + 4 * K * r) = v_; }
+            FMD_PLL_EACH(FMD_PLL_DRAIN)
+        }
+        FMD_PLL_STASH(q + 2)
+        FMD_PLL_FETCH(q + 3)
+        n_spans += spans;
+    }
+    }
     if (live && j == 0) {
         st(state, S_AGC_PILOT_GAIN, d.C, c) = gain;
         st(state, S_PLL_X1, d.C, c) = lx1; st(state, S_PLL_Y1, d.C, c) = ly1;
         st(state, S_PLL_INT, d.C, c) = integ; st(state, S_PLL_ERR, d.C, c) = err_prev; st(state, S_PLL_T, d.C, c) = tph_prev;
     }
+    // which body the next block's launch runs for these stations: the sequence-capable one after a block that ended out of lock (or went serial)
+    // (back to the other body only after a block that never left the constant-word form: a loop that wanders in and out of lock keeps this one)
+    if (hint && lane == 0) hint[blockIdx.x] = (n_seq != 0ull || n_seq_spans != 0ull) ? 1u : 0u;
     if (chain) {   // publish: the state stores above, then the sequence number
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (lane == 0) __hip_atomic_store(&chain[blockIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (spec_stats) {
         // per wavefront: chunks / chunks run serially / spans redone with the reference forms; per channel: spans, samples
-        if (lane == 0) { atomicAdd(&spec_stats[0], (unsigned long long)chunks); atomicAdd(&spec_stats[1], n_seq); atomicAdd(&spec_stats[2], n_exact); }
+        if (lane == 0) { atomicAdd(&spec_stats[0], (unsigned long long)chunks); atomicAdd(&spec_stats[1], n_seq); atomicAdd(&spec_stats[2], n_exact); atomicAdd(&spec_stats[5], n_seq_spans); }
         // per channel: the spans its wavefront ran, and the samples they covered (every sample of a speculative chunk)
         if (live && j == 0) { atomicAdd(&spec_stats[3], (unsigned long long)n_spans); atomicAdd(&spec_stats[4], ((unsigned long long)chunks - n_seq) * CH); }
         // shader-clock cycles and 100 MHz real-time ticks this wavefront ran: their ratio is the core clock the power
         // management granted while the other stages' kernels ran beside it (DESIGN.md "Clocks")
         if (lane == 0 && blockIdx.x == 0) { atomicAdd(&spec_stats[6], __builtin_readcyclecounter() - clk0); atomicAdd(&spec_stats[7], __builtin_amdgcn_s_memrealtime() - rt0); }
     }
+}
+
+// The kernel: LDS, and which of the two bodies this wavefront's stations get (hint: written by the same wavefront of the previous block's launch).
+// Two bodies rather than one with both forms: the all-locked batch keeps round 3's code and its time to the instruction (one body holding
+// both forms cost it 5-18 %: branches and register moves in the constant-word span, and the instruction cache when single spans strayed
+// into the other form's copy); a wavefront runs one body for a whole block, so its loop stays resident.
+template <int K>
+__global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
+                                                     float* __restrict__ state, LoopCoeffs k, int power_field,
+                                                     unsigned long long* __restrict__ spec_stats,
+                                                     unsigned int* __restrict__ chain, unsigned int seq, unsigned int* __restrict__ hint) {
+    constexpr int G = kWave / K, RING = kPllRing;
+    __shared__ __attribute__((aligned(16))) float2 xin[G][RING];   // pilot samples, ring by (sample index & 255)
+    __shared__ __attribute__((aligned(16))) float dts[G][RING];    // results, same ring
+    __shared__ __attribute__((aligned(16))) float ex[G][K + 4];    // [0] = err_prev, [1 + i] = err_i of the current span
+    __shared__ __attribute__((aligned(16))) float e1x[G][K + 4];   // fma(err_i, b1, 0)
+    __shared__ __attribute__((aligned(16))) float fsq[G][K + 4];   // out of lock: the guessed frequency word of every sample of the span
+    if (hint && __builtin_amdgcn_readfirstlane((int)hint[blockIdx.x]) != 0) pilot_pll_body<K, true>(d, pilot, pll_dt, state, k, power_field, spec_stats, chain, seq, hint, xin, dts, ex, e1x, fsq);
+    else pilot_pll_body<K, false>(d, pilot, pll_dt, state, k, power_field, spec_stats, chain, seq, hint, xin, dts, ex, e1x, fsq);
 }
 
 // ===============================================================================================================
@@ -2989,10 +3233,10 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     unsigned int* chain = r.seq ? ctx.b.pll_chain : nullptr;
     if (effective_channels(d) <= ctx.pll_k16_max_channels) {
         FMD_LAUNCH(r, true, true, k_pilot_pll<16>, dim3((unsigned)((d.C + 3) / 4)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
-                   ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats, chain, r.seq);
+                   ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats, chain, r.seq, ctx.b.pll_hint);
     } else {
         FMD_LAUNCH(r, true, true, k_pilot_pll<8>, dim3((unsigned)((d.C + 7) / 8)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
-                   ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats, chain, r.seq);
+                   ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats, chain, r.seq, ctx.b.pll_hint);
     }
     return hipGetLastError();
 }

@@ -63,6 +63,7 @@ int fmd_design_wrap_tie(uint32_t* bits2048);
  * out8[0] = 128-sample chunks, summed over wavefronts (4 channels each); out8[1] = of those, chunks run with the plain serial
  * iteration (wavefront out of lock); out8[2] = spans redone with the reference forms (a short form outside its domain);
  * out8[3] = spans, out8[4] = samples committed, both summed over channels (ratio = samples per 16-sample span);
+ * out8[5] = spans run in the sequence form (a loop out of lock: the span speculates on the sequence of frequency words), summed over wavefronts;
  * out8[6], out8[7] = shader-clock cycles and 100 MHz real-time ticks of one wavefront per launch (ratio x 100 = core MHz).
  * Results never depend on any of them; they explain k_pilot_pll's duration. */
 int fmd_get_spec_stats(fmd_handle h, uint64_t* out8, int reset);

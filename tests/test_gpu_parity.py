@@ -359,6 +359,31 @@ def test_pll_speculation_commits_long_spans_in_lock_and_short_ones_before(pkg):
     assert sum(p["serial_chunks"] for p in locked) == 0
 
 
+@pytest.mark.parametrize("pll_kernel,k", [("time_parallel", 16), ("time_parallel8", 8)])
+def test_loops_out_of_lock_run_the_sequence_form_not_the_serial_iteration(pkg, pll_kernel, k):
+    """Round 6: a station that cannot hold lock moves its NCO frequency word on every sample, so "the word stays put" commits
+    one sample a span; its wavefront then speculates on the SEQUENCE of words (a guess pass, then the exact pass confirms word by word) and
+    commits whole spans again.  From the second block on (the first finds out, with round 3's serial fall-back): no serial chunks, the
+    sequence form on every span, nearly K samples per span — next to a normal station in the same wavefront, and bit-identical to the
+    oracle (the serial restatement of the reference)."""
+    nb, bs = 6, 16384
+    rows = [synth.to_cf32(synth.fm_capture(nb * bs, fs=256_000.0, seed=900 + c, channel=c, **kw)["iq"])
+            for c, kw in enumerate([{}, {"pilot_level": 0.0}, {"pilot_hz": 19130.0}])]
+    caps = np.stack(rows)
+    _assert_exact(compare_with_oracle(pkg, caps, bs, 256_000, pll_kernel=pll_kernel))
+    dm = pkg.BatchDemod(n_channels=3, block_size=bs, fs_baseband=256_000, pll_kernel=pll_kernel)
+    per_block = []
+    for b in range(nb):
+        dm.process(caps[:, b * bs:(b + 1) * bs])
+        per_block.append(dm.spec_stats(reset=True)["pll"])
+    dm.close()
+    assert per_block[0]["serial_chunks"] > 0 and per_block[0]["sequence_spans"] == 0        # the block that finds out
+    for p in per_block[1:]:
+        assert p["serial_chunks"] == 0, per_block
+        assert p["sequence_spans"] >= 0.95 * (bs // 2) / k, per_block                       # (one wavefront: its spans are the slowest station's)
+        assert p["samples_per_span"] > 0.9 * k, per_block
+
+
 def test_blocks_with_more_symbols_than_the_sign_buffer_holds(pkg):
     """k_rds_sync buffers the symbols' signs for the Manchester decoder in LDS, 1024 per station; a block of
     131072 samples at 256 kSa/s (8192 RDS samples, ~1200 symbols; ~1790 at the symbol clock's upper rail) overflows one buffer, so the
