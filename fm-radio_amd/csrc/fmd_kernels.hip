@@ -1406,7 +1406,7 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
     constexpr int G = kWave / K, CH = kPllChunk, RING = kPllRing;
     constexpr int kPllSlowSpans = 3 * CH / K;     // a chunk that needed more spans than this is "out of lock"
     constexpr int kPllStuckSpans = 16;            // sequence-form spans in a row that committed one sample: serial chunks next
-    constexpr int kPllSeqSpans = (22 * CH) / (10 * K);
+    constexpr int kPllSeqSpans = (18 * CH) / (10 * K);
     __builtin_amdgcn_s_setprio(3);  // latency-bound recurrence: win issue arbitration against co-resident FIR waves
     const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
     const int lane = threadIdx.x, g = lane / K, j = lane % K;
@@ -1618,9 +1618,9 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
     // samples, never bits.  ~2.3 spans' worth of instructions per K samples instead of K serial iterations.
     // One body with a wave-uniform flag, not two instantiations: the exact pass IS the reference-forms branch the other form falls back to
     // (with the kernel's code doubled, the rare excursions into the second copy cost an all-locked batch 12 %: instruction cache).
-    // Returns (wave-uniform, seq only): few — some channel committed one sample; calm — no channel's guessed words changed more than twice
-    // inside the span, i.e. "F stays put" would have done about as well.
-    auto span = [&](const bool seq, const int cend, bool& few, bool& calm) __attribute__((always_inline)) {
+    // Returns (wave-uniform, seq only): few — some channel committed one sample; changes — how often the guessed words changed inside the span on
+    // the channel where they changed most (up to 4): "F stays put" would have needed about 1 + changes spans for these samples.
+    auto span = [&](const bool seq, const int cend, bool& few, int& changes) __attribute__((always_inline)) {
         const bool active = pos < cend;
         const int rem = n - pos;                             // samples left in the block for this channel
         // (A) S_0 = U(state, err_prev) and the exact frequency word of the span's first sample
@@ -1717,17 +1717,20 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
         float nx, ny, ni, ne, nt;
         if (__builtin_amdgcn_ballot_w64(active && integ_clamped) != 0ull) {
             // a saturated integrator (never in lock): verify with the exact clamps, predicated
+            // (from the registers (D) already holds, unrolled: a loop on its rail — a pilot beyond the NCO's range, a dead channel's NaN —
+            // takes this path on every span, and the LDS reads of the rolled form were seven round trips a span)
             float x1 = err_prev, yy1 = y1, ig2 = ig;
             bool valid = true;
             m = 1;
+#pragma unroll
             for (int i = 1; i < K; i++) {
-                const float ei = ex[g][i];
-                const float t0 = fmaf(x1, k.pll_b0, yy1 * k.pll_a0), t1 = fmaf(ei, k.pll_b1, 0.0f);
-                const float ny1 = (0.0f + t0) + t1;
-                const float ni1 = clampf(fmaf(ei, 0.1f * (1.0f / 128000.0f), ig2), -1.0f, 1.0f);
-                const float Fi = fmaf(clampf((ni1 + ny1 * 0.01f) * 1.0f, -1.0f, 1.0f), -100.0f, -19000.0f);
-                valid = valid && (f32_bits(Fi) == f32_bits(seq ? fsq[g][i] : F)) && (i < rem);
-                if (valid) { x1 = ei; yy1 = ny1; ig2 = ni1; m = i + 1; }
+                const float ei = ev[i - 1];
+                const float t0 = fmaf(x1, kc.b0, yy1 * kc.a0);
+                const float ny1 = (0.0f + t0) + t1v[i - 1];
+                const float ni1 = clampf(fmaf(ei, kc.ktsi, ig2), -1.0f, 1.0f);
+                const float Fi = fmaf(clampf((ni1 + ny1 * kc.c001) * 1.0f, -1.0f, 1.0f), kc.m100, kc.m19000);
+                valid = valid && (f32_bits(Fi) == f32_bits(seq ? Fq[i] : F)) && (i < rem);
+                x1 = valid ? ei : x1; yy1 = valid ? ny1 : yy1; ig2 = valid ? ni1 : ig2; m = valid ? i + 1 : m;
             }
             nx = x1; ny = yy1; ni = ig2; ne = ex[g][m]; nt = dts[g][(pos + m - 1) & (RING - 1)];
         } else {
@@ -1743,7 +1746,9 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
             few = __builtin_amdgcn_ballot_w64(active && m == 1 && rem > 1) != 0ull;
             const float Fprev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(Fmine), 0x111, 0xf, 0xf, true));      // row_shr:1 (a channel's lanes share a row)
             const unsigned long long chg = __builtin_amdgcn_ballot_w64(active && j > 0 && f32_bits(Fmine) != f32_bits(Fprev));
-            calm = __builtin_amdgcn_ballot_w64(__builtin_popcount((unsigned int)(chg >> (g * K)) & ((1u << K) - 1u)) >= 3) == 0ull;
+            const int nchg = __builtin_popcount((unsigned int)(chg >> (g * K)) & ((1u << K) - 1u));      // this channel's words changed that often in the span
+            changes = (__builtin_amdgcn_ballot_w64(nchg >= 1) != 0ull) + (__builtin_amdgcn_ballot_w64(nchg >= 2) != 0ull) +
+                      (__builtin_amdgcn_ballot_w64(nchg >= 3) != 0ull) + (__builtin_amdgcn_ballot_w64(nchg >= 4) != 0ull);
         }
         if (active) {
             lx1 = nx; ly1 = ny; integ = ni; err_prev = ne; tph_prev = nt; pos += m;
@@ -1755,24 +1760,26 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
         int spans = 0;
         bool serial = seq_left > 0;
         if (!serial) {
-            // Which form: "F stays put" until a chunk has taken kPllSeqSpans spans (2.2 x the fewest: on some channel that form commits fewer
-            // than K / 2.2 samples a span, what the sequence form costs) — the rest of the chunk and the following chunks in the sequence
-            // form, until a chunk's spans were calm three times out of four.  One scalar compare a span in the constant-word form.
+            // Which form: "F stays put" until a chunk has taken kPllSeqSpans spans (1.8 x the fewest: on some channel that form commits fewer
+            // than K / 1.8 samples a span, what a span of the sequence form costs) — the rest of the chunk and the following chunks in the
+            // sequence form, until over a whole chunk the other form would have needed clearly fewer than 1.8 spans per span of this one
+            // (1 + the changes of the guessed words).  One scalar compare a span in the constant-word form.
             // (Round 3's rule — a whole chunk of one-sample spans, then serial chunks with an exponential back-off and a speculative chunk
             // to probe — spent a third of an unlocked wavefront's time in the probes.)
-            int seq_spans = 0, calm_spans = 0;
+            int seq_spans = 0, chg_sum = 0;
             while (__builtin_amdgcn_ballot_w64(pos < cend) != 0ull) {
-                bool few = false, calm = false;
+                bool few = false;
+                int changes = 0;
                 spans++;
                 const bool sq = seq_form;
-                span(sq, cend, few, calm);             // (one call site: one copy of the body)
+                span(sq, cend, few, changes);          // (one call site: one copy of the body)
                 if (!sq) {
 #ifndef FMD_PLL_NOSEQ
                     if (spans >= kPllSeqSpans) seq_form = true;
 #endif
                 } else {
                     seq_spans++;
-                    calm_spans += calm ? 1 : 0;
+                    chg_sum += changes;
                     stuck = few ? stuck + 1 : 0;
                     if (stuck >= kPllStuckSpans) break;
                 }
@@ -1784,7 +1791,7 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
                 serial = true;
                 seq_left = 1 + (hold ? hold : 1); hold = hold ? (2 * hold < kSlowHoldMax ? 2 * hold : kSlowHoldMax) : 1; stuck = 0;
             } else {
-                if (seq_form && seq_spans == spans && 4 * calm_spans >= 3 * seq_spans) seq_form = false;
+                if (seq_form && seq_spans == spans && 10 * chg_sum < 4 * seq_spans) seq_form = false;
                 if (spans <= kPllSlowSpans) hold = 0;
             }
         }
