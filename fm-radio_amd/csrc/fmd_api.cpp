@@ -50,6 +50,16 @@ struct fmd_handle_s {
     hipStream_t last_stream = nullptr;
     hipStream_t sF = nullptr, sA = nullptr, sB = nullptr, sB2 = nullptr, sX = nullptr, sR = nullptr, sD = nullptr;   // sD: the optional de-emphasis stage
     unsigned pll_seq = 0;                    // k_pilot_pll launches handed over per wavefront so far (0: hand-over by stream order)
+    // exact mode, 3585 .. 4096 effective stations: the pilot-PLL kernel's lane count follows what is out of lock — 8 lanes a station while every
+    // loop holds lock (fewest instructions beside the FIR kernels), 16 while some do not (a loop out of lock costs its wavefront ~1.8x, and
+    // the kernel lasts as long as its slowest wavefront: 1.55 -> 1.12 ms a block with 16).  The kernel counts the wavefronts that ran out
+    // of lock (Buffers::pll_hint[C]); a 4-byte copy of the counter comes back every other block, and the host looks at it without waiting.
+    // The host may be queueing many blocks ahead of the GPU: what it goes by is the launch count that came back WITH the counter (16 lanes until
+    // the counter has stood still for 8 launches the host has SEEN; no news, no change).
+    bool pll_k_adaptive = false;
+    unsigned* pll_unl_host = nullptr;        // pinned: [0] counter, [1] launches
+    unsigned pll_unl_seen = 0, pll_done_seen = 0, pll_last_move = 0;
+    bool pll_moved_ever = false;
     bool pll_chained = false;
     int pll_waves = 0;
     hipEvent_t ev_in = nullptr, ev_P[kSlots] = {}, ev_F[kSlots] = {}, ev_A[kSlots] = {}, ev_B[kSlots] = {}, ev_E[kSlots] = {}, ev_X[kSlots] = {};
@@ -585,7 +595,9 @@ int zero_history(fmd_handle h, hipStream_t s) {
     }
     HIP_TRY(h, launch_reset_state(h->ctx, s));
     // everything is idle here (callers synchronise first): restart the per-wavefront PLL hand-over chain, watchdog flag included
-    if (b.pll_chain) HIP_TRY(h, hipMemsetAsync(b.pll_chain, 0, sizeof(unsigned) * (2 * (size_t)h->pll_waves + 1), s));      // (and the body hints behind it)
+    if (b.pll_chain) HIP_TRY(h, hipMemsetAsync(b.pll_chain, 0, sizeof(unsigned) * ((size_t)h->pll_waves + 1 + (size_t)d.C + 2), s));      // (and the body hints behind it)
+    if (h->pll_unl_host) h->pll_unl_host[0] = h->pll_unl_host[1] = 0u;
+    h->pll_unl_seen = h->pll_done_seen = h->pll_last_move = 0; h->pll_moved_ever = false; h->ctx.pll_k16_now = false;
     h->pll_seq = 0;
     h->n_blocks = 0;
     h->warm_left = h->ctx.fast ? (int)((8192 + d.n_fm_out - 1) / d.n_fm_out) : 0;     // kPllWarmSamples of every station's life
@@ -873,6 +885,16 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         hipEvent_t persistent = predecim ? h->ev_P[slot] : (h->ctx.any_deemph ? h->ev_D[slot] : h->ev_F[slot]);
         if ((input_done ? input_done : front_dep) != persistent) HIP_TRY(h, hipEventRecord(persistent, predecim ? sP : sFq));
         h->ev_consumed = persistent;
+    }
+    if (h->pll_k_adaptive) {
+        const unsigned done = reinterpret_cast<volatile unsigned*>(h->pll_unl_host)[1], v = reinterpret_cast<volatile unsigned*>(h->pll_unl_host)[0];
+        if (done != h->pll_done_seen) {
+            h->pll_done_seen = done;
+            if (v != h->pll_unl_seen) { h->pll_unl_seen = v; h->pll_last_move = done; h->pll_moved_ever = true; }
+            h->ctx.pll_k16_now = h->pll_moved_ever && done - h->pll_last_move < 8u;
+        }
+        // (no ordering against the PLL launches: both words only grow, whichever values the copy finds will do)
+        if ((h->n_blocks & 1) == 0) HIP_TRY(h, hipMemcpyAsync(h->pll_unl_host, h->ctx.b.pll_hint + h->ctx.d.C, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, sA));
     }
     if (!h->ctx.fast) {   // (FMD_FLAG_FAST_MATH: the pilot peak filter runs inside the PLL kernel, there is no power pass)
         if (pipe) HIP_TRY(h, hipStreamWaitEvent(sA, dep, 0));
@@ -1195,9 +1217,15 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     const bool time_parallel = d.C <= h->ctx.pll_time_parallel_max_channels;
     // (FMD_FLAG_KEEP_TAPS: k_pll_taps reads the loop's start state ahead of the PLL kernel — consecutive blocks' launches stay in stream order)
     h->pll_chained = h->pipelined && !h->ctx.fast && !h->ctx.keep_taps && time_parallel && effective_channels(d) <= 3328 && !(cfg->flags & (FMD_FLAG_PLL_STREAM_ORDER | FMD_FLAG_PLL_LOW_WORK));
-    h->pll_waves = (effective_channels(d) <= h->ctx.pll_k16_max_channels) ? (d.C + 3) / 4 : (d.C + 7) / 8;
-    if (!rc) rc = dev_alloc(h, &b.pll_chain, 2 * (size_t)h->pll_waves + 1);
+    h->pll_k_adaptive = !h->ctx.fast && time_parallel && !(cfg->flags & (FMD_FLAG_PLL_K8 | FMD_FLAG_PLL_LOW_WORK)) && effective_channels(d) > h->ctx.pll_k16_max_channels &&
+                        effective_channels(d) <= 4096 && !dev_env("FMD_PLL_K_FIXED");
+    h->pll_waves = (effective_channels(d) <= h->ctx.pll_k16_max_channels || h->pll_k_adaptive) ? (d.C + 3) / 4 : (d.C + 7) / 8;
+    if (!rc) rc = dev_alloc(h, &b.pll_chain, (size_t)h->pll_waves + 1 + (size_t)d.C + 2);
     if (!rc) b.pll_hint = b.pll_chain + h->pll_waves + 1;
+    if (!rc && !h->ctx.fast && time_parallel) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->pll_unl_host), 64, hipHostMallocDefault) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "pinned allocation failed");
+        else h->pll_unl_host[0] = h->pll_unl_host[1] = 0u;
+    }
     if (rc) return bail(rc);
     rc = zero_history(h, h->own_stream);
     if (!rc) rc = upload_controls(h, h->own_stream);
@@ -1220,6 +1248,7 @@ int fmd_destroy(fmd_handle h) {
     }
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->d_in) (void)hipFree(h->d_in);
+    if (h->pll_unl_host) (void)hipHostFree(h->pll_unl_host);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return FMD_OK;
@@ -1697,6 +1726,18 @@ int fmd_debug_set_chain(fmd_handle h, int on) {
     int rc = fmd_synchronize(h);
     if (rc) return rc;
     h->chain_off = on == 0;
+    return FMD_OK;
+}
+
+int fmd_debug_pll_lanes_adaptive(fmd_handle h, int k16_max_channels) {
+    if (!h || k16_max_channels < 0) return FMD_ERR_ARG;
+    if (h->ctx.fast || !h->pll_unl_host || h->ctx.d.C > h->ctx.pll_time_parallel_max_channels || effective_channels(h->ctx.d) > 4096) return fail(h, FMD_ERR_ARG, "the exact mode's time-parallel pilot-PLL kernel, up to 4096 stations");
+    int rc = fmd_synchronize(h);
+    if (rc) return rc;
+    h->ctx.pll_k16_max_channels = k16_max_channels;
+    h->pll_k_adaptive = effective_channels(h->ctx.d) > k16_max_channels;
+    h->pll_chained = false;                  // (the per-wavefront hand-over is indexed by wavefront: one lane count only)
+    h->pll_unl_seen = h->pll_unl_host[0]; h->pll_done_seen = h->pll_unl_host[1]; h->pll_moved_ever = false; h->ctx.pll_k16_now = false;
     return FMD_OK;
 }
 

@@ -1339,7 +1339,7 @@ __global__ __launch_bounds__(kWave) void k_pll_taps(Dims d, const float2* __rest
 // moves by only a few ulp a sample, so such a wavefront speculates on the SEQUENCE of words instead (a cheap guess pass, then the
 // exact pass confirms word by word: pilot_pll_body's span, seq): K samples a span at ~1.8x a span's cost, 1.4-1.9 ms a block.
 // The kernel holds two bodies — round 3's unchanged for wavefronts whose stations held lock through the previous block, the
-// sequence-capable one for the others (Buffers::pll_hint, written by the wavefront itself) — so the all-locked batch pays nothing.
+// sequence-capable one for the others (Buffers::pll_hint, per station, written by the wavefront itself) — so the all-locked batch pays nothing.
 //
 // Layout: one wavefront = 64 / K channels x K lanes (K = 16 or 8), one workgroup = one wavefront (12.6 KB LDS and 128 VGPRs
 // at K = 16: fits any hole a retiring FIR workgroup leaves; 24.8 KB and 169 VGPRs at K = 8).  128-sample chunks; LDS rings of two chunks per channel for the pilot samples and the
@@ -1829,7 +1829,16 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
     }
     // which body the next block's launch runs for these stations: the sequence-capable one after a block that ended out of lock (or went serial)
     // (back to the other body only after a block that never left the constant-word form: a loop that wanders in and out of lock keeps this one)
-    if (hint && lane == 0) hint[blockIdx.x] = (n_seq != 0ull || n_seq_spans != 0ull) ? 1u : 0u;
+    // (per station, so that the 16- and the 8-lane kernel can follow one another: fmd_api.cpp picks the lane count by what is out of lock)
+    if (hint) {
+        const unsigned int out = (n_seq != 0ull || n_seq_spans != 0ull) ? 1u : 0u;
+        if (live && j == 0) hint[c] = out;
+        // [C]: wavefronts that spent a quarter of a block or more out of lock, ever; [C + 1]: launches — the host watches the first move
+        // against the second (a chunk or two in the other form is what any loop does now and then: not counted)
+        const bool heavy = 4ull * n_seq >= (unsigned long long)chunks || 4ull * n_seq_spans >= (unsigned long long)(n_spans > 0 ? n_spans : 1);
+        if (heavy && lane == 0) atomicAdd(hint + d.C, 1u);
+        if (blockIdx.x == 0 && lane == 0) atomicAdd(hint + d.C + 1, 1u);
+    }
     if (chain) {   // publish: the state stores above, then the sequence number
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (lane == 0) __hip_atomic_store(&chain[blockIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1845,7 +1854,7 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
     }
 }
 
-// The kernel: LDS, and which of the two bodies this wavefront's stations get (hint: written by the same wavefront of the previous block's launch).
+// The kernel: LDS, and which of the two bodies this wavefront's stations get (hint: one flag per station, written by the previous block's launch).
 // Two bodies rather than one with both forms: the all-locked batch keeps round 3's code and its time to the instruction (one body holding
 // both forms cost it 5-18 %: branches and register moves in the constant-word span, and the instruction cache when single spans strayed
 // into the other form's copy); a wavefront runs one body for a whole block, so its loop stays resident.
@@ -1860,7 +1869,12 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
     __shared__ __attribute__((aligned(16))) float ex[G][K + 4];    // [0] = err_prev, [1 + i] = err_i of the current span
     __shared__ __attribute__((aligned(16))) float e1x[G][K + 4];   // fma(err_i, b1, 0)
     __shared__ __attribute__((aligned(16))) float fsq[G][K + 4];   // out of lock: the guessed frequency word of every sample of the span
-    if (hint && __builtin_amdgcn_readfirstlane((int)hint[blockIdx.x]) != 0) pilot_pll_body<K, true>(d, pilot, pll_dt, state, k, power_field, spec_stats, chain, seq, hint, xin, dts, ex, e1x, fsq);
+    bool out_of_lock = false;
+    if (hint) {
+        const int c = blockIdx.x * G + (int)threadIdx.x / K;
+        out_of_lock = __builtin_amdgcn_ballot_w64(c < d.C && hint[c < d.C ? c : d.C - 1] != 0u) != 0ull;
+    }
+    if (out_of_lock) pilot_pll_body<K, true>(d, pilot, pll_dt, state, k, power_field, spec_stats, chain, seq, hint, xin, dts, ex, e1x, fsq);
     else pilot_pll_body<K, false>(d, pilot, pll_dt, state, k, power_field, spec_stats, chain, seq, hint, xin, dts, ex, e1x, fsq);
 }
 
@@ -3238,7 +3252,7 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
         return hipGetLastError();
     }
     unsigned int* chain = r.seq ? ctx.b.pll_chain : nullptr;
-    if (effective_channels(d) <= ctx.pll_k16_max_channels) {
+    if (effective_channels(d) <= ctx.pll_k16_max_channels || ctx.pll_k16_now) {
         FMD_LAUNCH(r, true, true, k_pilot_pll<16>, dim3((unsigned)((d.C + 3) / 4)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
                    ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats, chain, r.seq, ctx.b.pll_hint);
     } else {

@@ -26,11 +26,13 @@ def oracle_controls(ctl) -> O.Controls:
 
 
 def run_gpu(pkg, caps: np.ndarray, block_size: int, fs: int, use_torch: bool = False, controls=None, per_channel_controls=None,
-            pll_kernel: str = "auto", fast_math: bool = False, split_front: bool = False):
+            pll_kernel: str = "auto", fast_math: bool = False, split_front: bool = False, pll_k16_max=None):
     """caps: [C, n, 2] float32 or uint8.  Returns dict of per-block concatenated streams [C, ...]."""
     n_ch = caps.shape[0]
     nb = caps.shape[1] // block_size
     dm = pkg.BatchDemod(n_ch, block_size, fs, keep_taps=True, pll_kernel=pll_kernel, fast_math=fast_math)
+    if pll_k16_max is not None:       # (include/fmdemod_debug.h: the pilot-PLL kernel's lane count by what is out of lock, from this batch size on)
+        dm.pll_lanes_adaptive(pll_k16_max)
     if split_front:       # (include/fmdemod_debug.h: the first decimator and the front end as two kernels)
         assert dm.L.fmd_debug_split_front(dm.h, 1) == 0
     if controls is not None:
@@ -75,10 +77,10 @@ def run_gpu(pkg, caps: np.ndarray, block_size: int, fs: int, use_torch: bool = F
 
 
 def compare_with_oracle(pkg, caps: np.ndarray, block_size: int, fs: int, use_torch: bool = False, controls=None,
-                        per_channel_controls=None, pll_kernel: str = "auto") -> dict:
+                        per_channel_controls=None, pll_kernel: str = "auto", pll_k16_max=None) -> dict:
     n_ch = caps.shape[0]
     u8 = caps.dtype == np.uint8
-    g = run_gpu(pkg, caps, block_size, fs, use_torch, controls, per_channel_controls, pll_kernel)
+    g = run_gpu(pkg, caps, block_size, fs, use_torch, controls, per_channel_controls, pll_kernel, pll_k16_max=pll_k16_max)
     report = {"bit_exact": {}, "max_abs": {}, "audio_rms_err": 0.0, "rds_sym_equal_counts": True, "rds_bytes_equal": True}
     for c in range(n_ch):
         ctl = (per_channel_controls or {}).get(c, controls)
