@@ -11,6 +11,11 @@ run "fast u8" "--u8"
 run "exact u8" "--exact --u8"
 for p in 0.01 0.1 1.0; do run "fast unlocked $p" "--unlocked-frac $p"; done
 for p in 0.01 0.1 1.0; do run "exact unlocked $p" "--exact --unlocked-frac $p --steps 20"; done
+run "exact unlocked 0.1 zero" "--exact --unlocked-frac 0.1 --unlocked-kind zero --steps 20"
+run "exact unlocked 0.1 detuned" "--exact --unlocked-frac 0.1 --unlocked-kind detuned --steps 20"
+run "exact 8192 unlocked 0.01" "--exact --channels 8192 --unlocked-frac 0.01 --steps 20"
+run "exact 1024 unlocked 0.01" "--exact --channels 1024 --unlocked-frac 0.01 --steps 20"
+run "exact 1024" "--exact --channels 1024"
 run "fast unlocked 0.1 zero" "--unlocked-frac 0.1 --unlocked-kind zero"
 run "fast unlocked 0.25 detuned" "--unlocked-frac 0.25 --unlocked-kind detuned"
 run "fast unlocked 0.25 mix" "--unlocked-frac 0.25 --unlocked-kind mix"
