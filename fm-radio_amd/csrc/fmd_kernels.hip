@@ -1390,6 +1390,11 @@ __device__ __forceinline__ float atan2f_locked(float y, float x, const PllConsts
     return t - t * (s1 + s2);
 }
 
+template <int S>
+__device__ __forceinline__ float dpp_row_shr(float v) {      // lane l of a 16-lane row gets lane l - S's value (0 below the row's first lane)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + S, 0xf, 0xf, true));
+}
+
 static constexpr int kPllChunk = 128;         // samples per chunk (64 for the 8-lane variant, to halve its 24.5 KB of LDS, cost 10 % of the step)
 static constexpr int kPllRing = 2 * kPllChunk;
 static constexpr int kSlowHoldMax = 16;       // longest run of serial chunks between two speculation attempts
@@ -1620,6 +1625,13 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
     // (with the kernel's code doubled, the rare excursions into the second copy cost an all-locked batch 12 %: instruction cache).
     // Returns (wave-uniform, seq only): few — some channel committed one sample; changes — how often the guessed words changed inside the span on
     // the channel where they changed most (up to 4): "F stays put" would have needed about 1 + changes spans for these samples.
+    float sc_a[4], sc_1[4], sc_pw = 1.0f;                  // the scans' coefficients for this lane: shift s = 1, 2, 4, 8 reaches lane j - s of the same channel or nothing
+    {
+        float as = kc.a0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) { sc_a[t] = j >= (1 << t) ? as : 0.0f; sc_1[t] = j >= (1 << t) ? 1.0f : 0.0f; as = as * as; }
+        for (int t = 0; t < j; t++) sc_pw *= kc.a0;       // a0^j
+    }
     auto span = [&](const bool seq, const int cend, bool& few, int& changes) __attribute__((always_inline)) {
         const bool active = pos < cend;
         const int rem = n - pos;                             // samples left in the block for this channel
@@ -1643,17 +1655,20 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
             const float mg = fmaf((float)(j + 1), F * kc.ts, tph_prev);      // (the phase under a constant word, unwrapped: the hardware sine takes turns)
             const float psg = fast_sin_turns(mg), pcg = fast_cos_turns(mg);
             const float eg = fast_atan2f(fmaf(psg, p, q2 * pcg), fmaf(p, pcg, -(q2 * psg)));
-            ex[g][j + 1] = eg;
-            e1x[g][j] = fmaf(eg, kc.b1, 0.0f);
-            float gy1 = y1, gig = ig, gx1 = err_prev, my_gy1 = y1, my_gig = ig;
-#pragma unroll
-            for (int i = 1; i < K; i++) {
-                const float ei = ex[g][i], t1i = e1x[g][i - 1];
-                const float t0 = fmaf(gx1, kc.b0, gy1 * kc.a0);
-                gy1 = (0.0f + t0) + t1i; gx1 = ei;
-                gig = clampf(fmaf(ei, kc.ktsi, gig), -1.0f, 1.0f);
-                my_gy1 = (i == j) ? gy1 : my_gy1; my_gig = (i == j) ? gig : my_gig;
-            }
+            // the loop filter over the guessed errors, in closed form on the lanes (a guess: any summation order will do) instead of the serial
+            // recurrence through LDS: lane l holds u_l = b1 e_l + b0 e_(l-1); the states behind sample j - 1 are
+            //   y1_j = a0^j y1_0 + sum_(k < j) a0^k u_(j-1-k),   ig_j = ig_0 + K Ts sum_(l < j) e_l
+            // — two inclusive scans by doubling over the channel's lanes (row shifts by 1, 2, 4, 8; the coefficients are zero where a shift
+            // would reach below the channel's first lane), then one more shift by a lane.
+            const float e_below = dpp_row_shr<1>(eg);
+            float vy = fmaf(kc.b1, eg, kc.b0 * (j == 0 ? err_prev : e_below)), vi = eg;
+            vy = fmaf(sc_a[0], dpp_row_shr<1>(vy), vy); vi = fmaf(sc_1[0], dpp_row_shr<1>(vi), vi);
+            vy = fmaf(sc_a[1], dpp_row_shr<2>(vy), vy); vi = fmaf(sc_1[1], dpp_row_shr<2>(vi), vi);
+            vy = fmaf(sc_a[2], dpp_row_shr<4>(vy), vy); vi = fmaf(sc_1[2], dpp_row_shr<4>(vi), vi);
+            if constexpr (K == 16) { vy = fmaf(sc_a[3], dpp_row_shr<8>(vy), vy); vi = fmaf(sc_1[3], dpp_row_shr<8>(vi), vi); }
+            const float vy_below = dpp_row_shr<1>(vy), vi_below = dpp_row_shr<1>(vi);
+            const float my_gy1 = fmaf(sc_pw, y1, j == 0 ? 0.0f : vy_below);
+            const float my_gig = clampf(fmaf(kc.ktsi, j == 0 ? 0.0f : vi_below, ig), -1.0f, 1.0f);
             Fmine = fmaf(clampf(my_gig + my_gy1 * kc.c001, -1.0f, 1.0f), kc.m100, kc.m19000);    // (lane 0: S_0's word, F itself)
             fsq[g][j] = Fmine;
 #pragma unroll
