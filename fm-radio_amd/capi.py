@@ -159,7 +159,7 @@ def load_library():
     L.fmd_profile_enable.argtypes = [H, C.c_int]
     L.fmd_debug_split_front.argtypes = [H, C.c_int]
     L.fmd_debug_set_chain.argtypes = [H, C.c_int]
-    L.fmd_debug_pll_lanes_adaptive.argtypes = [H, C.c_int]
+    L.fmd_debug_pll_adaptive.argtypes = [H, C.c_int, C.c_int]
     L.fmd_debug_extract_pairing.argtypes = [H, C.c_int]
     L.fmd_debug_chain_blocks.argtypes = [H, C.POINTER(C.c_long)]
     L.fmd_profile_read.argtypes = [H, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]
@@ -337,10 +337,10 @@ class BatchDemod:
         """fmd_debug_set_chain: False keeps the three-launch form of the tolerance mode's steady blocks (the parity A/B of k_chain)."""
         self._check(self.L.fmd_debug_set_chain(self.h, 1 if on else 0))
 
-    def pll_lanes_adaptive(self, k16_max_channels: int) -> None:
-        """fmd_debug_pll_lanes_adaptive: exact mode — batches above `k16_max_channels` stations pick the pilot-PLL kernel's lane count by what is
-        out of lock (a small value lets a small batch exercise the switch)."""
-        self._check(self.L.fmd_debug_pll_lanes_adaptive(self.h, int(k16_max_channels)))
+    def pll_adaptive(self, k16_max_channels: int, time_parallel_max_channels: int = 7168) -> None:
+        """fmd_debug_pll_adaptive: exact mode — the batch sizes from which the pilot-PLL kernel (its lane count; low-work or time-parallel) is picked
+        by what is out of lock (small values let a small batch exercise the switches)."""
+        self._check(self.L.fmd_debug_pll_adaptive(self.h, int(k16_max_channels), int(time_parallel_max_channels)))
 
     def set_extract_pairing(self, mode: int) -> None:
         """fmd_debug_extract_pairing: 0 auto, 1 wherever possible, 2 never (k_extract_bp with two stations per workgroup)."""

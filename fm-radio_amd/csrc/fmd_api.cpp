@@ -54,12 +54,10 @@ struct fmd_handle_s {
     // loop holds lock (fewest instructions beside the FIR kernels), 16 while some do not (a loop out of lock costs its wavefront ~1.8x, and
     // the kernel lasts as long as its slowest wavefront: 1.55 -> 1.12 ms a block with 16).  The kernel counts the wavefronts that ran out
     // of lock (Buffers::pll_hint[C]); a 4-byte copy of the counter comes back every other block, and the host looks at it without waiting.
-    // The host may be queueing many blocks ahead of the GPU: what it goes by is the launch count that came back WITH the counter (16 lanes until
-    // the counter has stood still for 8 launches the host has SEEN; no news, no change).
+    // The host may be queueing many blocks ahead of the GPU: what it goes by is the pair that came back — the newest launch that had wavefronts out
+    // of lock and the newest launch that has run: out of lock "now" while the two are fewer than 8 launches apart; no news, no change.
     bool pll_k_adaptive = false;
-    unsigned* pll_unl_host = nullptr;        // pinned: [0] counter, [1] launches
-    unsigned pll_unl_seen = 0, pll_done_seen = 0, pll_last_move = 0;
-    bool pll_moved_ever = false;
+    unsigned* pll_unl_host = nullptr;        // pinned: [0] newest launch with wavefronts out of lock, [1] newest launch that has run
     bool pll_chained = false;
     int pll_waves = 0;
     hipEvent_t ev_in = nullptr, ev_P[kSlots] = {}, ev_F[kSlots] = {}, ev_A[kSlots] = {}, ev_B[kSlots] = {}, ev_E[kSlots] = {}, ev_X[kSlots] = {};
@@ -597,7 +595,7 @@ int zero_history(fmd_handle h, hipStream_t s) {
     // everything is idle here (callers synchronise first): restart the per-wavefront PLL hand-over chain, watchdog flag included
     if (b.pll_chain) HIP_TRY(h, hipMemsetAsync(b.pll_chain, 0, sizeof(unsigned) * ((size_t)h->pll_waves + 1 + (size_t)d.C + 2), s));      // (and the body hints behind it)
     if (h->pll_unl_host) h->pll_unl_host[0] = h->pll_unl_host[1] = 0u;
-    h->pll_unl_seen = h->pll_done_seen = h->pll_last_move = 0; h->pll_moved_ever = false; h->ctx.pll_k16_now = false;
+    h->ctx.pll_unlocked_now = false; h->ctx.pll_launch_no = 0;
     h->pll_seq = 0;
     h->n_blocks = 0;
     h->warm_left = h->ctx.fast ? (int)((8192 + d.n_fm_out - 1) / d.n_fm_out) : 0;     // kPllWarmSamples of every station's life
@@ -887,12 +885,9 @@ int process_dev(fmd_handle h, const InT* d_iq, int n_channels, int n_samples, vo
         h->ev_consumed = persistent;
     }
     if (h->pll_k_adaptive) {
-        const unsigned done = reinterpret_cast<volatile unsigned*>(h->pll_unl_host)[1], v = reinterpret_cast<volatile unsigned*>(h->pll_unl_host)[0];
-        if (done != h->pll_done_seen) {
-            h->pll_done_seen = done;
-            if (v != h->pll_unl_seen) { h->pll_unl_seen = v; h->pll_last_move = done; h->pll_moved_ever = true; }
-            h->ctx.pll_k16_now = h->pll_moved_ever && done - h->pll_last_move < 8u;
-        }
+        const unsigned done = reinterpret_cast<volatile unsigned*>(h->pll_unl_host)[1], heavy = reinterpret_cast<volatile unsigned*>(h->pll_unl_host)[0];
+        h->ctx.pll_unlocked_now = heavy != 0u && (heavy > done || done - heavy < 8u);      // (heavy > done: the launch that is still running has such wavefronts)
+        h->ctx.pll_launch_no++;
         // (no ordering against the PLL launches: both words only grow, whichever values the copy finds will do)
         if ((h->n_blocks & 1) == 0) HIP_TRY(h, hipMemcpyAsync(h->pll_unl_host, h->ctx.b.pll_hint + h->ctx.d.C, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, sA));
     }
@@ -1106,6 +1101,7 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     // within the time-parallel kernel: 16 lanes per channel while a lone wavefront's latency is what matters (same-box A/B:
     // 8 % faster at 2560 channels, 6 % at 3072), 8 lanes per channel (30 % fewer VALU instructions) beyond (2 % faster at 4096)
     h->ctx.pll_k16_max_channels = (cfg->flags & FMD_FLAG_PLL_K8) ? 0 : 3584;
+    h->ctx.pll_unlocked_now = false; h->ctx.pll_launch_no = 0;
     if (const char* e = dev_env("FMD_DEBUG_PLL_K16_MAX")) h->ctx.pll_k16_max_channels = atoi(e);   // development knob
     d.n_fm_in = d.N / m; d.n_fm_out = d.n_fm_in / 2; d.n_rds = d.n_fm_out / 8; d.n_audio = d.n_fm_out / 4;
     d.n_est = (d.n_audio + 9) / 10;
@@ -1217,12 +1213,16 @@ int fmd_create(const fmd_config* cfg, fmd_handle* out) {
     const bool time_parallel = d.C <= h->ctx.pll_time_parallel_max_channels;
     // (FMD_FLAG_KEEP_TAPS: k_pll_taps reads the loop's start state ahead of the PLL kernel — consecutive blocks' launches stay in stream order)
     h->pll_chained = h->pipelined && !h->ctx.fast && !h->ctx.keep_taps && time_parallel && effective_channels(d) <= 3328 && !(cfg->flags & (FMD_FLAG_PLL_STREAM_ORDER | FMD_FLAG_PLL_LOW_WORK));
-    h->pll_k_adaptive = !h->ctx.fast && time_parallel && !(cfg->flags & (FMD_FLAG_PLL_K8 | FMD_FLAG_PLL_LOW_WORK)) && effective_channels(d) > h->ctx.pll_k16_max_channels &&
-                        effective_channels(d) <= 4096 && !dev_env("FMD_PLL_K_FIXED");
-    h->pll_waves = (effective_channels(d) <= h->ctx.pll_k16_max_channels || h->pll_k_adaptive) ? (d.C + 3) / 4 : (d.C + 7) / 8;
+    // (two ranges: 3585 .. 4096 effective stations — 8 or 16 lanes of the time-parallel kernel; above pll_time_parallel_max_channels, up to 16384 stations —
+    //  the low-work kernel or the time-parallel one with 8 lanes, whose sequence form gets through loops out of lock: 8192 stations with 1 % unlocked
+    //  2.87 -> 1.9 ms a block.  The FMD_FLAG_PLL_* selectors switch the choice off.)
+    h->pll_k_adaptive = !h->ctx.fast && !dev_env("FMD_PLL_K_FIXED") &&
+                        ((time_parallel && !(cfg->flags & (FMD_FLAG_PLL_K8 | FMD_FLAG_PLL_LOW_WORK)) && effective_channels(d) > h->ctx.pll_k16_max_channels && effective_channels(d) <= 4096) ||
+                         (!time_parallel && !(cfg->flags & FMD_FLAG_PLL_LOW_WORK) && d.C <= 16384));
+    h->pll_waves = (effective_channels(d) <= h->ctx.pll_k16_max_channels || (h->pll_k_adaptive && time_parallel)) ? (d.C + 3) / 4 : (d.C + 7) / 8;
     if (!rc) rc = dev_alloc(h, &b.pll_chain, (size_t)h->pll_waves + 1 + (size_t)d.C + 2);
     if (!rc) b.pll_hint = b.pll_chain + h->pll_waves + 1;
-    if (!rc && !h->ctx.fast && time_parallel) {
+    if (!rc && !h->ctx.fast) {
         if (hipHostMalloc(reinterpret_cast<void**>(&h->pll_unl_host), 64, hipHostMallocDefault) != hipSuccess) rc = fail(h, FMD_ERR_DEVICE, "pinned allocation failed");
         else h->pll_unl_host[0] = h->pll_unl_host[1] = 0u;
     }
@@ -1729,15 +1729,17 @@ int fmd_debug_set_chain(fmd_handle h, int on) {
     return FMD_OK;
 }
 
-int fmd_debug_pll_lanes_adaptive(fmd_handle h, int k16_max_channels) {
-    if (!h || k16_max_channels < 0) return FMD_ERR_ARG;
-    if (h->ctx.fast || !h->pll_unl_host || h->ctx.d.C > h->ctx.pll_time_parallel_max_channels || effective_channels(h->ctx.d) > 4096) return fail(h, FMD_ERR_ARG, "the exact mode's time-parallel pilot-PLL kernel, up to 4096 stations");
+int fmd_debug_pll_adaptive(fmd_handle h, int k16_max_channels, int time_parallel_max_channels) {
+    if (!h || k16_max_channels < 0 || time_parallel_max_channels < 0) return FMD_ERR_ARG;
+    if (h->ctx.fast || !h->pll_unl_host || effective_channels(h->ctx.d) > 4096) return fail(h, FMD_ERR_ARG, "the exact mode, up to 4096 stations");
     int rc = fmd_synchronize(h);
     if (rc) return rc;
     h->ctx.pll_k16_max_channels = k16_max_channels;
-    h->pll_k_adaptive = effective_channels(h->ctx.d) > k16_max_channels;
-    h->pll_chained = false;                  // (the per-wavefront hand-over is indexed by wavefront: one lane count only)
-    h->pll_unl_seen = h->pll_unl_host[0]; h->pll_done_seen = h->pll_unl_host[1]; h->pll_moved_ever = false; h->ctx.pll_k16_now = false;
+    h->ctx.pll_time_parallel_max_channels = time_parallel_max_channels;
+    const bool time_parallel = h->ctx.d.C <= time_parallel_max_channels;
+    h->pll_k_adaptive = !time_parallel || effective_channels(h->ctx.d) > k16_max_channels;
+    h->pll_chained = false;                  // (the per-wavefront hand-over is indexed by wavefront: one kernel, one lane count only)
+    h->ctx.pll_unlocked_now = false;
     return FMD_OK;
 }
 

@@ -210,7 +210,7 @@ struct Buffers {
     uint4*  bp_edge;                 // ... per cut-off slot [31 outputs][8 lanes][6] (fp16 pairs): the matrix of the block's first outputs' sums over the previous block's samples
     uint4*  front_mfma;              // FMD_FLAG_FAST_MATH only: Toeplitz operand images of k_front_mfma's two FIRs, [fir][k-step][hi/lo][lane]; m > 1: then k_predecim_mfma's
     unsigned int* pll_chain;         // [wavefronts of k_pilot_pll + 1] last block number each wavefront completed; [last] = watchdog flag
-    unsigned int* pll_hint;          // [C] 1: the station's wavefront left the previous block out of lock (it runs the kernel's sequence-capable body); [C]: count of wavefronts that spent a quarter of a block or more out of lock, [C + 1]: launches
+    unsigned int* pll_hint;          // [C] 1: the station's wavefront left the previous block out of lock (it runs the kernel's sequence-capable body); [C]: the newest launch (LaunchCtx::pll_launch_no) in which a wavefront spent a quarter of the block or more out of lock, [C + 1]: the newest launch that has run
     unsigned long long* spec_stats;  // [8] speculation counters: pll {chunks, general, replayed, -}, rds {chunks, general, replayed, -}
 };
 
@@ -234,7 +234,8 @@ struct LaunchCtx {
     int extract_pairing;                  // k_extract_bp with two stations per workgroup: 0 = where it pays (launch_extract_ta), 1 = wherever possible (tests), 2 = never
     int pll_time_parallel_max_channels;   // batches up to this size use the time-parallel PLL kernel, larger ones the low-work one
     int pll_k16_max_channels;             // (channels x m) up to this: 16 lanes per channel, above: 8
-    bool pll_k16_now;                     // ... or 16 all the same: stations were out of lock in the last blocks (fmd_api.cpp, up to 4096 stations)
+    unsigned pll_launch_no;               // 1-based number of the pilot-PLL launch being queued (exact mode)
+    bool pll_unlocked_now;                // wavefronts ran out of lock in the last blocks the host has seen (fmd_api.cpp): 16 lanes up to 4096 stations, and the time-parallel kernel instead of the low-work one above pll_time_parallel_max_channels
 };
 
 // where a slot's traces lie inside Buffers::taps[buf] (null pointers when the handle keeps none)

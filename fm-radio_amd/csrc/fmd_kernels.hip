@@ -1337,7 +1337,8 @@ __global__ __launch_bounds__(kWave) void k_pll_taps(Dims d, const float2* __rest
 // chunk that needed more than 3x the fewest spans the wavefront runs the next chunks with the plain serial iteration (pll_step),
 // backing off exponentially — 3.7-3.9 ms a block for a batch with ANY such station against 0.76 in lock.  Round 6: the word still
 // moves by only a few ulp a sample, so such a wavefront speculates on the SEQUENCE of words instead (a cheap guess pass, then the
-// exact pass confirms word by word: pilot_pll_body's span, seq): K samples a span at ~1.8x a span's cost, 1.4-1.9 ms a block.
+// exact pass confirms word by word: pilot_pll_body's span, seq): K samples a span at ~1.4x a span's cost, 1.06-1.25 ms a block (4096 stations,
+// 16 lanes while wavefronts are out of lock: fmd_api.cpp picks the lane count, and this kernel over the low-work one, by what the kernels report).
 // The kernel holds two bodies — round 3's unchanged for wavefronts whose stations held lock through the previous block, the
 // sequence-capable one for the others (Buffers::pll_hint, per station, written by the wavefront itself) — so the all-locked batch pays nothing.
 //
@@ -1406,7 +1407,7 @@ template <int K, bool SEQCAP>
 __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
                                                float* __restrict__ state, LoopCoeffs k, int power_field,
                                                unsigned long long* __restrict__ spec_stats,
-                                               unsigned int* __restrict__ chain, unsigned int seq, unsigned int* __restrict__ hint,
+                                               unsigned int* __restrict__ chain, unsigned int seq, unsigned int* __restrict__ hint, unsigned int launch_no,
                                                float2 (*xin)[kPllRing], float (*dts)[kPllRing], float (*ex)[K + 4], float (*e1x)[K + 4], float (*fsq)[K + 4]) {
     constexpr int G = kWave / K, CH = kPllChunk, RING = kPllRing;
     constexpr int kPllSlowSpans = 3 * CH / K;     // a chunk that needed more spans than this is "out of lock"
@@ -1848,11 +1849,11 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
     if (hint) {
         const unsigned int out = (n_seq != 0ull || n_seq_spans != 0ull) ? 1u : 0u;
         if (live && j == 0) hint[c] = out;
-        // [C]: wavefronts that spent a quarter of a block or more out of lock, ever; [C + 1]: launches — the host watches the first move
-        // against the second (a chunk or two in the other form is what any loop does now and then: not counted)
+        // [C]: the newest launch in which a wavefront spent a quarter of the block or more out of lock, [C + 1]: the newest launch that has run — the
+        // host watches the distance (a chunk or two in the other form is what any loop does now and then: not counted)
         const bool heavy = 4ull * n_seq >= (unsigned long long)chunks || 4ull * n_seq_spans >= (unsigned long long)(n_spans > 0 ? n_spans : 1);
-        if (heavy && lane == 0) atomicAdd(hint + d.C, 1u);
-        if (blockIdx.x == 0 && lane == 0) atomicAdd(hint + d.C + 1, 1u);
+        if (heavy && lane == 0) atomicMax(hint + d.C, launch_no);
+        if (blockIdx.x == 0 && lane == 0) atomicMax(hint + d.C + 1, launch_no);
     }
     if (chain) {   // publish: the state stores above, then the sequence number
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1877,7 +1878,7 @@ template <int K>
 __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
                                                      float* __restrict__ state, LoopCoeffs k, int power_field,
                                                      unsigned long long* __restrict__ spec_stats,
-                                                     unsigned int* __restrict__ chain, unsigned int seq, unsigned int* __restrict__ hint) {
+                                                     unsigned int* __restrict__ chain, unsigned int seq, unsigned int* __restrict__ hint, unsigned int launch_no) {
     constexpr int G = kWave / K, RING = kPllRing;
     __shared__ __attribute__((aligned(16))) float2 xin[G][RING];   // pilot samples, ring by (sample index & 255)
     __shared__ __attribute__((aligned(16))) float dts[G][RING];    // results, same ring
@@ -1889,8 +1890,8 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
         const int c = blockIdx.x * G + (int)threadIdx.x / K;
         out_of_lock = __builtin_amdgcn_ballot_w64(c < d.C && hint[c < d.C ? c : d.C - 1] != 0u) != 0ull;
     }
-    if (out_of_lock) pilot_pll_body<K, true>(d, pilot, pll_dt, state, k, power_field, spec_stats, chain, seq, hint, xin, dts, ex, e1x, fsq);
-    else pilot_pll_body<K, false>(d, pilot, pll_dt, state, k, power_field, spec_stats, chain, seq, hint, xin, dts, ex, e1x, fsq);
+    if (out_of_lock) pilot_pll_body<K, true>(d, pilot, pll_dt, state, k, power_field, spec_stats, chain, seq, hint, launch_no, xin, dts, ex, e1x, fsq);
+    else pilot_pll_body<K, false>(d, pilot, pll_dt, state, k, power_field, spec_stats, chain, seq, hint, launch_no, xin, dts, ex, e1x, fsq);
 }
 
 // ===============================================================================================================
@@ -2063,7 +2064,7 @@ __device__ __forceinline__ void chunk16_flush_f(const float2* lds, float* __rest
 // leaves starts at once.
 __global__ __launch_bounds__(2 * kWave) void k_pilot_pll_pairs(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
                                                          float* __restrict__ state, LoopCoeffs k, int power_field,
-                                                         unsigned long long* __restrict__ spec_stats) {
+                                                         unsigned long long* __restrict__ spec_stats, unsigned int* __restrict__ hint, unsigned int launch_no) {
     __shared__ __attribute__((aligned(16))) float2 ring[2][kPllCh * kRow16];
     const bool mover = threadIdx.x >= kWave;   // wave-uniform
     const int lane = threadIdx.x & (kWave - 1), c0 = blockIdx.x * kPllCh;
@@ -2158,6 +2159,15 @@ __global__ __launch_bounds__(2 * kWave) void k_pilot_pll_pairs(Dims d, const flo
         st(state, S_AGC_PILOT_GAIN, d.C, c) = gain;
         st(state, S_PLL_X1, d.C, c) = S.lx1; st(state, S_PLL_Y1, d.C, c) = S.ly1;
         st(state, S_PLL_INT, d.C, c) = S.integ; st(state, S_PLL_ERR, d.C, c) = S.err; st(state, S_PLL_T, d.C, c) = S.tph;
+    }
+    if (hint) {
+        // Buffers::pll_hint as k_pilot_pll keeps it: a wavefront that ran a quarter of the block or more with the general iteration has a loop out
+        // of lock — this kernel has no cheaper way through it, the time-parallel kernel's sequence form has, and the host (fmd_api.cpp) launches
+        // that one for the next blocks while the counter moves
+        const bool heavy = 4 * n_general >= chunks;
+        if (live && !odd) hint[c] = heavy ? 1u : 0u;
+        if (heavy && lane == 0) atomicMax(hint + d.C, launch_no);
+        if (blockIdx.x == 0 && lane == 0) atomicMax(hint + d.C + 1, launch_no);
     }
     if (lane == 0 && spec_stats) {   // same slots as k_pilot_pll: chunks (16 samples here) / run with the general iteration / replayed
         atomicAdd(&spec_stats[0], (unsigned long long)chunks);
@@ -3261,18 +3271,20 @@ hipError_t launch_stage_pll(const LaunchCtx& ctx, SlotRef r, hipStream_t s) {
     // FMD_FLAG_KEEP_TAPS: the loop's traces, from the state the block starts from (ahead of the kernel that advances it)
     if (ctx.b.taps[r.buf]) hipLaunchKernelGGL(k_pll_taps, dim3((unsigned)((d.C + kWave - 1) / kWave)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.state, ctx.loops,
                                               (int)S_PILOT_POWER0 + r.buf, tap_ptrs(ctx, r.buf));
-    if (d.C > ctx.pll_time_parallel_max_channels) {
+    // (ctx.pll_unlocked_now: wavefronts ran out of lock in the last blocks the host has seen — the low-work kernel gives way to the time-parallel one,
+    //  whose sequence form gets through such loops; the time-parallel kernel takes 16 lanes a station up to 4096 stations)
+    if (d.C > ctx.pll_time_parallel_max_channels && !ctx.pll_unlocked_now) {
         FMD_LAUNCH(r, true, true, k_pilot_pll_pairs, dim3((unsigned)((d.C + kPllCh - 1) / kPllCh)), dim3(2 * kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf],
-                   ctx.b.state, ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats);
+                   ctx.b.state, ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats, ctx.b.pll_hint, ctx.pll_launch_no);
         return hipGetLastError();
     }
     unsigned int* chain = r.seq ? ctx.b.pll_chain : nullptr;
-    if (effective_channels(d) <= ctx.pll_k16_max_channels || ctx.pll_k16_now) {
+    if (effective_channels(d) <= ctx.pll_k16_max_channels || (ctx.pll_unlocked_now && effective_channels(d) <= 4096)) {
         FMD_LAUNCH(r, true, true, k_pilot_pll<16>, dim3((unsigned)((d.C + 3) / 4)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
-                   ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats, chain, r.seq, ctx.b.pll_hint);
+                   ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats, chain, r.seq, ctx.b.pll_hint, ctx.pll_launch_no);
     } else {
         FMD_LAUNCH(r, true, true, k_pilot_pll<8>, dim3((unsigned)((d.C + 7) / 8)), dim3(kWave), 0, s, d, ctx.b.pilot[r.buf], ctx.b.pll_dt[r.buf], ctx.b.state,
-                   ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats, chain, r.seq, ctx.b.pll_hint);
+                   ctx.loops, (int)S_PILOT_POWER0 + r.buf, ctx.b.spec_stats, chain, r.seq, ctx.b.pll_hint, ctx.pll_launch_no);
     }
     return hipGetLastError();
 }

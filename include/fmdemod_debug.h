@@ -85,10 +85,11 @@ int fmd_profile_read(fmd_handle h, fmd_kernel_time* out, int cap, int* n_out);
  * Between blocks only; both forms leave the same histories, so a handle may change between them at any block.
  * fmd_debug_chain_blocks: how many blocks since create / reset ran as k_chain. */
 int fmd_debug_set_chain(fmd_handle h, int on);
-/* Exact mode, test hook: the batch size up to which k_pilot_pll runs 16 lanes a station (default 3584), and above it — up to 4096 stations — the
- * choice by what is out of lock (8 lanes while every loop holds lock, 16 while some do not: DESIGN.md section 4).  With a small value a small
- * batch exercises the switch (tests/test_gpu_parity.py); results are bit-identical whatever the lane count. */
-int fmd_debug_pll_lanes_adaptive(fmd_handle h, int k16_max_channels);
+/* Exact mode, test hook: the batch sizes up to which the pilot PLL runs as the time-parallel kernel with 16 lanes a station (default 3584) and as the
+ * time-parallel kernel at all (default 7168; the low-work kernel above).  Beyond either the choice follows what is out of lock:
+ * 8 lanes / the low-work kernel while every loop holds lock, 16 lanes (up to 4096 stations) / the time-parallel kernel while some do not.  With small
+ * values a small batch exercises the switches (tests/test_gpu_parity.py); results are bit-identical whatever kernel runs. */
+int fmd_debug_pll_adaptive(fmd_handle h, int k16_max_channels, int time_parallel_max_channels);
 /* Tolerance mode: k_extract_bp with two stations per workgroup (the tap tables and the block edge's matrix fetched once for both; results bit-identical):
  * 0 = where it pays (3072 stations and more with equal cut-offs, the default), 1 = wherever possible (so that tests reach it with a few stations), 2 = never. */
 int fmd_debug_extract_pairing(fmd_handle h, int mode);

@@ -31,8 +31,8 @@ def run_gpu(pkg, caps: np.ndarray, block_size: int, fs: int, use_torch: bool = F
     n_ch = caps.shape[0]
     nb = caps.shape[1] // block_size
     dm = pkg.BatchDemod(n_ch, block_size, fs, keep_taps=True, pll_kernel=pll_kernel, fast_math=fast_math)
-    if pll_k16_max is not None:       # (include/fmdemod_debug.h: the pilot-PLL kernel's lane count by what is out of lock, from this batch size on)
-        dm.pll_lanes_adaptive(pll_k16_max)
+    if pll_k16_max is not None:       # (include/fmdemod_debug.h: the pilot-PLL kernel by what is out of lock, from these batch sizes on)
+        dm.pll_adaptive(*pll_k16_max) if isinstance(pll_k16_max, tuple) else dm.pll_adaptive(pll_k16_max)
     if split_front:       # (include/fmdemod_debug.h: the first decimator and the front end as two kernels)
         assert dm.L.fmd_debug_split_front(dm.h, 1) == 0
     if controls is not None:

@@ -40,7 +40,7 @@ def test_debug_hooks_live_in_their_own_header(pkg):
     hooks = everything - product
     assert hooks == {"fmd_selftest_atan2", "fmd_selftest_atan2_table", "fmd_selftest_atan2_table_u8", "fmd_selftest_atan2_small", "fmd_selftest_fast_math",
                      "fmd_get_spec_stats", "fmd_profile_enable", "fmd_profile_read", "fmd_design_pll_span", "fmd_design_pll_sparse", "fmd_debug_split_front",
-                     "fmd_design_extract_bp", "fmd_design_wrap_tie", "fmd_debug_set_chain", "fmd_debug_chain_blocks", "fmd_debug_extract_pairing", "fmd_debug_pll_lanes_adaptive"}
+                     "fmd_design_extract_bp", "fmd_design_wrap_tie", "fmd_debug_set_chain", "fmd_debug_chain_blocks", "fmd_debug_extract_pairing", "fmd_debug_pll_adaptive"}
     assert {"fmd_submit_cf32_dev", "fmd_submit_u8_dev", "fmd_wait_input", "fmd_set_output_lag", "fmd_outputs_block", "fmd_outputs_epoch"} <= product
     assert {"fmd_release_outputs", "fmd_get_state", "fmd_set_state", "fmd_state_size", "fmd_output_lifetime_blocks"} <= product
     # both headers compile as plain C

@@ -384,32 +384,35 @@ def test_loops_out_of_lock_run_the_sequence_form_not_the_serial_iteration(pkg, p
         assert p["samples_per_span"] > 0.9 * k, per_block
 
 
-def test_pilot_pll_lane_count_follows_what_is_out_of_lock(pkg):
+@pytest.mark.parametrize("thresholds,calm,busy", [((4, 7168), 8, 16), ((4, 4), "low-work", 16)])
+def test_pilot_pll_kernel_follows_what_is_out_of_lock(pkg, thresholds, calm, busy):
     """Between 3585 and 4096 stations the exact mode runs the pilot-PLL kernel with 8 lanes a station while every loop holds lock and with 16
-    while some do not (a loop out of lock costs its wavefront ~1.8x and the kernel lasts as long as its slowest wavefront).  The test hook
-    moves that range down to this batch: one station loses its pilot for six blocks in the middle of the capture.  Every stream bit-identical
-    to the oracle through both switches, and the statistics show 8 lanes, then 16 (more than 8 samples a span), then 8 again."""
+    while some do not (a loop out of lock costs its wavefront ~1.4x and the kernel lasts as long as its slowest wavefront); above 7168 stations
+    the low-work kernel gives way to the time-parallel one (8 lanes; 16 up to 4096 stations), whose sequence form gets through such loops.  The
+    test hook moves those ranges down to this batch: one station's pilot is 130 Hz off for ten blocks in the middle of the capture.  Every
+    stream bit-identical to the oracle through both switches, and the statistics show the calm kernel, then the busy one, then the calm one."""
     bs, C = 16384, 12
-    parts = (14, 8, 16)
+    parts = (14, 10, 18)
     def cap(c, nblk, **kw):
         return synth.to_cf32(synth.fm_capture(nblk * bs, fs=256_000.0, seed=1300 + c, channel=c, **kw)["iq"])
     rows = [cap(c, sum(parts)) for c in range(C)]
     rows[5] = np.concatenate([cap(5, parts[0]), cap(50, parts[1], pilot_hz=19130.0), cap(51, parts[2])])
     caps = np.stack(rows)
-    _assert_exact(compare_with_oracle(pkg, caps, bs, 256_000, pll_k16_max=4))
+    _assert_exact(compare_with_oracle(pkg, caps, bs, 256_000, pll_k16_max=thresholds))
     dm = pkg.BatchDemod(n_channels=C, block_size=bs, fs_baseband=256_000)
-    dm.pll_lanes_adaptive(4)
-    sps = []
+    dm.pll_adaptive(*thresholds)
+    seen = []
     for b in range(sum(parts)):
         dm.process(caps[:, b * bs:(b + 1) * bs])
         dm.synchronize()
-        sps.append(dm.spec_stats(reset=True)["pll"]["samples_per_span"])
+        p = dm.spec_stats(reset=True)["pll"]
+        # (the low-work kernel counts 16-sample chunks and no spans; the time-parallel kernel 128-sample chunks per wavefront of 64 / lanes stations)
+        seen.append("low-work" if p["spans"] == 0 else (16 if p["samples_per_span"] > 8.0 else 8))
     dm.close()
-    lanes = [16 if v > 8.0 else 8 for v in sps]
     a, b = parts[0], parts[0] + parts[1]
-    assert lanes[a - 2:a] == [8, 8], sps                                            # in lock, the counter at rest for 8 launches: 8 lanes
-    assert lanes[b - 2:b] == [16, 16], sps                                          # the pilot gone: 16 within a few blocks (the counter's way back to the host)
-    assert lanes[-2:] == [8, 8], sps                                                # back in lock: 8 again
+    assert seen[a - 2:a] == [calm, calm], seen                                      # in lock, the counter at rest for 8 launches
+    assert seen[b - 2:b] == [busy, busy], seen                                      # the pilot off: within a few blocks (the counter's way back to the host)
+    assert seen[-2:] == [calm, calm], seen                                          # back in lock
 
 
 def test_blocks_with_more_symbols_than_the_sign_buffer_holds(pkg):

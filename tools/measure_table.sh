@@ -14,6 +14,9 @@ for p in 0.01 0.1 1.0; do run "exact unlocked $p" "--exact --unlocked-frac $p --
 run "exact unlocked 0.1 zero" "--exact --unlocked-frac 0.1 --unlocked-kind zero --steps 20"
 run "exact unlocked 0.1 detuned" "--exact --unlocked-frac 0.1 --unlocked-kind detuned --steps 20"
 run "exact 8192 unlocked 0.01" "--exact --channels 8192 --unlocked-frac 0.01 --steps 20"
+run "exact 8192 unlocked 0.1" "--exact --channels 8192 --unlocked-frac 0.1 --steps 20"
+run "exact 8192 unlocked 1.0" "--exact --channels 8192 --unlocked-frac 1.0 --steps 20"
+run "exact 16384 unlocked 0.01" "--exact --channels 16384 --unlocked-frac 0.01 --steps 20"
 run "exact 1024 unlocked 0.01" "--exact --channels 1024 --unlocked-frac 0.01 --steps 20"
 run "exact 1024" "--exact --channels 1024"
 run "fast unlocked 0.1 zero" "--unlocked-frac 0.1 --unlocked-kind zero"
