@@ -1339,8 +1339,8 @@ __global__ __launch_bounds__(kWave) void k_pll_taps(Dims d, const float2* __rest
 // moves by only a few ulp a sample, so such a wavefront speculates on the SEQUENCE of words instead (a cheap guess pass, then the
 // exact pass confirms word by word: pilot_pll_body's span, seq): K samples a span at ~1.4x a span's cost, 1.06-1.25 ms a block (4096 stations,
 // 16 lanes while wavefronts are out of lock: fmd_api.cpp picks the lane count, and this kernel over the low-work one, by what the kernels report).
-// The kernel holds two bodies — round 3's unchanged for wavefronts whose stations held lock through the previous block, the
-// sequence-capable one for the others (Buffers::pll_hint, per station, written by the wavefront itself) — so the all-locked batch pays nothing.
+// The kernel holds two chunk loops — round 3's unchanged for wavefronts whose stations held lock through the previous block, the
+// sequence-capable one for the others (Buffers::pll_hint, per station, written by the wavefront itself) — so the all-locked batch pays next to nothing.
 //
 // Layout: one wavefront = 64 / K channels x K lanes (K = 16 or 8), one workgroup = one wavefront (12.6 KB LDS and 128 VGPRs
 // at K = 16: fits any hole a retiring FIR workgroup leaves; 24.8 KB and 169 VGPRs at K = 8).  128-sample chunks; LDS rings of two chunks per channel for the pilot samples and the
@@ -1403,7 +1403,7 @@ static constexpr int kSlowHoldMax = 16;       // longest run of serial chunks be
 // K = lanes (= consecutive samples) per channel.  K = 16 gives the shortest latency (4 channels per wavefront, 1024 wavefronts
 // for 4096 channels); K = 8 spends 30 % fewer VALU instructions (8 channels per wavefront share the serial parts) for ~25 %
 // more latency — better as soon as the chip, not a lone wavefront, is the limit.
-template <int K, bool SEQCAP>
+template <int K>
 __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
                                                float* __restrict__ state, LoopCoeffs k, int power_field,
                                                unsigned long long* __restrict__ spec_stats,
@@ -1470,15 +1470,16 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
     float lx1 = st(state, S_PLL_X1, d.C, cs), ly1 = st(state, S_PLL_Y1, d.C, cs), integ = st(state, S_PLL_INT, d.C, cs);
     float err_prev = st(state, S_PLL_ERR, d.C, cs), tph_prev = st(state, S_PLL_T, d.C, cs);
     ex[g][0] = err_prev;
-
+    // which of the two loops below these stations get: round 3's while they held lock through the previous block (one flag per station, written at the end)
+    const bool SEQCAP = hint && __builtin_amdgcn_ballot_w64(live && hint[cs] != 0u) != 0ull;
 
     int pos = 0;                 // next sample of this channel (absolute within the block); identical in its 16 lanes
     int seq_left = 0, hold = 0;  // wave-uniform: serial chunks still to run / back-off
     unsigned long long n_exact = 0, n_seq = 0;   // wave-uniform counters (scalar registers)
     int n_spans = 0;
-    bool seq_form = false;       // (SEQCAP) wave-uniform: the spans run in the sequence form (below)
+    bool seq_form = false;       // (second loop) wave-uniform: the spans run in the sequence form (below)
     unsigned long long n_seq_spans = 0;
-    if constexpr (!SEQCAP) {
+    if (!SEQCAP) {
     // ---- the constant-word form with the serial fall-back (round 3), for a wavefront whose stations all held lock through the previous block ----
     for (int q = 0; q < chunks; q++) {
         const int cend = (q + 1) * CH;
@@ -1870,10 +1871,11 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
     }
 }
 
-// The kernel: LDS, and which of the two bodies this wavefront's stations get (hint: one flag per station, written by the previous block's launch).
-// Two bodies rather than one with both forms: the all-locked batch keeps round 3's code and its time to the instruction (one body holding
-// both forms cost it 5-18 %: branches and register moves in the constant-word span, and the instruction cache when single spans strayed
-// into the other form's copy); a wavefront runs one body for a whole block, so its loop stays resident.
+// The kernel: the LDS, and pilot_pll_body — one prologue and epilogue around two chunk loops, chosen per wavefront by its stations' flags
+// (Buffers::pll_hint, written by the previous block's launch).  Two loops rather than one with both forms: one span body holding both cost
+// the all-locked batch 5-18 % (branches and register moves in the constant-word span, and the instruction cache when single spans strayed
+// into the other form's copy); a wavefront runs one loop for a whole block, so its code stays resident, and the all-locked batch keeps
+// round 3's loop (same-box A/B against a build without the second loop: +0.9 % on the step).
 template <int K>
 __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __restrict__ pilot, float* __restrict__ pll_dt,
                                                      float* __restrict__ state, LoopCoeffs k, int power_field,
@@ -1885,13 +1887,7 @@ __global__ __launch_bounds__(kWave) void k_pilot_pll(Dims d, const float2* __res
     __shared__ __attribute__((aligned(16))) float ex[G][K + 4];    // [0] = err_prev, [1 + i] = err_i of the current span
     __shared__ __attribute__((aligned(16))) float e1x[G][K + 4];   // fma(err_i, b1, 0)
     __shared__ __attribute__((aligned(16))) float fsq[G][K + 4];   // out of lock: the guessed frequency word of every sample of the span
-    bool out_of_lock = false;
-    if (hint) {
-        const int c = blockIdx.x * G + (int)threadIdx.x / K;
-        out_of_lock = __builtin_amdgcn_ballot_w64(c < d.C && hint[c < d.C ? c : d.C - 1] != 0u) != 0ull;
-    }
-    if (out_of_lock) pilot_pll_body<K, true>(d, pilot, pll_dt, state, k, power_field, spec_stats, chain, seq, hint, launch_no, xin, dts, ex, e1x, fsq);
-    else pilot_pll_body<K, false>(d, pilot, pll_dt, state, k, power_field, spec_stats, chain, seq, hint, launch_no, xin, dts, ex, e1x, fsq);
+    pilot_pll_body<K>(d, pilot, pll_dt, state, k, power_field, spec_stats, chain, seq, hint, launch_no, xin, dts, ex, e1x, fsq);
 }
 
 // ===============================================================================================================
