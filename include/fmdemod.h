@@ -62,8 +62,8 @@ typedef struct {
 
 #define FMD_FLAG_KEEP_TAPS   1u  /* keep the intermediate streams readable through fmd_get_stream */
 #define FMD_FLAG_NO_PIPELINE 2u  /* run every stage on the caller's stream, one after the other (debugging / profiling) */
-#define FMD_FLAG_PLL_TIME_PARALLEL 4u  /* force the time-parallel pilot-PLL kernel (default: batches <= 7168 channels) */
-#define FMD_FLAG_PLL_K8           16u  /* time-parallel kernel with 8 (not 16) lanes per channel whatever the batch size (default: effective batches (stations, x 1.5 at 1.024 and 2.048 MSa/s) > 3584) */
+#define FMD_FLAG_PLL_TIME_PARALLEL 4u  /* force the time-parallel pilot-PLL kernel (default: batches <= 7168 channels, and larger ones while stations are out of pilot lock) */
+#define FMD_FLAG_PLL_K8           16u  /* time-parallel kernel with 8 (not 16) lanes per channel whatever the batch size (default: effective batches (stations, x 1.5 at 1.024 and 2.048 MSa/s) > 3584; up to 4096 stations 16 lanes all the same while stations are out of pilot lock) */
 #define FMD_FLAG_PLL_STREAM_ORDER  32u  /* consecutive blocks' pilot-PLL launches ordered by the stream (kernel boundary) instead of handing over per wavefront while both run (A/B and debugging; same results) */
 #define FMD_FLAG_PLL_LOW_WORK      8u  /* force the low-work pilot-PLL kernel (default: larger batches); same results either way */
 /* Tolerance mode.  Default (flag clear): every output is bit-identical to the CPU restatement of the reference (oracle/) — the
