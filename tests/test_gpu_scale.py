@@ -368,7 +368,10 @@ def test_dead_and_pilotless_channels_do_not_change_their_neighbours(pkg):
     rng = np.random.default_rng(3)
     noise = (2.0 * rng.standard_normal((n, 2))).astype(np.float32)
     zero = np.zeros((n, 2), np.float32)
-    caps = np.stack([good[0], nopilot, good[1], zero, noise, good[2], zero])
+    # (a dead front end whose zeros carry signs — 0 x a signed factor, what bench.py's dead channels are: atan2(+-0, +-0) is 0 or +-pi, the
+    #  discriminator turns that into full-scale impulses, the pilot loop never locks: no NaN anywhere, every bit the oracle's)
+    szero = np.where(rng.random((n, 2)) < 0.5, np.float32(0.0), np.float32(-0.0)).astype(np.float32)
+    caps = np.stack([good[0], nopilot, good[1], zero, noise, good[2], zero, szero])
     rep = compare_with_oracle(pkg, caps, bs, 256_000)
     bad = {k: v for k, v in rep["bit_exact"].items() if not v}
     # NaN payloads are not part of the contract: a stream of a dead channel counts as equal when both sides are NaN in the same places
