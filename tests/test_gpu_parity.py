@@ -415,6 +415,24 @@ def test_pilot_pll_kernel_follows_what_is_out_of_lock(pkg, thresholds, calm, bus
     assert seen[-2:] == [calm, calm], seen                                          # back in lock
 
 
+@pytest.mark.parametrize("thresholds", [None, (2, 7168), (2, 2)])
+def test_loops_that_wander_in_and_out_of_lock(pkg, thresholds):
+    """Stations whose pilot loop neither holds lock nor loses it for good — receiver noise only, a pilot at the noise floor, a dead front end
+    whose zeros carry signs — next to a normal station, sixteen blocks: the wavefront changes between the constant-word and the sequence form
+    chunk by chunk, and (with the test hook's thresholds) the library between the 8- and 16-lane and the low-work kernels block by block.
+    Whatever ran, every stream is the oracle's bit for bit."""
+    n, bs = 16 * 16384, 16384
+    rng = np.random.default_rng(77)
+    caps = np.stack([
+        synth.to_cf32(synth.fm_capture(n, fs=256_000.0, seed=601, channel=0)["iq"]),
+        (0.02 * rng.standard_normal((n, 2))).astype(np.float32),
+        synth.to_cf32(synth.fm_capture(n, fs=256_000.0, seed=603, channel=2, pilot_level=0.02, noise_sigma=0.3)["iq"]),
+        np.where(rng.random((n, 2)) < 0.5, np.float32(0.0), np.float32(-0.0)).astype(np.float32),
+        synth.to_cf32(synth.fm_capture(n, fs=256_000.0, seed=605, channel=4, pilot_level=0.01, noise_sigma=0.1)["iq"]),
+    ])
+    _assert_exact(compare_with_oracle(pkg, caps, bs, 256_000, pll_k16_max=thresholds))
+
+
 def test_blocks_with_more_symbols_than_the_sign_buffer_holds(pkg):
     """k_rds_sync buffers the symbols' signs for the Manchester decoder in LDS, 1024 per station; a block of
     131072 samples at 256 kSa/s (8192 RDS samples, ~1200 symbols; ~1790 at the symbol clock's upper rail) overflows one buffer, so the
