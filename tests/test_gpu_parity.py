@@ -433,6 +433,17 @@ def test_loops_that_wander_in_and_out_of_lock(pkg, thresholds):
     _assert_exact(compare_with_oracle(pkg, caps, bs, 256_000, pll_k16_max=thresholds))
 
 
+@pytest.mark.parametrize("fs,u8", [(1_024_000, True), (2_048_000, False)])
+def test_loops_out_of_lock_behind_the_first_decimator(pkg, fs, u8):
+    """The same at the reference's own rate and capture format (u8 at 1.024 MSa/s) and at 2.048 MSa/s: a station without pilot and one whose pilot is
+    130 Hz off, next to a normal one; the sequence form from the second block on, bit-identical."""
+    bs = fs * 64 // 1000
+    conv = synth.to_u8 if u8 else synth.to_cf32
+    caps = np.stack([conv(synth.fm_capture(6 * bs, fs=float(fs), seed=950 + c, channel=c, **kw)["iq"])
+                     for c, kw in enumerate([{}, {"pilot_level": 0.0}, {"pilot_hz": 19130.0}])])
+    _assert_exact(compare_with_oracle(pkg, caps, bs, fs))
+
+
 def test_blocks_with_more_symbols_than_the_sign_buffer_holds(pkg):
     """k_rds_sync buffers the symbols' signs for the Manchester decoder in LDS, 1024 per station; a block of
     131072 samples at 256 kSa/s (8192 RDS samples, ~1200 symbols; ~1790 at the symbol clock's upper rail) overflows one buffer, so the
