@@ -26,11 +26,11 @@ def oracle_controls(ctl) -> O.Controls:
 
 
 def run_gpu(pkg, caps: np.ndarray, block_size: int, fs: int, use_torch: bool = False, controls=None, per_channel_controls=None,
-            pll_kernel: str = "auto", fast_math: bool = False, split_front: bool = False, pll_k16_max=None):
+            pll_kernel: str = "auto", fast_math: bool = False, split_front: bool = False, pll_k16_max=None, pipelined: bool = True):
     """caps: [C, n, 2] float32 or uint8.  Returns dict of per-block concatenated streams [C, ...]."""
     n_ch = caps.shape[0]
     nb = caps.shape[1] // block_size
-    dm = pkg.BatchDemod(n_ch, block_size, fs, keep_taps=True, pll_kernel=pll_kernel, fast_math=fast_math)
+    dm = pkg.BatchDemod(n_ch, block_size, fs, keep_taps=True, pll_kernel=pll_kernel, fast_math=fast_math, pipelined=pipelined)
     if pll_k16_max is not None:       # (include/fmdemod_debug.h: the pilot-PLL kernel by what is out of lock, from these batch sizes on)
         dm.pll_adaptive(*pll_k16_max) if isinstance(pll_k16_max, tuple) else dm.pll_adaptive(pll_k16_max)
     if split_front:       # (include/fmdemod_debug.h: the first decimator and the front end as two kernels)
@@ -77,10 +77,10 @@ def run_gpu(pkg, caps: np.ndarray, block_size: int, fs: int, use_torch: bool = F
 
 
 def compare_with_oracle(pkg, caps: np.ndarray, block_size: int, fs: int, use_torch: bool = False, controls=None,
-                        per_channel_controls=None, pll_kernel: str = "auto", pll_k16_max=None) -> dict:
+                        per_channel_controls=None, pll_kernel: str = "auto", pll_k16_max=None, pipelined: bool = True) -> dict:
     n_ch = caps.shape[0]
     u8 = caps.dtype == np.uint8
-    g = run_gpu(pkg, caps, block_size, fs, use_torch, controls, per_channel_controls, pll_kernel, pll_k16_max=pll_k16_max)
+    g = run_gpu(pkg, caps, block_size, fs, use_torch, controls, per_channel_controls, pll_kernel, pll_k16_max=pll_k16_max, pipelined=pipelined)
     report = {"bit_exact": {}, "max_abs": {}, "audio_rms_err": 0.0, "rds_sym_equal_counts": True, "rds_bytes_equal": True}
     for c in range(n_ch):
         ctl = (per_channel_controls or {}).get(c, controls)

@@ -415,8 +415,8 @@ def test_pilot_pll_kernel_follows_what_is_out_of_lock(pkg, thresholds, calm, bus
     assert seen[-2:] == [calm, calm], seen                                          # back in lock
 
 
-@pytest.mark.parametrize("thresholds", [None, (2, 7168), (2, 2)])
-def test_loops_that_wander_in_and_out_of_lock(pkg, thresholds):
+@pytest.mark.parametrize("thresholds,pipelined", [(None, True), ((2, 7168), True), ((2, 2), True), ((2, 2), False)])
+def test_loops_that_wander_in_and_out_of_lock(pkg, thresholds, pipelined):
     """Stations whose pilot loop neither holds lock nor loses it for good — receiver noise only, a pilot at the noise floor, a dead front end
     whose zeros carry signs — next to a normal station, sixteen blocks: the wavefront changes between the constant-word and the sequence form
     chunk by chunk, and (with the test hook's thresholds) the library between the 8- and 16-lane and the low-work kernels block by block.
@@ -430,7 +430,7 @@ def test_loops_that_wander_in_and_out_of_lock(pkg, thresholds):
         np.where(rng.random((n, 2)) < 0.5, np.float32(0.0), np.float32(-0.0)).astype(np.float32),
         synth.to_cf32(synth.fm_capture(n, fs=256_000.0, seed=605, channel=4, pilot_level=0.01, noise_sigma=0.1)["iq"]),
     ])
-    _assert_exact(compare_with_oracle(pkg, caps, bs, 256_000, pll_k16_max=thresholds))
+    _assert_exact(compare_with_oracle(pkg, caps, bs, 256_000, pll_k16_max=thresholds, pipelined=pipelined))      # (not pipelined: FMD_FLAG_NO_PIPELINE, every stage on the caller's stream)
 
 
 @pytest.mark.parametrize("fs,u8", [(1_024_000, True), (2_048_000, False)])
