@@ -1479,26 +1479,16 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
     int n_spans = 0;
     bool seq_form = false;       // (second loop) wave-uniform: the spans run in the sequence form (below)
     unsigned long long n_seq_spans = 0;
+    int q_resume = 0, slow_run = 0;   // the first chunk for the second loop; slow chunks in a row
+    bool handed_over = false;    // the first loop met a loop out of lock and left the rest of the block to the second
     if (!SEQCAP) {
-    // ---- the constant-word form with the serial fall-back (round 3), for a wavefront whose stations all held lock through the previous block ----
+    // ---- the constant-word form (round 3's span), for a wavefront whose stations all held lock through the previous block.  Two chunks in a row that
+    // needed more than 3x the fewest spans say a loop is out of lock: the rest of the block goes to the second loop (round 3 ran serial chunks from
+    // the first such chunk on: 3.6 ms for the block in which a station loses lock; now ~1.3) ----
     for (int q = 0; q < chunks; q++) {
         const int cend = (q + 1) * CH;
         int spans = 0;
-        const bool speculative = seq_left == 0;
-        if (!speculative) {
-            // ---- out of lock: the plain serial iteration, computed identically by the 16 lanes of a channel ----
-            seq_left--; n_seq++;
-            PllState S{lx1, ly1, integ, err_prev, tph_prev};
-            while (__builtin_amdgcn_ballot_w64(pos < cend) != 0ull) {
-                if (pos < cend) {
-                    const float2 x = xin[g][pos & (RING - 1)];
-                    dts[g][pos & (RING - 1)] = pll_step(S, gain * x.x, gain * x.y, k);
-                    pos++;
-                }
-            }
-            lx1 = S.lx1; ly1 = S.ly1; integ = S.integ; err_prev = S.err; tph_prev = S.tph;
-            ex[g][0] = err_prev;
-        } else {
+        {
             while (__builtin_amdgcn_ballot_w64(pos < cend) != 0ull) {
                 const bool active = pos < cend;
                 const int rem = n - pos;                             // samples left in the block for this channel
@@ -1603,14 +1593,14 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
         }
         FMD_PLL_STASH(q + 2)
         FMD_PLL_FETCH(q + 3)
-        if (speculative) {   // a speculative chunk that went badly sends the wavefront serial for a while, doubling each time in a row
-            n_spans += spans;
-            if (spans > kPllSlowSpans) { seq_left = hold ? hold : 1; hold = hold ? (2 * hold < kSlowHoldMax ? 2 * hold : kSlowHoldMax) : 1; }
-            else hold = 0;
-        }
+        n_spans += spans;
+        slow_run = spans > kPllSlowSpans ? slow_run + 1 : 0;        // (two in a row: a single slow chunk is what a loop in lock has now and then)
+        if (slow_run >= 2) { q_resume = q + 1; handed_over = true; break; }
     }
-    } else {
-    // ---- the same with the sequence form for loops out of lock (round 6), for a wavefront that left the previous block out of lock ----
+    }
+    if (SEQCAP || handed_over) {
+    // ---- the same with the sequence form for loops out of lock (round 6): a wavefront that left the previous block out of lock, or met such a loop above ----
+    seq_form = handed_over;
     int stuck = 0;               // wave-uniform: consecutive sequence-form spans in which some channel committed one sample
     // One span of every channel of the wavefront: (A)-(D) above.
     // seq (round 6) — the form for a loop OUT of lock (a station without a pilot, acquisition): the frequency word then moves on every sample
@@ -1772,7 +1762,7 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
         }
         ex[g][0] = err_prev;
     };
-    for (int q = 0; q < chunks; q++) {
+    for (int q = q_resume; q < chunks; q++) {
         const int cend = (q + 1) * CH;
         int spans = 0;
         bool serial = seq_left > 0;
@@ -1848,7 +1838,7 @@ __device__ __forceinline__ void pilot_pll_body(Dims d, const float2* __restrict_
     // (back to the other body only after a block that never left the constant-word form: a loop that wanders in and out of lock keeps this one)
     // (per station, so that the 16- and the 8-lane kernel can follow one another: fmd_api.cpp picks the lane count by what is out of lock)
     if (hint) {
-        const unsigned int out = (n_seq != 0ull || n_seq_spans != 0ull) ? 1u : 0u;
+        const unsigned int out = (n_seq != 0ull || n_seq_spans != 0ull || handed_over) ? 1u : 0u;
         if (live && j == 0) hint[c] = out;
         // [C]: the newest launch in which a wavefront spent a quarter of the block or more out of lock, [C + 1]: the newest launch that has run — the
         // host watches the distance (a chunk or two in the other form is what any loop does now and then: not counted)

@@ -71,8 +71,8 @@ typedef struct {
  * know: a station WITHOUT a lockable pilot (mono station, empty channel, dead input) cannot be advanced under the locked loop's
  * "the frequency word stays put" speculation; its wavefront speculates on the SEQUENCE of words instead (round 6; the serial
  * 78-operation iteration before, ~4x), at about 1.4x a locked wavefront's time, and one such wavefront sets the kernel's duration:
- * 0.89 -> 1.06-1.20 ms per 4096-station block from 1 % unlocked stations on (the first block after a station
- * loses lock still runs the serial iteration; small batches, where that kernel's latency is the step, pay ~1.9x): a band scan,
+ * 0.89 -> 1.06-1.20 ms per 4096-station block from 1 % unlocked stations on (small batches, where that
+ * kernel's latency is the step, pay ~1.5x): a band scan,
  * where most channels are empty, still wants the tolerance mode, whose cost does not depend on lock at all.
  * With the flag the chain keeps the reference's signal flow and state variables but uses cheaper arithmetic: minimax arctangent,
  * hardware sine/cosine, the FIRs as bf16 x 3 products on the matrix cores (fp32 accumulation, ~1e-6 relative), the pilot peak filter

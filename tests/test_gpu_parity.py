@@ -353,7 +353,7 @@ def test_pll_speculation_commits_long_spans_in_lock_and_short_ones_before(pkg):
     dm.close()
     assert per_block[0]["chunks"] == 8192 // 128
     assert per_block[-1]["samples"] == 2 * 8192                     # every sample of both channels went through a span
-    assert per_block[0]["samples_per_span"] < 12.0                  # acquisition: the frequency word moves all the time
+    assert per_block[0]["samples_per_span"] < 12.0 or per_block[0]["sequence_spans"] > 0   # acquisition: the frequency word moves all the time
     locked = per_block[-4:]
     assert all(p["samples_per_span"] > 13.5 for p in locked), locked  # in lock: it changes on ~0.5 % of the samples
     assert sum(p["serial_chunks"] for p in locked) == 0
@@ -363,8 +363,8 @@ def test_pll_speculation_commits_long_spans_in_lock_and_short_ones_before(pkg):
 def test_loops_out_of_lock_run_the_sequence_form_not_the_serial_iteration(pkg, pll_kernel, k):
     """Round 6: a station that cannot hold lock moves its NCO frequency word on every sample, so "the word stays put" commits
     one sample a span; its wavefront then speculates on the SEQUENCE of words (a guess pass, then the exact pass confirms word by word) and
-    commits whole spans again.  From the second block on (the first finds out, with round 3's serial fall-back): no serial chunks, the
-    sequence form on every span, nearly K samples per span — next to a normal station in the same wavefront, and bit-identical to the
+    commits whole spans again.  From the second block on (the first finds out in its first chunk and hands the rest to the other loop): no serial
+    chunks anywhere, the sequence form on every span, nearly K samples per span — next to a normal station in the same wavefront, and bit-identical to the
     oracle (the serial restatement of the reference)."""
     nb, bs = 6, 16384
     rows = [synth.to_cf32(synth.fm_capture(nb * bs, fs=256_000.0, seed=900 + c, channel=c, **kw)["iq"])
@@ -377,7 +377,7 @@ def test_loops_out_of_lock_run_the_sequence_form_not_the_serial_iteration(pkg, p
         dm.process(caps[:, b * bs:(b + 1) * bs])
         per_block.append(dm.spec_stats(reset=True)["pll"])
     dm.close()
-    assert per_block[0]["serial_chunks"] > 0 and per_block[0]["sequence_spans"] == 0        # the block that finds out
+    assert per_block[0]["serial_chunks"] == 0 and per_block[0]["sequence_spans"] > 0        # the block that finds out: one slow chunk, then the sequence form
     for p in per_block[1:]:
         assert p["serial_chunks"] == 0, per_block
         assert p["sequence_spans"] >= 0.95 * (bs // 2) / k, per_block                       # (one wavefront: its spans are the slowest station's)
