@@ -460,8 +460,11 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--preroll", type=int, default=16, help="blocks demodulated before the warmup so the loops are in lock "
-                    "(a receiver's steady state; 16 blocks = 1 s of signal).  Untimed, like the warmup")
+    ap.add_argument("--preroll", type=int, default=128, help="blocks demodulated before the warmup, untimed like it: the pilot / RDS loops acquire lock "
+                    "(a receiver's steady state; 16 blocks = 1 s of signal) and the GPU reaches its steady clocks — from idle the shader clock "
+                    "is ~1.6 GHz over the first 5 ms and 2.0-2.2 GHz from ~25 ms of load on, so a 20-step timed region right behind a "
+                    "16-block lead-in measured the ramp (258 GSa/s against 273-280 behind 100-200 blocks and 291 sustained over "
+                    "12000 steps: profiles/round6/preroll_sweep.txt)")
     ap.add_argument("--channels", type=int, default=4096, help="channels PER GPU (BASELINE configs[2]: 4096)")
     ap.add_argument("--fs", type=int, default=256000, choices=[256000, 1024000, 2048000])
     ap.add_argument("--block", type=int, default=0, help="baseband samples per channel per step (default: 64 ms)")
