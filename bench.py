@@ -379,8 +379,8 @@ def measure_config(torch, pkg, device, label: str, C: int, fs: int, u8: bool, fa
     lock, fmd_submit_*_dev, HIP-event kernel times on every 4th block), shorter.  Returns ms_per_step, MSa/s, the dominant kernel's and the
     whole step's fraction of the HBM roofline on algorithmic bytes."""
     block = fs * 64 // 1000
-    if fs == 256_000 and C >= 1024 and fast:
-        preroll = max(preroll, 64)      # (the lead-in also brings the GPU to its steady clocks: ~25 ms of load — profiles/round6/preroll_sweep.txt)
+    if C >= 1024 and fast:
+        preroll = max(preroll, 64 if fs == 256_000 else 48)      # (the lead-in also brings the GPU to its steady clocks: ~25 ms of load — profiles/round6/preroll_sweep.txt)
     n_res = 2 if fs > 256_000 else min(8, steps + preroll + warmup)
     x = synth_block_device(torch, C, n_res * block, float(fs), 4321, device, u8)
     x = x.view(C, n_res, block, 2).permute(1, 0, 2, 3).contiguous()
